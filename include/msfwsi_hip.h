@@ -1,0 +1,168 @@
+/* C ABI of libmsfwsi_hip.so: the gfx950 (MI355X) kernels behind the MSF-WSI pre-train step.
+ *
+ * The reference (Dylan-H-Wang/msf-wsi) has no FFI of its own: its hot path reaches the device through
+ * torch operators called from src/models/{resnet,backbone}.py and tools/ssl_train.py.  Each entry point
+ * below therefore names the reference operator call it replaces (file:line into the reference tree).
+ * The Python host (msf_wsi_amd/) binds these with ctypes; see INTEGRATION.md for the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch's caching allocator); the library
+ *     never allocates, frees or synchronises; `stream` is a hipStream_t passed as void*.
+ *   - return value: 0 ok; <0 invalid argument (-1) / unsupported configuration (-2); >0 a hipError_t.
+ *   - re-entrant and stateless: safe to call from the forward thread and autograd's backward thread.
+ *   - activations are NHWC ("channels last"), viewed as [M = N*H*W][C]; dtype selects the storage type
+ *     of activations AND weights (MSFWSI_DT_F32 exact-fp32 MFMA path, MSFWSI_DT_BF16 bf16 MFMA with fp32
+ *     accumulation); per-channel vectors, statistics and weight gradients are always fp32 / fp64.
+ *   - channel counts must be multiples of one 16-byte chunk (4 fp32 / 8 bf16 elements).
+ */
+#ifndef MSFWSI_HIP_H
+#define MSFWSI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSFWSI_DT_F32 0
+#define MSFWSI_DT_BF16 1
+
+/* Geometry of one convolution (a Linear layer is R=S=1, H=W=1, N=rows). */
+typedef struct msfwsi_conv_desc {
+    int dtype;
+    int N, H, W, C; /* input  [N,H,W,C]   */
+    int P, Q, K;    /* output [N,P,Q,K]   */
+    int R, S, stride, pad;
+} msfwsi_conv_desc;
+
+/* ---- dense contractions (MFMA) ------------------------------------------------------------------ */
+
+/* y = conv(act(x), w) [+ bias];  act = relu(pro_scale[c]*x + pro_shift[c]) when pro_* != NULL (the
+ * producer's BatchNorm+ReLU fused into the operand load; padding stays zero).  w: [K][R][S][C].
+ * stats != NULL: adds per-channel sum(y) and sum(y*y) of the STORED outputs into
+ * stats[blockshard][2][K] (fp64, caller zeroes; nshard replicas spread the atomics).
+ * Replaces: conv3x3/conv1x1/conv1 forward, src/models/resnet.py:25-33,174,232-242 (+ the statistics
+ * half of the following nn.BatchNorm2d in train mode, resnet.py:68-77,124-134) and nn.Linear forward,
+ * src/models/backbone.py:12-31,161-186,205-212. */
+int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, const float* pro_scale,
+                    const float* pro_shift, const float* bias, double* stats, int nshard, void* stream);
+
+/* dx = conv_transpose(dy, w) [+ resid] [+ gap_scale * gapg[image]]  (input gradient).  w is the forward
+ * weight [K][R][S][C], read in place as the [k][n] operand.  resid: [N,H,W,C] added element-wise (the
+ * identity-path gradient of a residual block); gapg: [N][C] broadcast over H*W (global-average-pool
+ * gradient).  Replaces: autograd's convolution_backward(input) / linear backward(input) reached through
+ * scaler.scale(loss).backward(), tools/ssl_train.py:472. */
+int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx, const void* resid,
+                      const void* gapg, float gap_scale, void* stream);
+
+/* dw[K][R][S][C] (fp32) += dy^T * act(x)   (weight gradient, split over pixels, fp32 atomics).
+ * target_blocks: workgroup budget used to pick the split factor (<=0: default).
+ * Replaces: convolution_backward(weight) / linear backward(weight), tools/ssl_train.py:472. */
+int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* pro_scale,
+                      const float* pro_shift, int target_blocks, void* stream);
+
+/* ---- BatchNorm (training mode) ------------------------------------------------------------------ */
+
+/* sums[nshard][2][C] (fp64: sum, sum of squares over `count` elements per channel) -> scale/shift
+ * (gamma*invstd, beta-mean*scale), mean, invstd; updates running_mean/var (momentum, unbiased variance)
+ * and num_batches_tracked when non-NULL.  gamma/beta NULL = affine=False.
+ * Replaces: F.batch_norm(training=True) statistics of nn.BatchNorm2d / BatchNorm1d / SyncBatchNorm,
+ * src/models/resnet.py:175 etc., src/models/backbone.py:15,18,21,28; tools/ssl_train.py:160. */
+int msfwsi_bn_finalize(const double* sums, int nshard, int C, double count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var,
+                       long* num_batches_tracked, float* scale, float* shift, float* mean, float* invstd,
+                       void* stream);
+
+/* out[n] = sum over nshard replicas of in[shard][n]: packs the cross-replica (SyncBatchNorm) message. */
+int msfwsi_shard_sum(const double* in, int nshard, int n, double* out, void* stream);
+
+/* out = act(scale*c + shift [+ ident | + id_scale*ident + id_shift]); relu != 0 applies ReLU.
+ * Replaces: bn2/bn3 apply + residual add + ReLU, resnet.py:76-80,131-138 (id_scale: the downsample
+ * branch's BatchNorm, resnet.py:222-225); final projector BatchNorm1d(affine=False), backbone.py:21. */
+int msfwsi_bn_act(int dtype, const void* c, const float* scale, const float* shift, const void* ident,
+                  const float* id_scale, const float* id_shift, int relu, void* out, long M, int C, void* stream);
+
+/* Backward at a residual-block output y = relu(bn(c_main) + identity):
+ * g = (dy + gap_scale*gapg[image]) * (y>0); sums[shard][3][C] += {sum g, sum g*c_main, sum g*c_ds}.
+ * dy or gapg may be NULL (not both), c_ds may be NULL. */
+int msfwsi_block_end_bwd(int dtype, const void* dy, const void* y, const void* gapg, float gap_scale,
+                         const void* c_main, const void* c_ds, void* g, double* sums, int nshard, long M, int HW,
+                         int C, void* stream);
+
+/* Backward through an inner activation relu(scale*c+shift): g = da * (scale*c+shift > 0) (g may alias
+ * da); sums[shard][2][C] += {sum g, sum g*c}.  scale == NULL: no activation (g not written, g = da). */
+int msfwsi_act_bwd_reduce(int dtype, const void* da, const void* c, const float* scale, const float* shift,
+                          void* g, double* sums, int nshard, long M, int C, void* stream);
+
+/* BatchNorm backward coefficients: dc = k1*g + k2*c + k3; dgamma += sum g*xhat; dbeta += sum g.
+ * sums[nshard][nslots][C]; `which` picks the g*c slot (1, or 2 for the downsample branch). */
+int msfwsi_bn_bwd_finalize(const double* sums, int nshard, int nslots, int which, int C, double count,
+                           const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                           float* dbeta, float* k1, float* k2, float* k3, void* stream);
+
+/* dc = k1[c]*g + k2[c]*c + k3[c]  (batch_norm_backward input gradient). */
+int msfwsi_bn_bwd_apply(int dtype, const void* g, const void* c, const float* k1, const float* k2,
+                        const float* k3, void* dc, long M, int C, void* stream);
+
+/* ---- stem / pooling / data movement --------------------------------------------------------------- */
+
+/* fp32 NCHW image batch -> NHWC storage type with channels zero-padded to CP.
+ * Replaces the layout the batch of tools/ssl_train.py:430-438 has when it enters conv1. */
+int msfwsi_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, int CP, void* stream);
+
+/* out = maxpool3x3/s2/p1(relu(scale*c0+shift)); argmax = window slot (0..8) of the first maximum.
+ * Replaces: bn1 apply + relu + maxpool, src/models/resnet.py:235-237. */
+int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scale, const float* shift, void* out,
+                         unsigned char* argmax, int N, int H, int W, int C, void* stream);
+
+/* g0 = relu'(.) * maxpool_backward(dp); sums[shard][2][C] += {sum g0, sum g0*c0}. */
+int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax, const void* c0,
+                         const float* scale, const float* shift, void* g0, double* sums, int nshard, int N, int H,
+                         int W, int C, void* stream);
+
+/* out[n][c] = mean over HW of y[n][hw][c].  Replaces: AdaptiveAvgPool2d((1,1)) + flatten on the four
+ * stage outputs, src/models/resnet.py:244-250. */
+int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW, int C, void* stream);
+
+/* column sums of x[M][C] added into sums[C] (fp64) -- bias gradient of backbone.py:30's Linear. */
+int msfwsi_colsum(int dtype, const void* x, double* sums, long M, int C, void* stream);
+int msfwsi_add_f64_to_f32(const double* in, float* out, int n, float alpha, void* stream);
+
+/* scatter == 0: out[b*K+k] = in[b*K+idx[b][k]] (jigsaw un-shuffle, src/models/backbone.py:147-158);
+ * scatter == 1: its adjoint, out[b*K+idx[b][k]] (+)= in[b*K+k].  idx: int64 [B][K] on the device. */
+int msfwsi_rows_permute(int dtype, const void* in, const long* idx, void* out, int B, int K, int C, int scatter,
+                        int accumulate, void* stream);
+
+/* dst[r][0:cols] (+)= src[r][0:cols] with row strides (fuser concat, backbone.py:195-202, and adjoint). */
+int msfwsi_copy2d(int dtype, const void* src, long src_ld, void* dst, long dst_ld, long rows, int cols,
+                  int accumulate, void* stream);
+
+/* ---- loss / optimizer ------------------------------------------------------------------------- */
+
+/* *loss_accum += coef * sum_rows cos(p_row, z_row);  dp = (*loss_scale) * coef * dcos/dp  (z constant:
+ * stop-gradient).  Replaces: nn.CosineSimilarity(dim=1)(p, z).mean() terms and their backward,
+ * tools/ssl_train.py:422,448-466; coef = -0.5 * fuser_weight / rows. */
+int msfwsi_cosine_loss(int dtype, const void* p, const void* z, long rows, int d, float coef,
+                       const float* loss_scale, float eps, double* loss_accum, void* dp, void* stream);
+
+/* GradScaler pieces (tools/ssl_train.py:100,472-474): *found = 1 if any gradient is inf/nan; scale update. */
+int msfwsi_nonfinite_check(const float* g, long n, float* found, void* stream);
+int msfwsi_scaler_update(float* scale, int* growth_tracker, const float* found, float growth_factor,
+                         float backoff_factor, int growth_interval, void* stream);
+
+/* One Adam step over a flat fp32 parameter group (torch.optim.Adam defaults, tools/ssl_train.py:309,473);
+ * grads are divided by *loss_scale, the step is skipped when *found > 0; p_bf16 != NULL also refreshes
+ * the bf16 compute copy. */
+int msfwsi_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                float eps, long step, const float* loss_scale, const float* found, void* p_bf16, void* stream);
+
+int msfwsi_cast_bf16(const float* src, void* dst, long n, void* stream);
+int msfwsi_pad_cast(int dtype, const float* src, void* dst, long rows, int C, int CP, void* stream);
+int msfwsi_unpad_add(const float* src, float* dst, long rows, int C, int CP, void* stream);
+
+/* library identification: returns the gfx target string the code objects were built for */
+const char* msfwsi_target(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSFWSI_HIP_H */

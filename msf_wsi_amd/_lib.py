@@ -1,0 +1,112 @@
+"""ctypes binding of libmsfwsi_hip.so (C ABI declared in include/msfwsi_hip.h).
+
+The product path has no CPU or eager-torch fallback: if the shared library is missing or a symbol is
+absent, loading raises and every engine entry point fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsfwsi_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+DT_F32 = 0
+DT_BF16 = 1
+
+
+class ConvDesc(C.Structure):
+    """mirror of `msfwsi_conv_desc`"""
+
+    _fields_ = [(n, C.c_int) for n in ("dtype", "N", "H", "W", "C", "P", "Q", "K", "R", "S", "stride", "pad")]
+
+
+class MsfwsiHipError(RuntimeError):
+    pass
+
+
+_vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+_desc = C.POINTER(ConvDesc)
+
+# name -> argtypes; must list every symbol declared in include/msfwsi_hip.h
+SIGNATURES = {
+    "msfwsi_conv_fwd": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_conv_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _f, _vp],
+    "msfwsi_conv_wgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_bn_finalize": [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "msfwsi_shard_sum": [_vp, _i, _i, _vp, _vp],
+    "msfwsi_bn_act": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
+    "msfwsi_block_end_bwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _vp],
+    "msfwsi_act_bwd_reduce": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp],
+    "msfwsi_bn_bwd_finalize": [_vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "msfwsi_bn_bwd_apply": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
+    "msfwsi_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "msfwsi_stem_pool_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "msfwsi_stem_pool_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "msfwsi_gap_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "msfwsi_colsum": [_i, _vp, _vp, _l, _i, _vp],
+    "msfwsi_add_f64_to_f32": [_vp, _vp, _i, _f, _vp],
+    "msfwsi_rows_permute": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "msfwsi_copy2d": [_i, _vp, _l, _vp, _l, _l, _i, _i, _vp],
+    "msfwsi_cosine_loss": [_i, _vp, _vp, _l, _i, _f, _vp, _f, _vp, _vp, _vp],
+    "msfwsi_nonfinite_check": [_vp, _l, _vp, _vp],
+    "msfwsi_scaler_update": [_vp, _vp, _vp, _f, _f, _i, _vp],
+    "msfwsi_adam": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _l, _vp, _vp, _vp, _vp],
+    "msfwsi_cast_bf16": [_vp, _vp, _l, _vp],
+    "msfwsi_pad_cast": [_i, _vp, _vp, _l, _i, _i, _vp],
+    "msfwsi_unpad_add": [_vp, _vp, _l, _i, _i, _vp],
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH) or _stale():
+        subprocess.run(["make", "-C", CSRC_DIR, "-j4"], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _stale() -> bool:
+    try:
+        t = os.path.getmtime(LIB_PATH)
+        srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h"))]
+        srcs.append(os.path.join(_HERE, "..", "include", "msfwsi_hip.h"))
+        return any(os.path.getmtime(s) > t for s in srcs)
+    except OSError:
+        return True
+
+
+def load() -> C.CDLL:
+    """dlopen the library and type every entry point; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsfwsiHipError(
+            f"{LIB_PATH} not found: build it with `make -C {CSRC_DIR}` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the MSF-WSI hot path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MsfwsiHipError(f"symbol {name} missing from {LIB_PATH}") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.msfwsi_target.argtypes = []
+    lib.msfwsi_target.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        kind = {-1: "invalid argument", -2: "unsupported configuration"}.get(rc, "error")
+        raise MsfwsiHipError(f"{what}: {kind} (rc={rc})")
+    raise MsfwsiHipError(f"{what}: hipError_t {rc}")

@@ -1,0 +1,786 @@
+// Streaming (HBM-bound) kernels of the MSF-WSI pre-train step on gfx950: BatchNorm finalize / apply /
+// backward, residual add + ReLU, stem max-pool, global average pool, jigsaw row gather, 2-D copies.
+// All activation tensors are NHWC viewed as [M][C] with C contiguous; every thread moves 16-byte chunks.
+// Per-channel reductions: a thread owns one 16-byte channel chunk and walks rows; partials are combined
+// through LDS and leave as fp64 atomics into `nshard` replicas (memory-side atomics, spread over rows).
+#include "common.h"
+#include "../../include/msfwsi_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------------
+// column-reduction scaffolding
+// ---------------------------------------------------------------------------------------------
+struct ColGrid {
+    int cw;         // chunk columns handled by one block
+    int nrl;        // row lanes per block
+    int rows_per_block;
+    dim3 grid;
+};
+
+inline ColGrid make_col_grid(long M, int C, int vec, int target_blocks) {
+    ColGrid g;
+    const int cpr = C / vec;
+    g.cw = cpr < kThreads ? cpr : kThreads;
+    g.nrl = kThreads / g.cw;
+    const int colblocks = (cpr + g.cw - 1) / g.cw;
+    long rowblocks = target_blocks / colblocks;
+    if (rowblocks < 1) rowblocks = 1;
+    long rpb = (M + rowblocks - 1) / rowblocks;
+    if (rpb < g.nrl) rpb = g.nrl;
+    rowblocks = (M + rpb - 1) / rpb;
+    if (rowblocks > 65535) {
+        rowblocks = 65535;
+        rpb = (M + rowblocks - 1) / rowblocks;
+        rowblocks = (M + rpb - 1) / rpb;
+    }
+    g.rows_per_block = (int)rpb;
+    g.grid = dim3((unsigned)colblocks, (unsigned)rowblocks);
+    return g;
+}
+
+// combine per-thread partial sums acc[NS][VEC] over the block's row lanes and add them (fp64 atomics)
+// to sums[shard][NS][C].  smem must hold kThreads*NS*VEC floats.
+template <int NS, int VEC>
+__device__ __forceinline__ void col_commit(float (&acc)[NS][VEC], float* smem, int cw, int nrl, int cc, int rl,
+                                           bool active, int chan0, int C, double* sums, int nshard) {
+    const int tid = threadIdx.x;
+    if (nrl > 1) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) smem[(s * VEC + e) * kThreads + tid] = active ? acc[s][e] : 0.f;
+        __syncthreads();
+        if (active && rl == 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float t = 0.f;
+                    for (int r = 0; r < nrl; ++r) t += smem[(s * VEC + e) * kThreads + r * cw + cc];
+                    acc[s][e] = t;
+                }
+        }
+    }
+    if (active && rl == 0) {
+        double* base = sums + (long)(blockIdx.y % nshard) * NS * C;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) atomicAdd(base + (long)s * C + chan0 + e, (double)acc[s][e]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW fp32 image -> NHWC (channel-padded) storage type.  reference: the H2D'd batch of
+// tools/ssl_train.py:430-438 entering conv1 (src/models/resnet.py:174,234)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int HW, int CP) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const long total = (long)N * HW * (CP / VEC);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % (CP / VEC));
+        const long pix = i / (CP / VEC);
+        const int n = (int)(pix / HW);
+        const int hw = (int)(pix - (long)n * HW);
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = cv * VEC + e;
+            f[e] = c < C ? x[((long)n * C + c) * HW + hw] : 0.f;
+        }
+        *reinterpret_cast<uint4*>(y + pix * CP + cv * VEC) = pack16<T>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm (training) finalize: sums -> mean / invstd / fused scale+shift, running-stat update.
+// reference: nn.BatchNorm2d / BatchNorm1d in train mode (resnet.py:175,59-62; backbone.py:15,18,21,28):
+// biased variance for normalisation, unbiased into running_var, momentum 0.1, eps 1e-5.
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int nshard, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, long* nbt,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt != nullptr) *nbt += 1;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nshard; ++k) {
+        s += sums[((long)k * 2 + 0) * C + c];
+        q += sums[((long)k * 2 + 1) * C + c];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma != nullptr ? gamma[c] : 1.f;
+    const float b = beta != nullptr ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// sum `nshard` replicas of a length-n fp64 vector (the packed message of the cross-replica exchange)
+__global__ void shard_sum_kernel(const double* __restrict__ in, int nshard, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < nshard; ++k) s += in[(long)k * n + i];
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = act(scale*c + shift [+ identity | + id_scale*identity + id_shift])
+// reference: bn2/bn3 + residual add + ReLU (resnet.py:76-80,131-138), and the projector's final
+// BatchNorm1d(affine=False) (backbone.py:21) with relu=0, identity=null
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_act_kernel(const T* __restrict__ c, const float* __restrict__ scale, const float* __restrict__ shift,
+                              const T* __restrict__ ident, const float* __restrict__ id_scale,
+                              const float* __restrict__ id_shift, int relu, T* __restrict__ out, long M, int C) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int cpr = C / VEC;
+    const long total = M * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr) * VEC;
+        float f[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(c + i * VEC), f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = fmaf(f[e], scale[ch + e], shift[ch + e]);
+        if (ident != nullptr) {
+            float g[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(ident + i * VEC), g);
+            if (id_scale != nullptr) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] += fmaf(g[e], id_scale[ch + e], id_shift[ch + e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] += g[e];
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[e] = fmaxf(f[e], 0.f);
+        }
+        *reinterpret_cast<uint4*>(out + i * VEC) = pack16<T>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem: out = maxpool3x3/s2/p1(relu(scale*c0+shift)), plus the window index of the first maximum
+// reference: bn1 -> relu -> maxpool (resnet.py:235-237)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void stem_pool_fwd_kernel(const T* __restrict__ c0, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, T* __restrict__ out,
+                                     unsigned char* __restrict__ amax, int N, int H, int W, int C, int P, int Q) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int cpr = C / VEC;
+    const long total = (long)N * P * Q * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cpr);
+        long pix = i / cpr;
+        const int q = (int)(pix % Q);
+        pix /= Q;
+        const int p = (int)(pix % P);
+        const int n = (int)(pix / P);
+        const int ch = cv * VEC;
+        float sc[VEC], sh[VEC], best[VEC];
+        int bidx[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sc[e] = scale[ch + e];
+            sh[e] = shift[ch + e];
+            best[e] = -INFINITY;
+            bidx[e] = 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int h = 2 * p - 1 + r;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int w = 2 * q - 1 + s;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float f[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(c0 + (((long)n * H + h) * W + w) * C + ch), f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    // round to the storage type first: the pooled value must equal a stored activation
+                    const float v = round_to<T>(fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f));
+                    if (v > best[e]) {
+                        best[e] = v;
+                        bidx[e] = r * 3 + s;
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(out + i * VEC) = pack16<T>(best);
+        unsigned char* ap = amax + i * VEC;
+        if (VEC == 8) {
+            uint2 pk;
+            pk.x = bidx[0] | (bidx[1] << 8) | (bidx[2] << 16) | (bidx[3] << 24);
+            pk.y = bidx[4 % VEC] | (bidx[5 % VEC] << 8) | (bidx[6 % VEC] << 16) | (bidx[7 % VEC] << 24);
+            *reinterpret_cast<uint2*>(ap) = pk;
+        } else {
+            *reinterpret_cast<unsigned*>(ap) = bidx[0] | (bidx[1] << 8) | (bidx[2] << 16) | (bidx[3] << 24);
+        }
+    }
+}
+
+// backward of the above: g0 = relu'(.) * sum over the (<= 4) windows that selected this pixel of dp,
+// plus the BatchNorm-backward sums  S1 = sum g0,  S2 = sum g0*c0
+template <typename T>
+__global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ amax,
+                                     const T* __restrict__ c0, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, T* __restrict__ g0, double* sums, int nshard,
+                                     int N, int H, int W, int C, int P, int Q, int cw, int nrl, int rows_per_block) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    extern __shared__ float smem_f[];
+    const int tid = threadIdx.x;
+    const int cc = tid % cw, rl = tid / cw;
+    const int chunk = blockIdx.x * cw + cc;
+    const bool active = rl < nrl && chunk * VEC < C;
+    const int ch = chunk * VEC;
+    float acc[2][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+        float sc[VEC], sh[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sc[e] = scale[ch + e];
+            sh[e] = shift[ch + e];
+        }
+        const long M = (long)N * H * W;
+        const long rbeg = (long)blockIdx.y * rows_per_block;
+        const long rend = rbeg + rows_per_block < M ? rbeg + rows_per_block : M;
+        for (long m = rbeg + rl; m < rend; m += nrl) {
+            const int w = (int)(m % W);
+            const long t = m / W;
+            const int h = (int)(t % H);
+            const int n = (int)(t / H);
+            float g[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+            // windows (p,q) with 2p-1 <= h <= 2p+1
+            const int p_lo = h >> 1, p_hi = (h + 1) >> 1;
+            const int q_lo = w >> 1, q_hi = (w + 1) >> 1;
+            for (int p = p_lo; p <= p_hi; ++p) {
+                if (p >= P) continue;
+                const int r = h - (2 * p - 1);
+                for (int q = q_lo; q <= q_hi; ++q) {
+                    if (q >= Q) continue;
+                    const int s = w - (2 * q - 1);
+                    const long o = (((long)n * P + p) * Q + q) * C + ch;
+                    float d[VEC];
+                    unpack16<T>(*reinterpret_cast<const uint4*>(dp + o), d);
+                    const unsigned char* ap = amax + o;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        if (ap[e] == r * 3 + s) g[e] += d[e];
+                }
+            }
+            float x[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(c0 + m * C + ch), x);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (!(fmaf(x[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
+                g[e] = round_to<T>(g[e]);
+                acc[0][e] += g[e];
+                acc[1][e] = fmaf(g[e], x[e], acc[1][e]);
+            }
+            *reinterpret_cast<uint4*>(g0 + m * C + ch) = pack16<T>(g);
+        }
+    }
+    col_commit<2, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
+}
+
+// ---------------------------------------------------------------------------------------------
+// global average pool over H*W (resnet.py:244-250): one wave per (image, 16-byte channel chunk)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gap_fwd_kernel(const T* __restrict__ y, T* __restrict__ out, int N, int HW, int C) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int cpr = C / VEC;
+    const int lane = threadIdx.x & 63;
+    const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    if (wid >= (long)N * cpr) return;
+    const int n = (int)(wid / cpr), cv = (int)(wid % cpr);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int i = lane; i < HW; i += 64) {
+        float f[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(y + ((long)n * HW + i) * C + cv * VEC), f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = wave_sum(acc[e]) * inv;
+    if (lane == 0) *reinterpret_cast<uint4*>(out + (long)n * C + cv * VEC) = pack16<T>(acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward at a residual-block output  y = relu(bn(c_main) + identity):
+//   g = (dy + gapg/HW) * (y > 0);  S1 = sum g;  S2 = sum g*c_main;  S3 = sum g*c_ds (downsample branch)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void block_end_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ gapg,
+                                     float gap_scale, const T* __restrict__ c_main, const T* __restrict__ c_ds,
+                                     T* __restrict__ g_out, double* sums, int nshard, long M, int HW, int C, int cw,
+                                     int nrl, int rows_per_block) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    extern __shared__ float smem_f[];
+    const int tid = threadIdx.x;
+    const int cc = tid % cw, rl = tid / cw;
+    const int chunk = blockIdx.x * cw + cc;
+    const bool active = rl < nrl && chunk * VEC < C;
+    const int ch = chunk * VEC;
+    float acc[3][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = acc[2][e] = 0.f;
+    if (active) {
+        const long rbeg = (long)blockIdx.y * rows_per_block;
+        const long rend = rbeg + rows_per_block < M ? rbeg + rows_per_block : M;
+        for (long m = rbeg + rl; m < rend; m += nrl) {
+            const long o = m * C + ch;
+            float g[VEC], yy[VEC], cm[VEC];
+            if (dy != nullptr) {
+                unpack16<T>(*reinterpret_cast<const uint4*>(dy + o), g);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+            }
+            if (gapg != nullptr) {
+                float gg[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(gapg + (m / HW) * C + ch), gg);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = fmaf(gg[e], gap_scale, g[e]);
+            }
+            unpack16<T>(*reinterpret_cast<const uint4*>(y + o), yy);
+            unpack16<T>(*reinterpret_cast<const uint4*>(c_main + o), cm);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                g[e] = yy[e] > 0.f ? round_to<T>(g[e]) : 0.f;
+                acc[0][e] += g[e];
+                acc[1][e] = fmaf(g[e], cm[e], acc[1][e]);
+            }
+            if (c_ds != nullptr) {
+                float cd[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(c_ds + o), cd);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[2][e] = fmaf(g[e], cd[e], acc[2][e]);
+            }
+            *reinterpret_cast<uint4*>(g_out + o) = pack16<T>(g);
+        }
+    }
+    col_commit<3, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
+}
+
+// backward through an inner activation a = relu(scale*c+shift) (scale==null: identity activation):
+//   g = da * (scale*c+shift > 0);  S1 = sum g;  S2 = sum g*c
+template <typename T>
+__global__ void act_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ c,
+                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                      T* __restrict__ g_out, double* sums, int nshard, long M, int C, int cw, int nrl,
+                                      int rows_per_block) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    extern __shared__ float smem_f[];
+    const int tid = threadIdx.x;
+    const int cc = tid % cw, rl = tid / cw;
+    const int chunk = blockIdx.x * cw + cc;
+    const bool active = rl < nrl && chunk * VEC < C;
+    const int ch = chunk * VEC;
+    float acc[2][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (active) {
+        float sc[VEC], sh[VEC];
+        const bool masked = scale != nullptr;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sc[e] = masked ? scale[ch + e] : 0.f;
+            sh[e] = masked ? shift[ch + e] : 1.f;
+        }
+        const long rbeg = (long)blockIdx.y * rows_per_block;
+        const long rend = rbeg + rows_per_block < M ? rbeg + rows_per_block : M;
+        for (long m = rbeg + rl; m < rend; m += nrl) {
+            const long o = m * C + ch;
+            float g[VEC], x[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(da + o), g);
+            unpack16<T>(*reinterpret_cast<const uint4*>(c + o), x);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (!(fmaf(x[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
+                acc[0][e] += g[e];
+                acc[1][e] = fmaf(g[e], x[e], acc[1][e]);
+            }
+            if (masked) *reinterpret_cast<uint4*>(g_out + o) = pack16<T>(g);
+        }
+    }
+    col_commit<2, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
+}
+
+// BatchNorm backward coefficients from the reduced sums (torch batch_norm_backward, train mode):
+//   dx = k1*g + k2*c + k3,   dgamma += invstd*(S2 - mean*S1),   dbeta += S1
+// `which` selects the S2 slot (1 = main branch, 2 = downsample branch); ns = slots per shard.
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int nshard, int ns, int which, int C,
+                                       double count, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                       float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nshard; ++k) {
+        s1 += sums[((long)k * ns + 0) * C + c];
+        s2 += sums[((long)k * ns + which) * C + c];
+    }
+    const double mu = mean[c], is = invstd[c];
+    const double dot = is * (s2 - mu * s1);  // sum g * xhat
+    if (dgamma != nullptr) dgamma[c] += (float)dot;
+    if (dbeta != nullptr) dbeta[c] += (float)s1;
+    const double a = (gamma != nullptr ? (double)gamma[c] : 1.0) * is;
+    const double m1 = s1 / count, m2 = dot / count;
+    k1[c] = (float)a;
+    k2[c] = (float)(-a * m2 * is);
+    k3[c] = (float)(-a * m1 + a * m2 * is * mu);
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ c, const float* __restrict__ k1,
+                                    const float* __restrict__ k2, const float* __restrict__ k3, T* __restrict__ dc,
+                                    long M, int C) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int cpr = C / VEC;
+    const long total = M * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr) * VEC;
+        float a[VEC], x[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(g + i * VEC), a);
+        unpack16<T>(*reinterpret_cast<const uint4*>(c + i * VEC), x);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = fmaf(k1[ch + e], a[e], fmaf(k2[ch + e], x[e], k3[ch + e]));
+        *reinterpret_cast<uint4*>(dc + i * VEC) = pack16<T>(a);
+    }
+}
+
+// column sums of [M][C] (bias gradient of the predictor's last Linear, backbone.py:30): out[c] += sum_m x
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, double* sums, long M, int C, int cw, int nrl,
+                              int rows_per_block) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    extern __shared__ float smem_f[];
+    const int tid = threadIdx.x;
+    const int cc = tid % cw, rl = tid / cw;
+    const int chunk = blockIdx.x * cw + cc;
+    const bool active = rl < nrl && chunk * VEC < C;
+    const int ch = chunk * VEC;
+    float acc[1][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = 0.f;
+    if (active) {
+        const long rbeg = (long)blockIdx.y * rows_per_block;
+        const long rend = rbeg + rows_per_block < M ? rbeg + rows_per_block : M;
+        for (long m = rbeg + rl; m < rend; m += nrl) {
+            float f[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(x + m * C + ch), f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[0][e] += f[e];
+        }
+    }
+    col_commit<1, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, 1);
+}
+
+__global__ void add_f64_to_f32_kernel(const double* __restrict__ in, float* out, int n, float alpha) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += alpha * (float)in[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// jigsaw row gather / scatter (backbone.py:147-158): out[b*K+k] = in[b*K+idx[b][k]]
+// scatter=1 is its adjoint: out[b*K+idx[b][k]] (+)= in[b*K+k]   (idx rows are permutations)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rows_permute_kernel(const T* __restrict__ in, const long* __restrict__ idx, T* __restrict__ out,
+                                    int B, int K, int C, int scatter, int accumulate) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int cpr = C / VEC;
+    const long total = (long)B * K * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cpr);
+        const long row = i / cpr;
+        const long b = row / K;
+        const long j = idx[row];
+        const long other = b * K + j;
+        const long srow = scatter ? row : other, drow = scatter ? other : row;
+        uint4 v = *reinterpret_cast<const uint4*>(in + srow * C + cv * VEC);
+        if (accumulate) {
+            float a[VEC], d[VEC];
+            unpack16<T>(v, a);
+            unpack16<T>(*reinterpret_cast<const uint4*>(out + drow * C + cv * VEC), d);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a[e] += d[e];
+            v = pack16<T>(a);
+        }
+        *reinterpret_cast<uint4*>(out + drow * C + cv * VEC) = v;
+    }
+}
+
+// strided 2-D copy / accumulate (fuser concat and its adjoint, backbone.py:195-202)
+template <typename T>
+__global__ void copy2d_kernel(const T* __restrict__ src, long src_ld, T* __restrict__ dst, long dst_ld, long rows,
+                              int cols, int accumulate) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int cpr = cols / VEC;
+    const long total = rows * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cpr);
+        const long r = i / cpr;
+        uint4 v = *reinterpret_cast<const uint4*>(src + r * src_ld + cv * VEC);
+        if (accumulate) {
+            float a[VEC], d[VEC];
+            unpack16<T>(v, a);
+            unpack16<T>(*reinterpret_cast<const uint4*>(dst + r * dst_ld + cv * VEC), d);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a[e] += d[e];
+            v = pack16<T>(a);
+        }
+        *reinterpret_cast<uint4*>(dst + r * dst_ld + cv * VEC) = v;
+    }
+}
+
+inline unsigned stream_grid(long total) {
+    long b = (total + kThreads - 1) / kThreads;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+inline bool dtype_ok(int dt) { return dt == MSFWSI_DT_F32 || dt == MSFWSI_DT_BF16; }
+inline int vec_of(int dt) { return dt == MSFWSI_DT_BF16 ? 8 : 4; }
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int msfwsi_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, int CP,
+                                   void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && x && y && N > 0 && C > 0 && H > 0 && W > 0 && CP >= C);
+    MSFWSI_CHECK_ARG(CP % vec_of(dtype) == 0);
+    const long total = (long)N * H * W * (CP / vec_of(dtype));
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream), x,
+                           (__bf16*)y, N, C, H * W, CP);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream), x,
+                           (float*)y, N, C, H * W, CP);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_bn_finalize(const double* sums, int nshard, int C, double count, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* running_mean,
+                                  float* running_var, long* num_batches_tracked, float* scale, float* shift,
+                                  float* mean, float* invstd, void* stream) {
+    MSFWSI_CHECK_ARG(sums && nshard >= 1 && C > 0 && count > 0 && scale && shift && mean && invstd);
+    MSFWSI_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), sums, nshard, C, count,
+                       gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, mean,
+                       invstd);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_shard_sum(const double* in, int nshard, int n, double* out, void* stream) {
+    MSFWSI_CHECK_ARG(in && out && nshard >= 1 && n > 0);
+    hipLaunchKernelGGL(shard_sum_kernel, dim3((n + 127) / 128), dim3(128), 0, ST(stream), in, nshard, n, out);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_bn_act(int dtype, const void* c, const float* scale, const float* shift, const void* ident,
+                             const float* id_scale, const float* id_shift, int relu, void* out, long M, int C,
+                             void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && c && scale && shift && out && M > 0 && C > 0 && C % vec_of(dtype) == 0);
+    MSFWSI_CHECK_ARG((id_scale == nullptr) == (id_shift == nullptr));
+    const long total = M * (C / vec_of(dtype));
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(bn_act_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const __bf16*)c, scale, shift, (const __bf16*)ident, id_scale, id_shift, relu, (__bf16*)out,
+                           M, C);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const float*)c, scale, shift, (const float*)ident, id_scale, id_shift, relu, (float*)out, M,
+                           C);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scale, const float* shift, void* out,
+                                    unsigned char* argmax, int N, int H, int W, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && c0 && scale && shift && out && argmax && N > 0 && H > 1 && W > 1);
+    MSFWSI_CHECK_ARG(C % vec_of(dtype) == 0);
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * P * Q * (C / vec_of(dtype));
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(stem_pool_fwd_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const __bf16*)c0, scale, shift, (__bf16*)out, argmax, N, H, W, C, P, Q);
+    else
+        hipLaunchKernelGGL(stem_pool_fwd_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const float*)c0, scale, shift, (float*)out, argmax, N, H, W, C, P, Q);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax, const void* c0,
+                                    const float* scale, const float* shift, void* g0, double* sums, int nshard, int N,
+                                    int H, int W, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && dp && argmax && c0 && scale && shift && g0 && sums && nshard >= 1);
+    MSFWSI_CHECK_ARG(N > 0 && H > 1 && W > 1 && C % vec_of(dtype) == 0);
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const int vec = vec_of(dtype);
+    ColGrid g = make_col_grid((long)N * H * W, C, vec, 2048);
+    const size_t lds = (size_t)kThreads * 2 * vec * sizeof(float);
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(stem_pool_bwd_kernel<__bf16>, g.grid, dim3(kThreads), lds, ST(stream), (const __bf16*)dp,
+                           argmax, (const __bf16*)c0, scale, shift, (__bf16*)g0, sums, nshard, N, H, W, C, P, Q, g.cw,
+                           g.nrl, g.rows_per_block);
+    else
+        hipLaunchKernelGGL(stem_pool_bwd_kernel<float>, g.grid, dim3(kThreads), lds, ST(stream), (const float*)dp,
+                           argmax, (const float*)c0, scale, shift, (float*)g0, sums, nshard, N, H, W, C, P, Q, g.cw,
+                           g.nrl, g.rows_per_block);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && y && out && N > 0 && HW > 0 && C % vec_of(dtype) == 0);
+    const long waves = (long)N * (C / vec_of(dtype));
+    const long blocks = (waves + 3) / 4;
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(gap_fwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(kThreads), 0, ST(stream),
+                           (const __bf16*)y, (__bf16*)out, N, HW, C);
+    else
+        hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, ST(stream),
+                           (const float*)y, (float*)out, N, HW, C);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_block_end_bwd(int dtype, const void* dy, const void* y, const void* gapg, float gap_scale,
+                                    const void* c_main, const void* c_ds, void* g, double* sums, int nshard, long M,
+                                    int HW, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && y && c_main && g && sums && nshard >= 1 && M > 0 && HW > 0);
+    MSFWSI_CHECK_ARG(C % vec_of(dtype) == 0 && (dy != nullptr || gapg != nullptr));
+    const int vec = vec_of(dtype);
+    ColGrid cg = make_col_grid(M, C, vec, 2048);
+    const size_t lds = (size_t)kThreads * 3 * vec * sizeof(float);
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(block_end_bwd_kernel<__bf16>, cg.grid, dim3(kThreads), lds, ST(stream), (const __bf16*)dy,
+                           (const __bf16*)y, (const __bf16*)gapg, gap_scale, (const __bf16*)c_main,
+                           (const __bf16*)c_ds, (__bf16*)g, sums, nshard, M, HW, C, cg.cw, cg.nrl, cg.rows_per_block);
+    else
+        hipLaunchKernelGGL(block_end_bwd_kernel<float>, cg.grid, dim3(kThreads), lds, ST(stream), (const float*)dy,
+                           (const float*)y, (const float*)gapg, gap_scale, (const float*)c_main, (const float*)c_ds,
+                           (float*)g, sums, nshard, M, HW, C, cg.cw, cg.nrl, cg.rows_per_block);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_act_bwd_reduce(int dtype, const void* da, const void* c, const float* scale,
+                                     const float* shift, void* g, double* sums, int nshard, long M, int C,
+                                     void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && da && c && sums && nshard >= 1 && M > 0 && C % vec_of(dtype) == 0);
+    MSFWSI_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+    MSFWSI_CHECK_ARG(scale == nullptr || g != nullptr);
+    const int vec = vec_of(dtype);
+    ColGrid cg = make_col_grid(M, C, vec, 2048);
+    const size_t lds = (size_t)kThreads * 2 * vec * sizeof(float);
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(act_bwd_reduce_kernel<__bf16>, cg.grid, dim3(kThreads), lds, ST(stream), (const __bf16*)da,
+                           (const __bf16*)c, scale, shift, (__bf16*)g, sums, nshard, M, C, cg.cw, cg.nrl,
+                           cg.rows_per_block);
+    else
+        hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, cg.grid, dim3(kThreads), lds, ST(stream), (const float*)da,
+                           (const float*)c, scale, shift, (float*)g, sums, nshard, M, C, cg.cw, cg.nrl,
+                           cg.rows_per_block);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_bn_bwd_finalize(const double* sums, int nshard, int nslots, int which, int C, double count,
+                                      const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                                      float* dbeta, float* k1, float* k2, float* k3, void* stream) {
+    MSFWSI_CHECK_ARG(sums && nshard >= 1 && nslots >= 2 && which >= 1 && which < nslots && C > 0 && count > 0);
+    MSFWSI_CHECK_ARG(mean && invstd && k1 && k2 && k3);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), sums, nshard, nslots,
+                       which, C, count, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_bn_bwd_apply(int dtype, const void* g, const void* c, const float* k1, const float* k2,
+                                   const float* k3, void* dc, long M, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && g && c && k1 && k2 && k3 && dc && M > 0 && C % vec_of(dtype) == 0);
+    const long total = M * (C / vec_of(dtype));
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const __bf16*)g, (const __bf16*)c, k1, k2, k3, (__bf16*)dc, M, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const float*)g, (const float*)c, k1, k2, k3, (float*)dc, M, C);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_colsum(int dtype, const void* x, double* sums, long M, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && x && sums && M > 0 && C % vec_of(dtype) == 0);
+    const int vec = vec_of(dtype);
+    ColGrid cg = make_col_grid(M, C, vec, 1024);
+    const size_t lds = (size_t)kThreads * vec * sizeof(float);
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(colsum_kernel<__bf16>, cg.grid, dim3(kThreads), lds, ST(stream), (const __bf16*)x, sums, M,
+                           C, cg.cw, cg.nrl, cg.rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, cg.grid, dim3(kThreads), lds, ST(stream), (const float*)x, sums, M, C,
+                           cg.cw, cg.nrl, cg.rows_per_block);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_add_f64_to_f32(const double* in, float* out, int n, float alpha, void* stream) {
+    MSFWSI_CHECK_ARG(in && out && n > 0);
+    hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), in, out, n, alpha);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_rows_permute(int dtype, const void* in, const long* idx, void* out, int B, int K, int C,
+                                   int scatter, int accumulate, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && in && idx && out && B > 0 && K > 0 && C % vec_of(dtype) == 0);
+    const long total = (long)B * K * (C / vec_of(dtype));
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(rows_permute_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const __bf16*)in, idx, (__bf16*)out, B, K, C, scatter, accumulate);
+    else
+        hipLaunchKernelGGL(rows_permute_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const float*)in, idx, (float*)out, B, K, C, scatter, accumulate);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_copy2d(int dtype, const void* src, long src_ld, void* dst, long dst_ld, long rows, int cols,
+                             int accumulate, void* stream) {
+    const int vec = vec_of(dtype);
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && src && dst && rows > 0 && cols > 0 && cols % vec == 0);
+    MSFWSI_CHECK_ARG(src_ld % vec == 0 && dst_ld % vec == 0);
+    const long total = rows * (cols / vec);
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(copy2d_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const __bf16*)src, src_ld, (__bf16*)dst, dst_ld, rows, cols, accumulate);
+    else
+        hipLaunchKernelGGL(copy2d_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const float*)src, src_ld, (float*)dst, dst_ld, rows, cols, accumulate);
+    return msfwsi_launch_status();
+}

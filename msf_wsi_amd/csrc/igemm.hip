@@ -1,0 +1,540 @@
+// Gather-GEMM ("implicit GEMM") for the MSF-WSI encoders and heads on gfx950.
+//
+//   out[m][n] = sum_k A(m,k) * B(k,n)        m = (image, p, q) output pixel, n = output channel
+//
+// FWD   : A(m,(r,s,c)) = act(src[img, p*stride-pad+r, q*stride-pad+s, c]),  B = W[n][r][s][c]
+//         replaces nn.Conv2d (bias-free 3x3/1x1/7x7, reference src/models/resnet.py:25-33,174) and
+//         nn.Linear (src/models/backbone.py:12-31, a 1x1 conv on an H=W=1 tensor); `act` is the
+//         producer's BatchNorm+ReLU (resnet.py:69-71) applied while the tile is staged, so the
+//         normalised activation never round-trips through HBM.  The epilogue emits the raw conv
+//         output plus per-channel sum / sum-of-squares for the consumer BatchNorm (training mode).
+// DGRAD : A(m,(r,s,co)) = dY[img, (p+pad-r)/stride, (q+pad-s)/stride, co],   B = W[co][r][s][n]
+//         (the forward weight tensor read as a [k][n] operand -> no transposed weight copy).
+//
+// Activations are NHWC, weights are [Cout][R][S][Cin] (torch channels_last physical layout).
+// Tile: BM x BN outputs per 256-thread workgroup (4 waves), 64-byte k-slab per stage (32 bf16 /
+// 16 fp32), double-buffered LDS, register-staged global loads, MFMA 32x32 (bf16: 32x32x16,
+// fp32: 32x32x2 exact-fp32).  The weight tile is the MFMA A operand and the activation tile the
+// B operand, so a lane's 16 accumulator registers hold 4x4 consecutive output channels of ONE
+// pixel; the tile is then transposed through LDS and leaves as 16-byte row chunks.
+#include "common.h"
+#include "../../include/msfwsi_hip.h"
+
+namespace {
+
+struct IgemmParams {
+    const void* src;
+    const void* wgt;
+    void* out;
+    const float* pro_scale;  // per source channel, nullable
+    const float* pro_shift;
+    const float* bias;       // per output channel, nullable
+    double* stats;           // [nshard][2][Nout], nullable
+    const void* resid;       // [M][Nout], nullable (added in the epilogue)
+    const void* gapg;        // [Nimg][Nout] storage type, nullable (added, times gap_scale)
+    float gap_scale;
+    int N, H, W, C;          // source tensor
+    int P, Q, Nout;          // output tensor
+    int R, S, stride, pad;
+    int M, Ktot;
+    int nshard;
+    int ntile_n;
+};
+
+template <typename T>
+struct Frag;
+template <>
+struct Frag<float> {
+    typedef f32x4 type;
+};
+template <>
+struct Frag<__bf16> {
+    typedef bf16x8 type;
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_step(f32x16& acc, const typename Frag<T>::type& w,
+                                         const typename Frag<T>::type& x);
+template <>
+__device__ __forceinline__ void mma_step<__bf16>(f32x16& acc, const bf16x8& w, const bf16x8& x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_step<float>(f32x16& acc, const f32x4& w, const f32x4& x) {
+    // lane half h supplies k = 4h+e to step e on BOTH operands: a consistent k permutation
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
+struct IgemmCfg {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int BK = ElemTraits<T>::BK;
+    static constexpr int CPRK = BK / VEC;  // 16-byte chunks per k-slab row (= 4)
+    static constexpr int LDK = BK + VEC;   // 80-byte rows: conflict-free ds_read_b128
+    // natural [k][n] weight tile (DGRAD): row stride == 64 (mod 256) bytes for bf16 tr-reads
+    static constexpr int LDN = (sizeof(T) == 2) ? (BN + 32) : (BN + 4);
+    static constexpr int TM = BM / WM / 32;
+    static constexpr int TN = BN / WN / 32;
+    static constexpr int A_CHUNKS = BM * CPRK / 256;
+    static constexpr int B_CHUNKS = BN * CPRK / 256;
+    static constexpr int LDC = BN + VEC;
+    static constexpr int A_BYTES = BM * LDK * (int)sizeof(T);
+    static constexpr int B_BYTES = DGRAD ? BK * LDN * (int)sizeof(T) : BN * LDK * (int)sizeof(T);
+    static constexpr int AB_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int C_BYTES = BM * LDC * (int)sizeof(T);
+    static constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
+    static constexpr int RED_BYTES = 4 * BN * 2 * (int)sizeof(float);
+    static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small");
+};
+
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD> Cfg;
+    constexpr int VEC = Cfg::VEC, BK = Cfg::BK, CPRK = Cfg::CPRK, LDK = Cfg::LDK, LDN = Cfg::LDN;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_CHUNKS = Cfg::A_CHUNKS, B_CHUNKS = Cfg::B_CHUNKS;
+    constexpr int LDC = Cfg::LDC;
+    typedef typename Frag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* As = reinterpret_cast<T*>(smem);                        // [2][BM][LDK]
+    T* Bs = reinterpret_cast<T*>(smem + 2 * Cfg::A_BYTES);     // [2][BN][LDK] or [2][BK][LDN]
+    T* Cs = reinterpret_cast<T*>(smem);                        // [BM][LDC]   (after the k loop)
+    float* red = reinterpret_cast<float*>(smem + Cfg::MAIN_BYTES);  // [4][BN][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tile_n = blockIdx.x % prm.ntile_n;
+    const int tile_m = blockIdx.x / prm.ntile_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const T* __restrict__ src = reinterpret_cast<const T*>(prm.src);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(prm.wgt);
+
+    const int PQ = prm.P * prm.Q;
+    const bool fastk = (prm.C % BK) == 0;  // a k-slab never straddles two filter taps
+    const bool has_pro = prm.pro_scale != nullptr;
+
+    // ---- per-thread row descriptors for the activation chunks (fixed over the k loop) ----
+    int a_hb[A_CHUNKS], a_wb[A_CHUNKS];
+    long a_img[A_CHUNKS];
+    bool a_rowok[A_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / CPRK;
+        const int m = m0 + row;
+        a_rowok[i] = m < prm.M;
+        const int mm = a_rowok[i] ? m : 0;
+        const int img = mm / PQ;
+        const int rem = mm - img * PQ;
+        const int p = rem / prm.Q;
+        const int q = rem - p * prm.Q;
+        a_img[i] = (long)img * prm.H * prm.W;
+        if (DGRAD) {
+            a_hb[i] = p + prm.pad;
+            a_wb[i] = q + prm.pad;
+        } else {
+            a_hb[i] = p * prm.stride - prm.pad;
+            a_wb[i] = q * prm.stride - prm.pad;
+        }
+    }
+
+    uint4 a_reg[A_CHUNKS];
+    bool a_ok[A_CHUNKS];
+    float a_sc[A_CHUNKS][VEC], a_sh[A_CHUNKS][VEC];
+    uint4 b_reg[B_CHUNKS];
+
+    // running tap state for the fast path
+    int tap_r = 0, tap_s = 0, tap_c = 0;
+
+    auto load_global = [&](int k0) {
+        // ---------------- activation tile ----------------
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int c = tid + i * 256;
+            const int kc = c % CPRK;
+            const int kk = k0 + kc * VEC;
+            int r, s, ch;
+            if (fastk) {
+                r = tap_r;
+                s = tap_s;
+                ch = tap_c + kc * VEC;
+            } else if (prm.R * prm.S == 1) {
+                r = 0;
+                s = 0;
+                ch = kk;
+            } else {
+                const int rs = kk / prm.C;
+                ch = kk - rs * prm.C;
+                r = rs / prm.S;
+                s = rs - r * prm.S;
+            }
+            int h, w;
+            bool ok = a_rowok[i] && (kk < prm.Ktot);
+            if (DGRAD) {
+                const int th = a_hb[i] - r, tw = a_wb[i] - s;
+                if (prm.stride == 1) {
+                    h = th;
+                    w = tw;
+                } else {  // stride 2
+                    ok = ok && (((th | tw) & 1) == 0);
+                    h = th >> 1;
+                    w = tw >> 1;
+                }
+                ok = ok && th >= 0 && tw >= 0;
+            } else {
+                h = a_hb[i] + r;
+                w = a_wb[i] + s;
+            }
+            ok = ok && (unsigned)h < (unsigned)prm.H && (unsigned)w < (unsigned)prm.W;
+            a_ok[i] = ok;
+            a_reg[i] = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const long off = ((a_img[i] + (long)h * prm.W + w) * prm.C) + ch;
+                a_reg[i] = *reinterpret_cast<const uint4*>(src + off);
+                if (has_pro) {
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 4) {
+                        const float4 sc = *reinterpret_cast<const float4*>(prm.pro_scale + ch + e);
+                        const float4 sh = *reinterpret_cast<const float4*>(prm.pro_shift + ch + e);
+                        a_sc[i][e + 0] = sc.x; a_sc[i][e + 1] = sc.y; a_sc[i][e + 2] = sc.z; a_sc[i][e + 3] = sc.w;
+                        a_sh[i][e + 0] = sh.x; a_sh[i][e + 1] = sh.y; a_sh[i][e + 2] = sh.z; a_sh[i][e + 3] = sh.w;
+                    }
+                }
+            }
+        }
+        // ---------------- weight tile ----------------
+#pragma unroll
+        for (int i = 0; i < B_CHUNKS; ++i) {
+            const int c = tid + i * 256;
+            b_reg[i] = make_uint4(0, 0, 0, 0);
+            if (!DGRAD) {
+                const int nrow = c / CPRK, kc = c % CPRK;
+                const int n = n0 + nrow, kk = k0 + kc * VEC;
+                if (n < prm.Nout && kk < prm.Ktot)
+                    b_reg[i] = *reinterpret_cast<const uint4*>(wgt + (long)n * prm.Ktot + kk);
+            } else {
+                constexpr int CPN = BN / VEC;
+                const int krow = c / CPN, cn = c % CPN;
+                const int kk = k0 + krow, n = n0 + cn * VEC;
+                int r, s, co;
+                if (fastk) {
+                    r = tap_r;
+                    s = tap_s;
+                    co = tap_c + krow;
+                } else if (prm.R * prm.S == 1) {
+                    r = 0;
+                    s = 0;
+                    co = kk;
+                } else {
+                    const int rs = kk / prm.C;
+                    co = kk - rs * prm.C;
+                    r = rs / prm.S;
+                    s = rs - r * prm.S;
+                }
+                if (kk < prm.Ktot && n < prm.Nout)
+                    b_reg[i] = *reinterpret_cast<const uint4*>(
+                        wgt + (((long)co * prm.R + r) * prm.S + s) * prm.Nout + n);
+            }
+        }
+        if (fastk) {  // advance the tap for the next slab
+            tap_c += BK;
+            if (tap_c >= prm.C) {
+                tap_c = 0;
+                if (++tap_s == prm.S) {
+                    tap_s = 0;
+                    ++tap_r;
+                }
+            }
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+        T* Ab = As + buf * (BM * LDK);
+        T* Bb = Bs + buf * (DGRAD ? BK * LDN : BN * LDK);
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / CPRK, kc = c % CPRK;
+            uint4 v = a_reg[i];
+            if (has_pro && a_ok[i]) {
+                float f[VEC];
+                unpack16<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], a_sc[i][e], a_sh[i][e]), 0.f);
+                v = pack16<T>(f);
+            }
+            *reinterpret_cast<uint4*>(Ab + row * LDK + kc * VEC) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_CHUNKS; ++i) {
+            const int c = tid + i * 256;
+            if (!DGRAD) {
+                const int nrow = c / CPRK, kc = c % CPRK;
+                *reinterpret_cast<uint4*>(Bb + nrow * LDK + kc * VEC) = b_reg[i];
+            } else {
+                constexpr int CPN = BN / VEC;
+                const int krow = c / CPN, cn = c % CPN;
+                *reinterpret_cast<uint4*>(Bb + krow * LDN + cn * VEC) = b_reg[i];
+            }
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+    auto compute = [&](int buf) {
+        const T* Ab = As + buf * (BM * LDK);
+        const T* Bb = Bs + buf * (DGRAD ? BK * LDN : BN * LDK);
+#pragma unroll
+        for (int ks = 0; ks < BK / (2 * VEC); ++ks) {
+            frag_t xf[TM], wf[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = (wm * TM + tm) * 32 + l31;
+                xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * LDK + ks * 2 * VEC + lh * VEC);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int ncol = (wn * TN + tn) * 32;
+                if (!DGRAD) {
+                    wf[tn] = *reinterpret_cast<const frag_t*>(Bb + (ncol + l31) * LDK + ks * 2 * VEC + lh * VEC);
+                } else if constexpr (sizeof(T) == 2) {
+                    // transposed LDS read: 16-lane group G -> columns 16*(G&1).., k-half G>>1
+                    const int li = lane & 15, G = lane >> 4;
+                    const int q = li >> 2, p = li & 3;
+                    const int kbase = ks * 16 + (G >> 1) * 8 + q;
+                    const T* a0 = Bb + kbase * LDN + ncol + (G & 1) * 16 + p * 4;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * LDN));
+                    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    wf[tn] = __builtin_bit_cast(frag_t, both);
+                } else {
+                    frag_t t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        t[e] = reinterpret_cast<const float*>(Bb)[(ks * 8 + lh * 4 + e) * LDN + ncol + l31];
+                    wf[tn] = t;
+                }
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) mma_step<T>(acc[tn][tm], wf[tn], xf[tm]);
+        }
+    };
+
+    // ---------------- main loop ----------------
+    const int nk = (prm.Ktot + BK - 1) / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_global((kt + 1) * BK);
+        compute(buf);
+        if (kt + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: accumulators -> LDS tile (storage type) ----------------
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ncol = (wn * TN + tn) * 32 + 8 * g + 4 * lh;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (prm.bias != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n0 + ncol + e < prm.Nout) bv[e] = prm.bias[n0 + ncol + e];
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = (wm * TM + tm) * 32 + l31;
+                T* dst = Cs + row * LDC + ncol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) store_elem<T>(dst, e, acc[tn][tm][g * 4 + e] + bv[e]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- row-chunk pass: coalesced 16-byte stores + per-channel statistics ----------------
+    constexpr int CPR = BN / VEC;        // chunks per tile row
+    constexpr int RPP = 256 / CPR;       // rows per pass
+    const int cc = tid % CPR;
+    const int rr = tid / CPR;
+    const int ncol = n0 + cc * VEC;
+    const bool col_ok = ncol < prm.Nout;
+    T* __restrict__ out = reinterpret_cast<T*>(prm.out);
+    const T* __restrict__ resid = reinterpret_cast<const T*>(prm.resid);
+    float ssum[VEC], ssq[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
+
+#pragma unroll 2
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int row = rr + pass * RPP;
+        const int m = m0 + row;
+        if (m < prm.M && col_ok) {
+            uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
+            const long off = (long)m * prm.Nout + ncol;
+            if (resid != nullptr || prm.gapg != nullptr) {
+                float f[VEC];
+                unpack16<T>(v, f);
+                if (resid != nullptr) {
+                    float g[VEC];
+                    unpack16<T>(*reinterpret_cast<const uint4*>(resid + off), g);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[e] += g[e];
+                }
+                if (prm.gapg != nullptr) {
+                    float gp[VEC];
+                    unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) +
+                                                                (long)(m / PQ) * prm.Nout + ncol), gp);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
+                }
+                v = pack16<T>(f);
+            }
+            *reinterpret_cast<uint4*>(out + off) = v;
+            if (prm.stats != nullptr) {
+                float f[VEC];
+                unpack16<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    ssum[e] += f[e];
+                    ssq[e] = fmaf(f[e], f[e], ssq[e]);
+                }
+            }
+        }
+    }
+
+    if (prm.stats != nullptr) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+            for (int off = CPR; off < 64; off <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], off, 64);
+                ssq[e] += __shfl_xor(ssq[e], off, 64);
+            }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                red[(wave * BN + lane * VEC + e) * 2 + 0] = ssum[e];
+                red[(wave * BN + lane * VEC + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int col = i % BN, which = i / BN;
+            if (n0 + col < prm.Nout) {
+                float t = 0.f;
+                // a wave covers 64/CPR rows per pass; all 4 waves contribute
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t += red[(w * BN + col) * 2 + which];
+                double* dst = prm.stats + ((long)(tile_m % prm.nshard) * 2 + which) * prm.Nout + n0 + col;
+                atomicAdd(dst, (double)t);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
+int launch_igemm(IgemmParams& prm, hipStream_t stream) {
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD> Cfg;
+    const int ntm = (prm.M + BM - 1) / BM;
+    prm.ntile_n = (prm.Nout + BN - 1) / BN;
+    const long nblk = (long)ntm * prm.ntile_n;
+    if (nblk <= 0 || nblk > 0x7fffffffL) return MSFWSI_EINVAL;
+    auto kern = igemm_kernel<T, BM, BN, WM, WN, DGRAD>;
+    if (Cfg::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, stream, prm);
+    return msfwsi_launch_status();
+}
+
+template <typename T, bool DGRAD>
+int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
+    if (prm.Nout <= 64) return launch_igemm<T, 128, 64, 2, 2, DGRAD>(prm, stream);
+    return launch_igemm<T, 128, 128, 2, 2, DGRAD>(prm, stream);
+}
+
+int check_desc(const msfwsi_conv_desc* d) {
+    if (d == nullptr) return MSFWSI_EINVAL;
+    if (d->dtype != MSFWSI_DT_F32 && d->dtype != MSFWSI_DT_BF16) return MSFWSI_EUNSUPPORTED;
+    const int vec = d->dtype == MSFWSI_DT_BF16 ? 8 : 4;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->P <= 0 || d->Q <= 0) return MSFWSI_EINVAL;
+    if (d->R <= 0 || d->S <= 0 || d->pad < 0) return MSFWSI_EINVAL;
+    if (d->stride != 1 && d->stride != 2) return MSFWSI_EUNSUPPORTED;
+    if (d->C % vec != 0 || d->K % vec != 0) return MSFWSI_EUNSUPPORTED;
+    // output extent must be the convolution's
+    if (d->P != (d->H + 2 * d->pad - d->R) / d->stride + 1) return MSFWSI_EINVAL;
+    if (d->Q != (d->W + 2 * d->pad - d->S) / d->stride + 1) return MSFWSI_EINVAL;
+    if ((long)d->N * d->P * d->Q > 0x7fffffffL || (long)d->N * d->H * d->W > 0x7fffffffL) return MSFWSI_EINVAL;
+    return MSFWSI_OK;
+}
+
+}  // namespace
+
+extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y,
+                               const float* pro_scale, const float* pro_shift, const float* bias,
+                               double* stats, int nshard, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MSFWSI_OK) return rc;
+    MSFWSI_CHECK_ARG(x != nullptr && w != nullptr && y != nullptr);
+    MSFWSI_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr));
+    MSFWSI_CHECK_ARG(stats == nullptr || nshard >= 1);
+    IgemmParams prm{};
+    prm.src = x; prm.wgt = w; prm.out = y;
+    prm.pro_scale = pro_scale; prm.pro_shift = pro_shift; prm.bias = bias;
+    prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C;
+    prm.P = d->P; prm.Q = d->Q; prm.Nout = d->K;
+    prm.R = d->R; prm.S = d->S; prm.stride = d->stride; prm.pad = d->pad;
+    prm.M = d->N * d->P * d->Q;
+    prm.Ktot = d->R * d->S * d->C;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MSFWSI_DT_BF16) return dispatch_tile<__bf16, false>(prm, st);
+    return dispatch_tile<float, false>(prm, st);
+}
+
+extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
+                                 const void* resid, const void* gapg, float gap_scale, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MSFWSI_OK) return rc;
+    MSFWSI_CHECK_ARG(dy != nullptr && w != nullptr && dx != nullptr);
+    IgemmParams prm{};
+    prm.src = dy; prm.wgt = w; prm.out = dx;
+    prm.resid = resid; prm.gapg = gapg; prm.gap_scale = gap_scale;
+    prm.nshard = 1;
+    // source = dY [N,P,Q,K]; output = dX [N,H,W,C]
+    prm.N = d->N; prm.H = d->P; prm.W = d->Q; prm.C = d->K;
+    prm.P = d->H; prm.Q = d->W; prm.Nout = d->C;
+    prm.R = d->R; prm.S = d->S; prm.stride = d->stride; prm.pad = d->pad;
+    prm.M = d->N * d->H * d->W;
+    prm.Ktot = d->R * d->S * d->K;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MSFWSI_DT_BF16) return dispatch_tile<__bf16, true>(prm, st);
+    return dispatch_tile<float, true>(prm, st);
+}

@@ -1,0 +1,244 @@
+// Loss and optimizer kernels of the MSF-WSI pre-train step on gfx950 (all HBM-bound):
+//   * fused negative-cosine (SimSiam) loss forward+backward, one wavefront per row
+//     (reference: nn.CosineSimilarity(dim=1) terms of tools/ssl_train.py:422,448-466)
+//   * non-finite check + dynamic loss-scale update (torch.cuda.amp.GradScaler, ssl_train.py:100,472-474)
+//   * flat multi-tensor Adam (torch.optim.Adam defaults, ssl_train.py:309,473) that also refreshes the
+//     bf16 compute copy of the weights in the same pass
+//   * fp32 -> storage-type casts with channel padding (stem weights / their gradients)
+#include "common.h"
+#include "../../include/msfwsi_hip.h"
+
+namespace {
+
+template <typename T>
+__global__ void cosine_loss_kernel(const T* __restrict__ p, const T* __restrict__ z, long rows, int d, float coef,
+                                   const float* __restrict__ loss_scale, float eps, double* loss_accum,
+                                   T* __restrict__ dp) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const long row = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const T* pr = p + row * d;
+    const T* zr = z + row * d;
+    float dot = 0.f, pp = 0.f, zz = 0.f;
+    for (int i = lane * VEC; i < d; i += 64 * VEC) {
+        float a[VEC], b[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(pr + i), a);
+        unpack16<T>(*reinterpret_cast<const uint4*>(zr + i), b);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            dot = fmaf(a[e], b[e], dot);
+            pp = fmaf(a[e], a[e], pp);
+            zz = fmaf(b[e], b[e], zz);
+        }
+    }
+    dot = wave_sum(dot);
+    pp = wave_sum(pp);
+    zz = wave_sum(zz);
+    const float np_raw = sqrtf(pp), nz_raw = sqrtf(zz);
+    const float np = fmaxf(np_raw, eps), nz = fmaxf(nz_raw, eps);
+    const float inv = 1.f / (np * nz);
+    const float cosv = dot * inv;
+    if (lane == 0 && loss_accum != nullptr) atomicAdd(loss_accum, (double)coef * (double)cosv);
+    if (dp != nullptr) {
+        const float gs = coef * (loss_scale != nullptr ? *loss_scale : 1.f);
+        // d cos / d p = z/(np*nz) - cos * p / np^2   (second term vanishes while the norm is clamped)
+        const float a1 = gs * inv;
+        const float a2 = np_raw > eps ? gs * cosv / (np * np) : 0.f;
+        T* dr = dp + row * d;
+        for (int i = lane * VEC; i < d; i += 64 * VEC) {
+            float a[VEC], b[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(pr + i), a);
+            unpack16<T>(*reinterpret_cast<const uint4*>(zr + i), b);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a[e] = a1 * b[e] - a2 * a[e];
+            *reinterpret_cast<uint4*>(dr + i) = pack16<T>(a);
+        }
+    }
+}
+
+__global__ void nonfinite_check_kernel(const float* __restrict__ g, long n, float* found) {
+    bool bad = false;
+    const long n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !isfinite(g[n4 * 4 + threadIdx.x]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found = 1.f;
+}
+
+// torch._amp_update_scale_: scale/growth_tracker live on the device so no step ever syncs on them
+__global__ void scaler_update_kernel(float* scale, int* growth_tracker, const float* found, float growth_factor,
+                                     float backoff_factor, int growth_interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (*found > 0.f) {
+        *scale = *scale * backoff_factor;
+        *growth_tracker = 0;
+    } else {
+        const int succ = *growth_tracker + 1;
+        if (succ == growth_interval) {
+            const float ns = *scale * growth_factor;
+            if (isfinite(ns)) *scale = ns;
+            *growth_tracker = 0;
+        } else {
+            *growth_tracker = succ;
+        }
+    }
+}
+
+// torch.optim.Adam (no amsgrad, no weight decay), same operation order as _single_tensor_adam:
+//   m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float beta1, float beta2, float eps, float step_size,
+                            float bc2_sqrt, const float* __restrict__ loss_scale, const float* __restrict__ found,
+                            unsigned short* __restrict__ p_bf16) {
+    if (found != nullptr && *found > 0.f) return;  // GradScaler.step skips the update
+    const float inv_scale = loss_scale != nullptr ? 1.f / *loss_scale : 1.f;
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x;
+        const float* gg = &gv.x;
+        float* mm = &mv.x;
+        float* vq = &vv.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * inv_scale;
+            mm[e] = mm[e] + (gr - mm[e]) * (1.f - beta1);
+            vq[e] = vq[e] * beta2 + (1.f - beta2) * gr * gr;
+            const float denom = sqrtf(vq[e]) / bc2_sqrt + eps;
+            pp[e] = pp[e] - step_size * (mm[e] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (p_bf16 != nullptr) {
+            uint2 o;
+            o.x = pack2_bf16(pp[0], pp[1]);
+            o.y = pack2_bf16(pp[2], pp[3]);
+            reinterpret_cast<uint2*>(p_bf16)[i] = o;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = n4 * 4 + threadIdx.x;
+        const float gr = g[i] * inv_scale;
+        m[i] = m[i] + (gr - m[i]) * (1.f - beta1);
+        v[i] = v[i] * beta2 + (1.f - beta2) * gr * gr;
+        const float denom = sqrtf(v[i]) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (m[i] / denom);
+        if (p_bf16 != nullptr) p_bf16[i] = float_to_bf16_bits(p[i]);
+    }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        uint2 o;
+        o.x = pack2_bf16(v.x, v.y);
+        o.y = pack2_bf16(v.z, v.w);
+        reinterpret_cast<uint2*>(dst)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = float_to_bf16_bits(src[n4 * 4 + threadIdx.x]);
+}
+
+// [rows][C] fp32 -> [rows][CP] storage type, zero padded (stem weights: C=3 -> CP=8 / 4)
+template <typename T>
+__global__ void pad_cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long rows, int C, int CP) {
+    const long total = rows * CP;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / CP;
+        const int c = (int)(i - r * CP);
+        store_elem<T>(dst, i, c < C ? src[r * C + c] : 0.f);
+    }
+}
+// adjoint: dst[rows][C] += src[rows][CP][:C]
+__global__ void unpad_add_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int C, int CP) {
+    const long total = rows * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        dst[i] += src[r * CP + c];
+    }
+}
+
+inline unsigned sgrid(long total, int threads) {
+    long b = (total + threads - 1) / threads;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int msfwsi_cosine_loss(int dtype, const void* p, const void* z, long rows, int d, float coef,
+                                  const float* loss_scale, float eps, double* loss_accum, void* dp, void* stream) {
+    MSFWSI_CHECK_ARG((dtype == MSFWSI_DT_F32 || dtype == MSFWSI_DT_BF16) && p && z && rows > 0 && d > 0);
+    MSFWSI_CHECK_ARG(d % (dtype == MSFWSI_DT_BF16 ? 8 : 4) == 0);
+    const long blocks = (rows + 3) / 4;
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(cosine_loss_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, ST(stream),
+                           (const __bf16*)p, (const __bf16*)z, rows, d, coef, loss_scale, eps, loss_accum, (__bf16*)dp);
+    else
+        hipLaunchKernelGGL(cosine_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ST(stream), (const float*)p,
+                           (const float*)z, rows, d, coef, loss_scale, eps, loss_accum, (float*)dp);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_nonfinite_check(const float* g, long n, float* found, void* stream) {
+    MSFWSI_CHECK_ARG(g && found && n > 0);
+    hipLaunchKernelGGL(nonfinite_check_kernel, dim3(sgrid(n / 4 + 1, 256)), dim3(256), 0, ST(stream), g, n, found);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_scaler_update(float* scale, int* growth_tracker, const float* found, float growth_factor,
+                                    float backoff_factor, int growth_interval, void* stream) {
+    MSFWSI_CHECK_ARG(scale && growth_tracker && found && growth_interval > 0);
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, ST(stream), scale, growth_tracker, found,
+                       growth_factor, backoff_factor, growth_interval);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                           float eps, long step, const float* loss_scale, const float* found, void* p_bf16,
+                           void* stream) {
+    MSFWSI_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(sgrid(n / 4 + 1, 256)), dim3(256), 0, ST(stream), p, g, m, v, n, beta1, beta2,
+                       eps, step_size, bc2_sqrt, loss_scale, found, (unsigned short*)p_bf16);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_cast_bf16(const float* src, void* dst, long n, void* stream) {
+    MSFWSI_CHECK_ARG(src && dst && n > 0);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(sgrid(n / 4 + 1, 256)), dim3(256), 0, ST(stream), src,
+                       (unsigned short*)dst, n);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_pad_cast(int dtype, const float* src, void* dst, long rows, int C, int CP, void* stream) {
+    MSFWSI_CHECK_ARG((dtype == MSFWSI_DT_F32 || dtype == MSFWSI_DT_BF16) && src && dst && rows > 0 && C > 0 && CP >= C);
+    if (dtype == MSFWSI_DT_BF16)
+        hipLaunchKernelGGL(pad_cast_kernel<__bf16>, dim3(sgrid(rows * CP, 256)), dim3(256), 0, ST(stream), src,
+                           (__bf16*)dst, rows, C, CP);
+    else
+        hipLaunchKernelGGL(pad_cast_kernel<float>, dim3(sgrid(rows * CP, 256)), dim3(256), 0, ST(stream), src,
+                           (float*)dst, rows, C, CP);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_unpad_add(const float* src, float* dst, long rows, int C, int CP, void* stream) {
+    MSFWSI_CHECK_ARG(src && dst && rows > 0 && C > 0 && CP >= C);
+    hipLaunchKernelGGL(unpad_add_kernel, dim3(sgrid(rows * C, 256)), dim3(256), 0, ST(stream), src, dst, rows, C, CP);
+    return msfwsi_launch_status();
+}

@@ -1,0 +1,385 @@
+"""Typed Python front of the C ABI: torch tensors in, kernel launches on the current HIP stream out.
+
+Every wrapper checks shapes/dtypes/devices on the host before launching (a faulting kernel can reset
+the GPU), then forwards raw device pointers.  Tensors are NHWC ("[M][C]") as described in
+include/msfwsi_hip.h.  Nothing here computes on the CPU or through torch operators.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, DT_BF16, DT_F32
+
+NSHARD = 32  # replicas of every fp64 statistics accumulator (spreads memory-side atomics)
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError(f"unsupported storage dtype {t.dtype}")
+
+
+def vec_of(dtype: torch.dtype) -> int:
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str, dtype=None, numel=None):
+    if not t.is_cuda:
+        raise _lib.MsfwsiHipError(f"{name}: expected a GPU tensor (no CPU path exists)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name}: expected {numel} elements, got {t.numel()}")
+    if t.numel() > 1 and t.data_ptr() % 16 != 0:
+        raise ValueError(f"{name}: must be 16-byte aligned")
+
+
+def _opt(t, name, dtype=None, numel=None):
+    if t is not None:
+        _req(t, name, dtype, numel)
+
+
+def conv_desc(dtype: torch.dtype, N, H, W, Cin, K, R, S, stride, pad) -> ConvDesc:
+    P = (H + 2 * pad - R) // stride + 1
+    Q = (W + 2 * pad - S) // stride + 1
+    return ConvDesc(DT_BF16 if dtype == torch.bfloat16 else DT_F32, N, H, W, Cin, P, Q, K, R, S, stride, pad)
+
+
+def new_stats(C_: int, slots: int = 2, device=None) -> torch.Tensor:
+    return torch.zeros(NSHARD, slots, C_, dtype=torch.float64, device=device or "cuda")
+
+
+# ------------------------------------------------------------------------------------------------
+def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
+    """y = conv(act(x), w) (+bias); pro = (scale, shift) of the producer BatchNorm; stats [NSHARD,2,K]."""
+    lib = _lib.load()
+    dt = x.dtype
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(w, "w", dt, d.K * d.R * d.S * d.C)
+    _req(y, "y", dt, d.N * d.P * d.Q * d.K)
+    ps = psh = None
+    if pro is not None:
+        ps, psh = pro
+        _req(ps, "pro_scale", torch.float32, d.C)
+        _req(psh, "pro_shift", torch.float32, d.C)
+    _opt(bias, "bias", torch.float32, d.K)
+    nsh = 1
+    if stats is not None:
+        _req(stats, "stats", torch.float64)
+        nsh = stats.shape[0]
+        if stats.numel() != nsh * 2 * d.K:
+            raise ValueError("stats must be [nshard,2,K]")
+    _lib.check(lib.msfwsi_conv_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(ps), _p(psh), _p(bias), _p(stats), nsh,
+                                   _stream()), "conv_fwd")
+    return y
+
+
+def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0):
+    lib = _lib.load()
+    dt = dy.dtype
+    _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
+    _req(w, "w", dt, d.K * d.R * d.S * d.C)
+    _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
+    _opt(resid, "resid", dt, d.N * d.H * d.W * d.C)
+    _opt(gapg, "gapg", dt, d.N * d.C)
+    _lib.check(lib.msfwsi_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(gapg), float(gap_scale),
+                                     _stream()), "conv_dgrad")
+    return dx
+
+
+def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=1024):
+    lib = _lib.load()
+    dt = x.dtype
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
+    _req(dw, "dw", torch.float32, d.K * d.R * d.S * d.C)
+    ps = psh = None
+    if pro is not None:
+        ps, psh = pro
+        _req(ps, "pro_scale", torch.float32, d.C)
+        _req(psh, "pro_shift", torch.float32, d.C)
+    _lib.check(lib.msfwsi_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ps), _p(psh), int(target_blocks),
+                                     _stream()), "conv_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
+def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_var, nbt, scale, shift, mean,
+                invstd):
+    lib = _lib.load()
+    _req(sums, "sums", torch.float64)
+    Cn = scale.numel()
+    nsh = sums.numel() // (2 * Cn)
+    if nsh * 2 * Cn != sums.numel():
+        raise ValueError("sums must be [nshard,2,C]")
+    for n, t in (("gamma", gamma), ("beta", beta), ("running_mean", running_mean), ("running_var", running_var)):
+        _opt(t, n, torch.float32, Cn)
+    _opt(nbt, "num_batches_tracked", torch.int64, 1)
+    for n, t in (("scale", scale), ("shift", shift), ("mean", mean), ("invstd", invstd)):
+        _req(t, n, torch.float32, Cn)
+    _lib.check(lib.msfwsi_bn_finalize(_p(sums), nsh, Cn, float(count), _p(gamma), _p(beta), float(eps),
+                                      float(momentum), _p(running_mean), _p(running_var), _p(nbt), _p(scale),
+                                      _p(shift), _p(mean), _p(invstd), _stream()), "bn_finalize")
+
+
+def shard_sum(sums, out):
+    lib = _lib.load()
+    _req(sums, "sums", torch.float64)
+    _req(out, "out", torch.float64)
+    n = out.numel()
+    nsh = sums.numel() // n
+    if nsh * n != sums.numel():
+        raise ValueError("shard_sum: size mismatch")
+    _lib.check(lib.msfwsi_shard_sum(_p(sums), nsh, n, _p(out), _stream()), "shard_sum")
+    return out
+
+
+def bn_act(c, scale, shift, out, ident=None, id_scale=None, id_shift=None, relu=True):
+    lib = _lib.load()
+    Cn = scale.numel()
+    M = c.numel() // Cn
+    _req(c, "c", None, M * Cn)
+    _req(out, "out", c.dtype, M * Cn)
+    _req(scale, "scale", torch.float32, Cn)
+    _req(shift, "shift", torch.float32, Cn)
+    _opt(ident, "ident", c.dtype, M * Cn)
+    _opt(id_scale, "id_scale", torch.float32, Cn)
+    _opt(id_shift, "id_shift", torch.float32, Cn)
+    _lib.check(lib.msfwsi_bn_act(dt_of(c), _p(c), _p(scale), _p(shift), _p(ident), _p(id_scale), _p(id_shift),
+                                 int(bool(relu)), _p(out), M, Cn, _stream()), "bn_act")
+    return out
+
+
+def block_end_bwd(dy, y, gapg, gap_scale, c_main, c_ds, g, sums, HW):
+    lib = _lib.load()
+    Cn = y.shape[-1]
+    M = y.numel() // Cn
+    _req(y, "y")
+    _opt(dy, "dy", y.dtype, M * Cn)
+    _opt(gapg, "gapg", y.dtype, (M // HW) * Cn)
+    _req(c_main, "c_main", y.dtype, M * Cn)
+    _opt(c_ds, "c_ds", y.dtype, M * Cn)
+    _req(g, "g", y.dtype, M * Cn)
+    _req(sums, "sums", torch.float64)
+    nsh = sums.numel() // (3 * Cn)
+    if nsh * 3 * Cn != sums.numel() or M % HW != 0:
+        raise ValueError("block_end_bwd: bad sums / HW")
+    _lib.check(lib.msfwsi_block_end_bwd(dt_of(y), _p(dy), _p(y), _p(gapg), float(gap_scale), _p(c_main), _p(c_ds),
+                                        _p(g), _p(sums), nsh, M, HW, Cn, _stream()), "block_end_bwd")
+
+
+def act_bwd_reduce(da, c, scale, shift, g, sums):
+    lib = _lib.load()
+    Cn = c.shape[-1]
+    M = c.numel() // Cn
+    _req(da, "da", c.dtype, M * Cn)
+    _req(c, "c")
+    _opt(scale, "scale", torch.float32, Cn)
+    _opt(shift, "shift", torch.float32, Cn)
+    _opt(g, "g", c.dtype, M * Cn)
+    _req(sums, "sums", torch.float64)
+    nsh = sums.numel() // (2 * Cn)
+    if nsh * 2 * Cn != sums.numel():
+        raise ValueError("act_bwd_reduce: sums must be [nshard,2,C]")
+    _lib.check(lib.msfwsi_act_bwd_reduce(dt_of(c), _p(da), _p(c), _p(scale), _p(shift), _p(g), _p(sums), nsh, M, Cn,
+                                         _stream()), "act_bwd_reduce")
+
+
+def bn_bwd_finalize(sums, nslots, which, count, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3):
+    lib = _lib.load()
+    Cn = mean.numel()
+    _req(sums, "sums", torch.float64)
+    nsh = sums.numel() // (nslots * Cn)
+    if nsh * nslots * Cn != sums.numel():
+        raise ValueError("bn_bwd_finalize: sums size")
+    for n, t in (("gamma", gamma), ("dgamma", dgamma), ("dbeta", dbeta)):
+        _opt(t, n, torch.float32, Cn)
+    for n, t in (("mean", mean), ("invstd", invstd), ("k1", k1), ("k2", k2), ("k3", k3)):
+        _req(t, n, torch.float32, Cn)
+    _lib.check(lib.msfwsi_bn_bwd_finalize(_p(sums), nsh, nslots, which, Cn, float(count), _p(gamma), _p(mean),
+                                          _p(invstd), _p(dgamma), _p(dbeta), _p(k1), _p(k2), _p(k3), _stream()),
+               "bn_bwd_finalize")
+
+
+def bn_bwd_apply(g, c, k1, k2, k3, dc):
+    lib = _lib.load()
+    Cn = k1.numel()
+    M = c.numel() // Cn
+    _req(g, "g", c.dtype, M * Cn)
+    _req(c, "c")
+    _req(dc, "dc", c.dtype, M * Cn)
+    for n, t in (("k1", k1), ("k2", k2), ("k3", k3)):
+        _req(t, n, torch.float32, Cn)
+    _lib.check(lib.msfwsi_bn_bwd_apply(dt_of(c), _p(g), _p(c), _p(k1), _p(k2), _p(k3), _p(dc), M, Cn, _stream()),
+               "bn_bwd_apply")
+    return dc
+
+
+# ------------------------------------------------------------------------------------------------
+def nchw_to_nhwc(x, y, CP):
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    _req(x, "x", torch.float32)
+    _req(y, "y", None, N * H * W * CP)
+    _lib.check(lib.msfwsi_nchw_to_nhwc(dt_of(y), _p(x), _p(y), N, Cc, H, W, CP, _stream()), "nchw_to_nhwc")
+    return y
+
+
+def stem_pool_fwd(c0, scale, shift, out, argmax, N, H, W, Cn):
+    lib = _lib.load()
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    _req(c0, "c0", None, N * H * W * Cn)
+    _req(out, "out", c0.dtype, N * P * Q * Cn)
+    _req(argmax, "argmax", torch.uint8, N * P * Q * Cn)
+    _req(scale, "scale", torch.float32, Cn)
+    _req(shift, "shift", torch.float32, Cn)
+    _lib.check(lib.msfwsi_stem_pool_fwd(dt_of(c0), _p(c0), _p(scale), _p(shift), _p(out), _p(argmax), N, H, W, Cn,
+                                        _stream()), "stem_pool_fwd")
+
+
+def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn):
+    lib = _lib.load()
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    _req(c0, "c0", None, N * H * W * Cn)
+    _req(dp, "dp", c0.dtype, N * P * Q * Cn)
+    _req(argmax, "argmax", torch.uint8, N * P * Q * Cn)
+    _req(g0, "g0", c0.dtype, N * H * W * Cn)
+    _req(scale, "scale", torch.float32, Cn)
+    _req(shift, "shift", torch.float32, Cn)
+    _req(sums, "sums", torch.float64)
+    nsh = sums.numel() // (2 * Cn)
+    if nsh * 2 * Cn != sums.numel():
+        raise ValueError("stem_pool_bwd: sums must be [nshard,2,C]")
+    _lib.check(lib.msfwsi_stem_pool_bwd(dt_of(c0), _p(dp), _p(argmax), _p(c0), _p(scale), _p(shift), _p(g0),
+                                        _p(sums), nsh, N, H, W, Cn, _stream()), "stem_pool_bwd")
+
+
+def gap_fwd(y, out, N, HW, Cn):
+    lib = _lib.load()
+    _req(y, "y", None, N * HW * Cn)
+    _req(out, "out", y.dtype, N * Cn)
+    _lib.check(lib.msfwsi_gap_fwd(dt_of(y), _p(y), _p(out), N, HW, Cn, _stream()), "gap_fwd")
+    return out
+
+
+def colsum(x, sums):
+    lib = _lib.load()
+    Cn = sums.numel()
+    M = x.numel() // Cn
+    _req(x, "x", None, M * Cn)
+    _req(sums, "sums", torch.float64, Cn)
+    _lib.check(lib.msfwsi_colsum(dt_of(x), _p(x), _p(sums), M, Cn, _stream()), "colsum")
+
+
+def add_f64_to_f32(src, dst, alpha=1.0):
+    lib = _lib.load()
+    _req(src, "src", torch.float64)
+    _req(dst, "dst", torch.float32, src.numel())
+    _lib.check(lib.msfwsi_add_f64_to_f32(_p(src), _p(dst), src.numel(), float(alpha), _stream()), "add_f64_to_f32")
+
+
+def rows_permute(inp, idx, out, B, K, Cn, scatter=False, accumulate=False):
+    lib = _lib.load()
+    _req(inp, "in", None, B * K * Cn)
+    _req(out, "out", inp.dtype, B * K * Cn)
+    _req(idx, "idx", torch.int64, B * K)
+    _lib.check(lib.msfwsi_rows_permute(dt_of(inp), _p(inp), _p(idx), _p(out), B, K, Cn, int(scatter),
+                                       int(accumulate), _stream()), "rows_permute")
+    return out
+
+
+def copy2d(src, src_off, src_ld, dst, dst_off, dst_ld, rows, cols, accumulate=False):
+    """dst.flat[dst_off + r*dst_ld + c] (+)= src.flat[src_off + r*src_ld + c]"""
+    lib = _lib.load()
+    _req(src, "src")
+    _req(dst, "dst", src.dtype)
+    if src_off + (rows - 1) * src_ld + cols > src.numel() or dst_off + (rows - 1) * dst_ld + cols > dst.numel():
+        raise ValueError("copy2d: out of range")
+    es = src.element_size()
+    v = vec_of(src.dtype)
+    if src_off % v or dst_off % v:
+        raise ValueError("copy2d: offsets must be 16-byte aligned")
+    _lib.check(lib.msfwsi_copy2d(dt_of(src), src.data_ptr() + src_off * es, src_ld, dst.data_ptr() + dst_off * es,
+                                 dst_ld, rows, cols, int(accumulate), _stream()), "copy2d")
+
+
+# ------------------------------------------------------------------------------------------------
+def cosine_loss(p, z, coef, loss_accum, dp=None, loss_scale=None, eps=1e-8):
+    lib = _lib.load()
+    rows, dd = p.shape
+    _req(p, "p")
+    _req(z, "z", p.dtype, rows * dd)
+    _opt(dp, "dp", p.dtype, rows * dd)
+    _opt(loss_accum, "loss_accum", torch.float64, 1)
+    _opt(loss_scale, "loss_scale", torch.float32, 1)
+    _lib.check(lib.msfwsi_cosine_loss(dt_of(p), _p(p), _p(z), rows, dd, float(coef), _p(loss_scale), float(eps),
+                                      _p(loss_accum), _p(dp), _stream()), "cosine_loss")
+
+
+def nonfinite_check(g, found):
+    lib = _lib.load()
+    _req(g, "g", torch.float32)
+    _req(found, "found", torch.float32, 1)
+    _lib.check(lib.msfwsi_nonfinite_check(_p(g), g.numel(), _p(found), _stream()), "nonfinite_check")
+
+
+def scaler_update(scale, tracker, found, growth_factor, backoff_factor, growth_interval):
+    lib = _lib.load()
+    _req(scale, "scale", torch.float32, 1)
+    _req(tracker, "tracker", torch.int32, 1)
+    _req(found, "found", torch.float32, 1)
+    _lib.check(lib.msfwsi_scaler_update(_p(scale), _p(tracker), _p(found), float(growth_factor),
+                                        float(backoff_factor), int(growth_interval), _stream()), "scaler_update")
+
+
+def adam(p, g, m, v, lr, beta1, beta2, eps, step, loss_scale=None, found=None, p_bf16=None):
+    lib = _lib.load()
+    n = p.numel()
+    for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _req(t, nm, torch.float32, n)
+    _opt(loss_scale, "loss_scale", torch.float32, 1)
+    _opt(found, "found", torch.float32, 1)
+    _opt(p_bf16, "p_bf16", torch.bfloat16, n)
+    _lib.check(lib.msfwsi_adam(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps),
+                               int(step), _p(loss_scale), _p(found), _p(p_bf16), _stream()), "adam")
+
+
+def cast_bf16(src, dst):
+    lib = _lib.load()
+    _req(src, "src", torch.float32)
+    _req(dst, "dst", torch.bfloat16, src.numel())
+    _lib.check(lib.msfwsi_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_bf16")
+    return dst
+
+
+def pad_cast(src, dst, rows, Cn, CP):
+    lib = _lib.load()
+    _req(src, "src", torch.float32, rows * Cn)
+    _req(dst, "dst", None, rows * CP)
+    _lib.check(lib.msfwsi_pad_cast(dt_of(dst), _p(src), _p(dst), rows, Cn, CP, _stream()), "pad_cast")
+    return dst
+
+
+def unpad_add(src, dst, rows, Cn, CP):
+    lib = _lib.load()
+    _req(src, "src", torch.float32, rows * CP)
+    _req(dst, "dst", torch.float32, rows * Cn)
+    _lib.check(lib.msfwsi_unpad_add(_p(src), _p(dst), rows, Cn, CP, _stream()), "unpad_add")

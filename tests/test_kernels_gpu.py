@@ -1,0 +1,387 @@
+"""Per-kernel numerics on a real MI355X: every C-ABI entry point against a plain PyTorch fp32/fp64 CPU
+reference of the same operator on the same seeded inputs (fp32: rel-L2 <= 2e-5; bf16 storage: <= 1.5e-2,
+inputs pre-rounded to bf16 so only the kernel's own rounding is measured)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 2e-5 if dt == torch.float32 else 1.5e-2
+
+
+def rel(a, b):
+    a = a.double().cpu()
+    b = b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def nhwc(x):  # NCHW cpu fp32 -> NHWC contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def rnd(shape, dt, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dt).float()
+
+
+CONVS = [
+    # N, H, W, C, K, R, stride, pad
+    (2, 14, 14, 64, 64, 3, 1, 1),
+    (3, 13, 11, 32, 128, 3, 2, 1),
+    (2, 9, 9, 64, 256, 1, 1, 0),
+    (2, 10, 10, 128, 64, 1, 2, 0),
+    (2, 20, 20, 8, 64, 7, 2, 3),
+    (5, 1, 1, 64, 16, 1, 1, 0),     # Linear 64->16, 5 rows
+    (130, 1, 1, 16, 64, 1, 1, 0),   # Linear 16->64
+    (9, 1, 1, 576, 144, 1, 1, 0),   # fuser predictor shapes
+    (3, 6, 6, 256, 200, 3, 1, 1),   # K not a tile multiple
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", CONVS)
+@pytest.mark.parametrize("pro", [False, True])
+def test_conv_fwd(hip_lib, dt, geom, pro):
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K, R, st, pad = geom
+    g = torch.Generator().manual_seed(1)
+    x = rnd((N, Cc, H, W), dt, g)
+    w = rnd((K, Cc, R, R), dt, g, 1.0 / math.sqrt(Cc * R * R))
+    bias = torch.randn(K, generator=g)
+    sc = torch.rand(Cc, generator=g) + 0.5
+    sh = torch.randn(Cc, generator=g) * 0.3
+    xin = x
+    if pro:
+        xin = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dt).float()
+    ref = F.conv2d(xin.double(), w.double(), bias.double(), stride=st, padding=pad).float()
+    d = kn.conv_desc(dt, N, H, W, Cc, K, R, R, st, pad)
+    xd = nhwc(x).to(dt).cuda()
+    wd = nhwc(w).to(dt).cuda()
+    y = torch.empty(N, d.P, d.Q, K, dtype=dt, device="cuda")
+    stats = kn.new_stats(K)
+    kn.conv_fwd(d, xd, wd, y, pro=(sc.cuda(), sh.cuda()) if pro else None, bias=bias.cuda(), stats=stats)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert rel(got, ref) < tol(dt)
+    s = stats.sum(0).cpu()
+    yy = y.double().cpu().reshape(-1, K)
+    assert torch.allclose(s[0], yy.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(s[1], (yy * yy).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", CONVS)
+def test_conv_dgrad(hip_lib, dt, geom):
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K, R, st, pad = geom
+    g = torch.Generator().manual_seed(2)
+    d = kn.conv_desc(dt, N, H, W, Cc, K, R, R, st, pad)
+    w = rnd((K, Cc, R, R), dt, g, 1.0 / math.sqrt(K * R * R))
+    dy = rnd((N, K, d.P, d.Q), dt, g)
+    resid = rnd((N, Cc, H, W), dt, g)
+    gapg = rnd((N, Cc), dt, g)
+    ref = torch.nn.grad.conv2d_input((N, Cc, H, W), w.double(), dy.double(), stride=st, padding=pad)
+    ref = ref + resid.double() + 0.25 * gapg.double().view(N, Cc, 1, 1)
+    dx = torch.empty(N, H, W, Cc, dtype=dt, device="cuda")
+    kn.conv_dgrad(d, nhwc(dy).to(dt).cuda(), nhwc(w).to(dt).cuda(), dx, resid=nhwc(resid).to(dt).cuda(),
+                  gapg=gapg.to(dt).cuda(), gap_scale=0.25)
+    torch.cuda.synchronize()
+    assert rel(dx.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", CONVS)
+@pytest.mark.parametrize("pro", [False, True])
+def test_conv_wgrad(hip_lib, dt, geom, pro):
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K, R, st, pad = geom
+    g = torch.Generator().manual_seed(3)
+    d = kn.conv_desc(dt, N, H, W, Cc, K, R, R, st, pad)
+    x = rnd((N, Cc, H, W), dt, g)
+    dy = rnd((N, K, d.P, d.Q), dt, g)
+    sc = torch.rand(Cc, generator=g) + 0.5
+    sh = torch.randn(Cc, generator=g) * 0.3
+    xin = x
+    if pro:
+        xin = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dt).float()
+    ref = torch.nn.grad.conv2d_weight(xin.double(), (K, Cc, R, R), dy.double(), stride=st, padding=pad)
+    dw = torch.zeros(K, R, R, Cc, dtype=torch.float32, device="cuda")
+    for tb in (1, 64):  # one split and many splits accumulate into the same buffer
+        kn.conv_wgrad(d, nhwc(x).to(dt).cuda(), nhwc(dy).to(dt).cuda(), dw,
+                      pro=(sc.cuda(), sh.cuda()) if pro else None, target_blocks=tb)
+    torch.cuda.synchronize()
+    got = dw.cpu().permute(0, 3, 1, 2) * 0.5
+    assert rel(got, ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(300, 64), (7, 144), (5000, 16), (64, 2304)])
+def test_batchnorm_train_fwd_bwd(hip_lib, dt, shape):
+    """conv-epilogue stats -> bn_finalize -> bn_act, then act_bwd_reduce -> bn_bwd_finalize -> bn_bwd_apply
+    against F.batch_norm + relu under autograd."""
+    from msf_wsi_amd import kernels as kn
+
+    M, Cn = shape
+    g = torch.Generator().manual_seed(4)
+    c = rnd((M, Cn), dt, g) * 1.5 + 0.3
+    c = c.to(dt).float()
+    gamma = torch.rand(Cn, generator=g) + 0.5
+    beta = torch.randn(Cn, generator=g) * 0.2
+    rm, rv = torch.randn(Cn, generator=g) * 0.1, torch.rand(Cn, generator=g) + 0.5
+    da = rnd((M, Cn), dt, g)
+    # reference
+    cr = c.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    bn = F.batch_norm(cr, rm_ref, rv_ref, gr, br, training=True, momentum=0.1, eps=1e-5)
+    a = F.relu(bn)
+    a.backward(da.double())
+    # device
+    cd = c.to(dt).cuda()
+    sums = kn.new_stats(Cn)
+    sums[0, 0] = cd.double().sum(0)
+    sums[0, 1] = (cd.double() ** 2).sum(0)
+    scale, shift, mean, invstd = (torch.empty(Cn, device="cuda") for _ in range(4))
+    rmd, rvd = rm.cuda(), rv.cuda()
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    kn.bn_finalize(sums, M, gamma.cuda(), beta.cuda(), 1e-5, 0.1, rmd, rvd, nbt, scale, shift, mean, invstd)
+    out = torch.empty_like(cd)
+    kn.bn_act(cd, scale, shift, out, relu=True)
+    torch.cuda.synchronize()
+    assert rel(out.float(), a.detach()) < tol(dt)
+    assert torch.allclose(rmd.cpu().double(), rm_ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rvd.cpu().double(), rv_ref, rtol=1e-5, atol=1e-6)
+    assert int(nbt.item()) == 1
+    # backward
+    bs = kn.new_stats(Cn)
+    gbuf = torch.empty_like(cd)
+    kn.act_bwd_reduce(da.to(dt).cuda(), cd, scale, shift, gbuf, bs)
+    dgamma, dbeta = torch.zeros(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
+    k1, k2, k3 = (torch.empty(Cn, device="cuda") for _ in range(3))
+    kn.bn_bwd_finalize(bs, 2, 1, M, gamma.cuda(), mean, invstd, dgamma, dbeta, k1, k2, k3)
+    dc = torch.empty_like(cd)
+    kn.bn_bwd_apply(gbuf, cd, k1, k2, k3, dc)
+    torch.cuda.synchronize()
+    t = tol(dt) * (1 if dt == torch.float32 else 2)
+    # activations exactly at the ReLU kink may flip in bf16; rel-L2 absorbs that
+    assert rel(dc.float(), cr.grad) < max(t, 1e-4)
+    assert rel(dgamma, gr.grad) < max(t, 1e-4)
+    assert rel(dbeta, br.grad) < max(t, 1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_residual_block_end(hip_lib, dt):
+    from msf_wsi_amd import kernels as kn
+
+    N, HW, Cn = 3, 25, 64
+    M = N * HW
+    g = torch.Generator().manual_seed(5)
+    c = rnd((M, Cn), dt, g)
+    cds = rnd((M, Cn), dt, g)
+    s1, b1 = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.2
+    s2, b2 = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.2
+    y_ref = F.relu(c * s1 + b1 + cds * s2 + b2)
+    out = torch.empty(M, Cn, dtype=dt, device="cuda")
+    kn.bn_act(c.to(dt).cuda(), s1.cuda(), b1.cuda(), out, ident=cds.to(dt).cuda(), id_scale=s2.cuda(),
+              id_shift=b2.cuda(), relu=True)
+    assert rel(out.float(), y_ref) < tol(dt)
+    out2 = torch.empty(M, Cn, dtype=dt, device="cuda")
+    kn.bn_act(c.to(dt).cuda(), s1.cuda(), b1.cuda(), out2, ident=cds.to(dt).cuda(), relu=True)
+    assert rel(out2.float(), F.relu(c * s1 + b1 + cds)) < tol(dt)
+    # backward sums
+    dy = rnd((M, Cn), dt, g)
+    gap = rnd((N, Cn), dt, g)
+    yv = out.float().cpu()
+    gg = (dy + 0.04 * gap.repeat_interleave(HW, 0)).to(dt).float() * (yv > 0)
+    gbuf = torch.empty(M, Cn, dtype=dt, device="cuda")
+    sums = kn.new_stats(Cn, 3)
+    kn.block_end_bwd(dy.to(dt).cuda(), out, gap.to(dt).cuda(), 0.04, c.to(dt).cuda(), cds.to(dt).cuda(), gbuf, sums,
+                     HW)
+    torch.cuda.synchronize()
+    assert rel(gbuf.float(), gg) < tol(dt)
+    s = sums.sum(0).cpu()
+    gd = gbuf.double().cpu()
+    assert torch.allclose(s[0], gd.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(s[1], (gd * c.double()).sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(s[2], (gd * cds.double()).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hw", [(16, 16), (15, 13)])
+def test_stem_pool(hip_lib, dt, hw):
+    from msf_wsi_amd import kernels as kn
+
+    N, Cn = 2, 64
+    H, W = hw
+    g = torch.Generator().manual_seed(6)
+    c0 = rnd((N, Cn, H, W), dt, g)
+    sc, sh = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.3
+    a = F.relu(c0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dt).double().requires_grad_(True)
+    p_ref = F.max_pool2d(a, 3, 2, 1)
+    P, Q = p_ref.shape[2:]
+    dp = rnd((N, Cn, P, Q), dt, g)
+    p_ref.backward(dp.double())
+    g_ref = a.grad * (a.detach() > 0)
+    c0d = nhwc(c0).to(dt).cuda()
+    out = torch.empty(N, P, Q, Cn, dtype=dt, device="cuda")
+    am = torch.empty(N, P, Q, Cn, dtype=torch.uint8, device="cuda")
+    kn.stem_pool_fwd(c0d, sc.cuda(), sh.cuda(), out, am, N, H, W, Cn)
+    torch.cuda.synchronize()
+    assert rel(out.float().cpu().permute(0, 3, 1, 2), p_ref.detach()) < 1e-6
+    g0 = torch.empty(N, H, W, Cn, dtype=dt, device="cuda")
+    sums = kn.new_stats(Cn)
+    kn.stem_pool_bwd(nhwc(dp).to(dt).cuda(), am, c0d, sc.cuda(), sh.cuda(), g0, sums, N, H, W, Cn)
+    torch.cuda.synchronize()
+    assert rel(g0.float().cpu().permute(0, 3, 1, 2), g_ref) < tol(dt)
+    s = sums.sum(0).cpu()
+    gd = g0.double().cpu().reshape(-1, Cn)
+    assert torch.allclose(s[0], gd.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(s[1], (gd * c0d.double().cpu().reshape(-1, Cn)).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gap_permute_copy_colsum(hip_lib, dt):
+    from msf_wsi_amd import kernels as kn
+
+    g = torch.Generator().manual_seed(7)
+    N, HW, Cn = 5, 49, 128
+    y = rnd((N, HW, Cn), dt, g)
+    out = torch.empty(N, Cn, dtype=dt, device="cuda")
+    kn.gap_fwd(y.to(dt).cuda(), out, N, HW, Cn)
+    assert rel(out.float(), y.mean(1)) < tol(dt)
+    B, K = 3, 16
+    f = rnd((B * K, Cn), dt, g)
+    idx = torch.stack([torch.randperm(K, generator=g) for _ in range(B)])
+    ref = f.view(B, K, Cn)[torch.arange(B).view(-1, 1), idx].reshape(B * K, Cn)
+    o = torch.empty(B * K, Cn, dtype=dt, device="cuda")
+    kn.rows_permute(f.to(dt).cuda(), idx.cuda(), o, B, K, Cn)
+    assert torch.equal(o.float().cpu(), ref)
+    back = torch.zeros(B * K, Cn, dtype=dt, device="cuda")
+    kn.rows_permute(o, idx.cuda(), back, B, K, Cn, scatter=True)
+    assert torch.equal(back.float().cpu(), f)
+    # concat-style copy
+    dst = torch.zeros(B, 9 * Cn, dtype=dt, device="cuda")
+    ctx = rnd((B, Cn), dt, g)
+    kn.copy2d(ctx.to(dt).cuda(), 0, Cn, dst, 0, 9 * Cn, B, Cn)
+    kn.copy2d(f.to(dt).cuda(), 0, K * Cn, dst, Cn, 9 * Cn, B, 8 * Cn)
+    refc = torch.cat([ctx, f.view(B, K, Cn)[:, :8].flatten(1)], 1)
+    assert torch.equal(dst.float().cpu(), refc)
+    kn.copy2d(f.to(dt).cuda(), 0, K * Cn, dst, Cn, 9 * Cn, B, 8 * Cn, accumulate=True)
+    refc[:, Cn:] = (refc[:, Cn:] * 2).to(dt).float()
+    assert torch.equal(dst.float().cpu(), refc)
+    cs = torch.zeros(Cn, dtype=torch.float64, device="cuda")
+    kn.colsum(f.to(dt).cuda(), cs)
+    assert torch.allclose(cs.cpu(), f.double().sum(0), rtol=1e-6, atol=1e-5)
+    acc = torch.ones(Cn, device="cuda")
+    kn.add_f64_to_f32(cs, acc, 2.0)
+    assert torch.allclose(acc.cpu().double(), 1 + 2 * f.double().sum(0), rtol=1e-5, atol=1e-4)
+
+
+def test_nchw_to_nhwc_and_pad(hip_lib):
+    from msf_wsi_amd import kernels as kn
+
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 3, 10, 12, generator=g)
+    for dt, CP in ((torch.float32, 4), (torch.bfloat16, 8)):
+        y = torch.empty(3, 10, 12, CP, dtype=dt, device="cuda")
+        kn.nchw_to_nhwc(x.cuda(), y, CP)
+        ref = torch.zeros(3, 10, 12, CP)
+        ref[..., :3] = x.permute(0, 2, 3, 1)
+        assert torch.equal(y.float().cpu(), ref.to(dt).float())
+        w = torch.randn(64 * 49, 3, generator=g)
+        wp = torch.empty(64 * 49, CP, dtype=dt, device="cuda")
+        kn.pad_cast(w.cuda(), wp, 64 * 49, 3, CP)
+        assert torch.equal(wp.float().cpu()[:, :3], w.to(dt).float())
+        assert wp.float().cpu()[:, 3:].abs().max() == 0
+        gw = torch.randn(64 * 49, CP, generator=g)
+        acc = torch.ones(64 * 49, 3, device="cuda")
+        kn.unpad_add(gw.cuda(), acc, 64 * 49, 3, CP)
+        assert torch.allclose(acc.cpu(), 1 + gw[:, :3])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(8, 64), (128, 512), (5, 4608)])
+def test_cosine_loss(hip_lib, dt, shape):
+    from msf_wsi_amd import kernels as kn
+
+    rows, d = shape
+    g = torch.Generator().manual_seed(9)
+    p = rnd((rows, d), dt, g)
+    z = rnd((rows, d), dt, g)
+    pr = p.double().requires_grad_(True)
+    w = 0.7
+    loss = -(F.cosine_similarity(pr, z.double(), dim=1).mean()) * 0.5 * w
+    (loss * 128.0).backward()
+    acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    dp = torch.empty(rows, d, dtype=dt, device="cuda")
+    ls = torch.full((1,), 128.0, device="cuda")
+    kn.cosine_loss(p.to(dt).cuda(), z.to(dt).cuda(), -0.5 * w / rows, acc, dp, ls)
+    torch.cuda.synchronize()
+    assert abs(acc.item() - loss.item()) < 1e-5
+    assert rel(dp.float(), pr.grad) < tol(dt)
+
+
+def test_adam_and_scaler(hip_lib):
+    from msf_wsi_amd import kernels as kn
+
+    g = torch.Generator().manual_seed(10)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=3e-3)
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    scale = torch.full((1,), 1024.0, device="cuda")
+    found = torch.zeros(1, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        gd = (gr * 1024.0).cuda()
+        kn.nonfinite_check(gd, found)
+        kn.adam(p, gd, m, v, 3e-3, 0.9, 0.999, 1e-8, step, loss_scale=scale, found=found, p_bf16=pb)
+    torch.cuda.synchronize()
+    assert found.item() == 0
+    assert torch.allclose(p.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(pb.float().cpu(), p.cpu().bfloat16().float())
+    # a non-finite gradient: flagged, step skipped, scale backs off
+    gd = torch.randn(n, generator=g).cuda()
+    gd[n - 2] = float("inf")
+    before = p.clone()
+    kn.nonfinite_check(gd, found)
+    kn.adam(p, gd, m, v, 3e-3, 0.9, 0.999, 1e-8, 4, loss_scale=scale, found=found)
+    tracker = torch.zeros(1, dtype=torch.int32, device="cuda")
+    kn.scaler_update(scale, tracker, found, 2.0, 0.5, 2)
+    torch.cuda.synchronize()
+    assert found.item() == 1 and torch.equal(p, before) and scale.item() == 512.0
+    found.zero_()
+    kn.scaler_update(scale, tracker, found, 2.0, 0.5, 2)
+    kn.scaler_update(scale, tracker, found, 2.0, 0.5, 2)
+    torch.cuda.synchronize()
+    assert scale.item() == 1024.0 and tracker.item() == 0
+
+
+def test_bad_arguments_are_rejected(hip_lib):
+    """the ABI refuses malformed geometry instead of launching"""
+    from msf_wsi_amd import kernels as kn
+    from msf_wsi_amd._lib import MsfwsiHipError
+
+    d = kn.conv_desc(torch.float32, 1, 8, 8, 6, 8, 3, 3, 1, 1)  # C=6 is not a 16-byte multiple
+    x = torch.zeros(1, 8, 8, 6, device="cuda")
+    w = torch.zeros(8, 3, 3, 6, device="cuda")
+    y = torch.zeros(1, 8, 8, 8, device="cuda")
+    with pytest.raises(MsfwsiHipError):
+        kn.conv_fwd(d, x, w, y)
+    with pytest.raises(MsfwsiHipError):
+        kn.conv_fwd(kn.conv_desc(torch.float32, 1, 8, 8, 8, 8, 3, 3, 1, 1), x.cpu(), w, y)
