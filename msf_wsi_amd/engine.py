@@ -1,0 +1,646 @@
+"""Execution engine of the MSF-WSI pre-train step on MI355X: schedules the hand-written HIP kernels
+(msf_wsi_amd/csrc via msf_wsi_amd.kernels) for the forward and the hand-derived backward of
+  * the ResNet encoders                      (reference src/models/resnet.py:232-256)
+  * MSFWSI.forward: 4 encoder passes, jigsaw un-shuffle, 24 MLP heads, fuser concat
+                                              (reference src/models/backbone.py:129-222)
+and exposes them to torch autograd as ONE node, so `loss.backward()` of the reference loop
+(tools/ssl_train.py:472) lands in the same kernels and parameter `.grad`s appear as ordinary tensors
+(DDP / optimizers read them unchanged).
+
+Memory model: per conv only the RAW output c is kept (storage dtype); BatchNorm+ReLU are re-applied inside
+the consumer kernels' operand loads from (c, scale, shift), forward and backward.  Residual-block outputs
+are the only normalised activations that are materialised.
+
+There is no CPU / eager-torch fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib
+from . import kernels as kn
+
+
+# ------------------------------------------------------------------------------------------------
+# records
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class BNState:
+    scale: torch.Tensor
+    shift: torch.Tensor
+    mean: torch.Tensor
+    invstd: torch.Tensor
+    count: float  # elements per channel over ALL replicas
+
+
+@dataclass
+class Unit:
+    """one conv/linear (+ optional BatchNorm) application"""
+    op: nn.Module
+    bn: Optional[nn.Module]
+    relu: bool
+    desc: object
+    x: torch.Tensor                  # operand tensor (raw)
+    x_pro: Optional[BNState]         # BatchNorm+ReLU to apply to x on load
+    c: torch.Tensor                  # raw output
+    st: Optional[BNState] = None
+
+
+@dataclass
+class BlockRec:
+    y_in: torch.Tensor
+    units: List[Unit]
+    ds: Optional[Unit]
+    y_out: torch.Tensor
+    HW: int
+    stage: int
+    stage_end: bool
+
+
+@dataclass
+class EncPass:
+    enc: nn.Module
+    N: int
+    H: int
+    W: int
+    xin: torch.Tensor
+    stem: Unit
+    pooled: torch.Tensor
+    amax: torch.Tensor
+    blocks: List[BlockRec]
+    feats: List[torch.Tensor]
+
+
+@dataclass
+class ChainRec:
+    units: List[Unit]
+    out: torch.Tensor
+
+
+@dataclass
+class StepRec:
+    B: int
+    enc: Dict[str, EncPass] = field(default_factory=dict)
+    idx: List[torch.Tensor] = field(default_factory=list)
+    heads: Dict[Tuple[str, int, int], Tuple[ChainRec, ChainRec]] = field(default_factory=dict)
+    tgt_sorted: Dict[Tuple[int, int], torch.Tensor] = field(default_factory=dict)
+
+
+def chan_pad(dtype: torch.dtype) -> int:
+    """stem input channels are zero-padded to one 16-byte chunk"""
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+# ------------------------------------------------------------------------------------------------
+# weights / gradients
+# ------------------------------------------------------------------------------------------------
+class WeightStore:
+    """Compute-dtype operand views of the parameters.  fp32 uses the parameter storage in place
+    (channels_last == [K][R][S][C]); bf16 copies are cast by the HIP cast kernel and cached per parameter
+    version.  A trainer may pre-register externally maintained copies (`register`)."""
+
+    def __init__(self):
+        self._cache: Dict[int, Tuple[int, int, torch.Tensor]] = {}
+        self._ext: Dict[int, torch.Tensor] = {}
+
+    def register(self, param: torch.Tensor, dtype: torch.dtype, tensor: torch.Tensor):
+        self._ext[(id(param), dtype)] = tensor
+
+    @staticmethod
+    def physical(param: torch.Tensor) -> torch.Tensor:
+        """fp32 [K][R][S][C] (or [out][in]) contiguous view of a parameter; re-lays it out once if needed"""
+        if param.dim() == 4:
+            v = param.data.permute(0, 2, 3, 1)
+            if not v.is_contiguous():
+                param.data = param.data.contiguous(memory_format=torch.channels_last)
+                v = param.data.permute(0, 2, 3, 1)
+                if not v.is_contiguous():  # degenerate strides (size-1 dims): force a real copy
+                    param.data = param.data.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+                    v = param.data.permute(0, 2, 3, 1)
+            return v
+        return param.data if param.data.is_contiguous() else param.data.contiguous()
+
+    def get(self, param: torch.Tensor, dtype: torch.dtype, pad_to: int = 0) -> torch.Tensor:
+        ext = self._ext.get((id(param), dtype))
+        if ext is not None:
+            return ext
+        phys = self.physical(param)
+        if dtype == torch.float32 and not pad_to:
+            return phys
+        key = (id(param), dtype)
+        ver = (param._version, phys.data_ptr())
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        if pad_to:
+            rows = phys.numel() // phys.shape[-1]
+            out = torch.empty(*phys.shape[:-1], pad_to, dtype=dtype, device=phys.device)
+            kn.pad_cast(phys, out, rows, phys.shape[-1], pad_to)
+        else:
+            out = torch.empty(phys.shape, dtype=dtype, device=phys.device)
+            kn.cast_bf16(phys, out)
+        self._cache[key] = (ver, out)
+        return out
+
+
+class GradStore:
+    """fp32 gradient accumulators in the kernels' physical layout, created zeroed on first use."""
+
+    def __init__(self):
+        self.bufs: Dict[int, torch.Tensor] = {}
+        self.params: Dict[int, torch.Tensor] = {}
+
+    def get(self, param: torch.Tensor) -> torch.Tensor:
+        b = self.bufs.get(id(param))
+        if b is None:
+            phys = WeightStore.physical(param)
+            b = torch.zeros(phys.shape, dtype=torch.float32, device=phys.device)
+            self.bufs[id(param)] = b
+            self.params[id(param)] = param
+        return b
+
+    def logical(self, param: torch.Tensor) -> Optional[torch.Tensor]:
+        b = self.bufs.get(id(param))
+        if b is None:
+            return None
+        return b.permute(0, 3, 1, 2) if param.dim() == 4 else b
+
+
+# ------------------------------------------------------------------------------------------------
+class Engine:
+    def __init__(self, process_group=None, sync_bn: Optional[bool] = None):
+        self.weights = WeightStore()
+        self.group = process_group
+        self._sync_bn = sync_bn
+        self.update_running = True
+
+    # ---- configuration ---------------------------------------------------------------------
+    @staticmethod
+    def compute_dtype() -> torch.dtype:
+        env = os.environ.get("MSFWSI_DTYPE")
+        if env:
+            return {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                    "bfloat16": torch.bfloat16}[env.lower()]
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            if dt == torch.bfloat16:
+                return dt
+            raise _lib.MsfwsiHipError(
+                f"autocast dtype {dt} is not implemented by the gfx950 kernels; use bf16 (--amp --bf16) or fp32")
+        return torch.float32
+
+    def _world(self) -> int:
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def _sync(self, bn: nn.Module) -> bool:
+        if self._world() == 1:
+            return False
+        if self._sync_bn is not None:
+            return self._sync_bn
+        return isinstance(bn, nn.SyncBatchNorm)
+
+    # ---- BatchNorm helpers ---------------------------------------------------------------------
+    def _bn_finalize(self, stats: torch.Tensor, count: int, bn: nn.Module) -> BNState:
+        Cn = stats.shape[-1]
+        dev = stats.device
+        vecs = torch.empty(4, Cn, dtype=torch.float32, device=dev)
+        total = float(count)
+        if self._sync(bn):
+            packed = torch.empty(2 * Cn, dtype=torch.float64, device=dev)
+            kn.shard_sum(stats, packed)
+            dist.all_reduce(packed, group=self.group)  # RCCL sum of [sum, sumsq]; equal shards per rank
+            stats = packed.view(1, 2, Cn)
+            total *= self._world()
+        if bn.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not used by MSF-WSI")
+        track = self.update_running and bn.track_running_stats and bn.training
+        kn.bn_finalize(stats, total, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
+                       bn.momentum, bn.running_mean if track else None, bn.running_var if track else None,
+                       bn.num_batches_tracked if track else None, vecs[0], vecs[1], vecs[2], vecs[3])
+        return BNState(vecs[0], vecs[1], vecs[2], vecs[3], total)
+
+    def _bn_bwd_coeffs(self, sums: torch.Tensor, nslots: int, which: int, bn: nn.Module, st: BNState,
+                       grads: GradStore):
+        Cn = sums.shape[-1]
+        dev = sums.device
+        if self._sync(bn):
+            packed = torch.empty(nslots * Cn, dtype=torch.float64, device=dev)
+            kn.shard_sum(sums, packed)
+            dist.all_reduce(packed, group=self.group)
+            # parameter gradients are averaged over replicas later (DDP); keep local sums for dgamma/dbeta
+            local = torch.empty(nslots * Cn, dtype=torch.float64, device=dev)
+            kn.shard_sum(sums, local)
+            k = torch.empty(3, Cn, dtype=torch.float32, device=dev)
+            scratch = torch.empty(3, Cn, dtype=torch.float32, device=dev)
+            kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count,
+                               bn.weight if bn.affine else None, st.mean, st.invstd, None, None, k[0], k[1], k[2])
+            if bn.affine:
+                kn.bn_bwd_finalize(local.view(1, nslots, Cn), nslots, which, st.count, bn.weight, st.mean, st.invstd,
+                                   grads.get(bn.weight), grads.get(bn.bias), scratch[0], scratch[1], scratch[2])
+            return k
+        k = torch.empty(3, Cn, dtype=torch.float32, device=dev)
+        kn.bn_bwd_finalize(sums, nslots, which, st.count, bn.weight if bn.affine else None, st.mean, st.invstd,
+                           grads.get(bn.weight) if bn.affine else None, grads.get(bn.bias) if bn.affine else None,
+                           k[0], k[1], k[2])
+        return k
+
+    # ---- single conv / linear unit ---------------------------------------------------------------
+    def _unit_fwd(self, op: nn.Module, bn: Optional[nn.Module], relu: bool, x: torch.Tensor,
+                  x_pro: Optional[BNState], geom, dtype: torch.dtype, pad_c: int = 0) -> Unit:
+        N, H, W, Cin = geom
+        if isinstance(op, nn.Conv2d):
+            K, R, S = op.out_channels, op.kernel_size[0], op.kernel_size[1]
+            stride, pad = op.stride[0], op.padding[0]
+        else:
+            K, R, S, stride, pad = op.out_features, 1, 1, 1, 0
+        d = kn.conv_desc(dtype, N, H, W, Cin, K, R, S, stride, pad)
+        w = self.weights.get(op.weight, dtype, pad_to=pad_c)
+        c = torch.empty(N, d.P, d.Q, K, dtype=dtype, device=x.device)
+        stats = kn.new_stats(K, 2, x.device) if bn is not None else None
+        bias = getattr(op, "bias", None)
+        kn.conv_fwd(d, x, w, c, pro=(x_pro.scale, x_pro.shift) if x_pro is not None else None,
+                    bias=bias.data if bias is not None else None, stats=stats)
+        u = Unit(op, bn, relu, d, x, x_pro, c)
+        if bn is not None:
+            u.st = self._bn_finalize(stats, N * d.P * d.Q, bn)
+        return u
+
+    def _unit_wgrad(self, u: Unit, dc: torch.Tensor, grads: GradStore, dtype: torch.dtype):
+        pro = (u.x_pro.scale, u.x_pro.shift) if u.x_pro is not None else None
+        if u.desc.C != u.op.weight.shape[1]:  # channel-padded stem
+            CP = u.desc.C
+            dwp = torch.zeros(u.desc.K, u.desc.R, u.desc.S, CP, dtype=torch.float32, device=dc.device)
+            kn.conv_wgrad(u.desc, u.x, dc, dwp, pro=pro)
+            rows = u.desc.K * u.desc.R * u.desc.S
+            kn.unpad_add(dwp, grads.get(u.op.weight), rows, u.op.weight.shape[1], CP)
+        else:
+            kn.conv_wgrad(u.desc, u.x, dc, grads.get(u.op.weight), pro=pro)
+        bias = getattr(u.op, "bias", None)
+        if bias is not None:
+            cs = torch.zeros(u.desc.K, dtype=torch.float64, device=dc.device)
+            kn.colsum(dc, cs)
+            kn.add_f64_to_f32(cs, grads.get(bias), 1.0)
+
+    def _unit_dgrad(self, u: Unit, dc: torch.Tensor, dtype: torch.dtype, resid=None, gapg=None, gap_scale=0.0):
+        d = u.desc
+        dx = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dc.device)
+        w = self.weights.get(u.op.weight, dtype)
+        kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale)
+        return dx
+
+    # ---- encoder -------------------------------------------------------------------------------
+    def encoder_forward(self, enc: nn.Module, x: torch.Tensor, dtype: torch.dtype) -> EncPass:
+        if not x.is_cuda:
+            raise _lib.MsfwsiHipError("the MSF-WSI encoders run only on a HIP device (no CPU path)")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected [N,3,H,W] images, got {tuple(x.shape)}")
+        x = x.detach()
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        CP = chan_pad(dtype)
+        xin = torch.empty(N, H, W, CP, dtype=dtype, device=x.device)
+        kn.nchw_to_nhwc(x, xin, CP)
+        stem = self._unit_fwd(enc.conv1, enc.bn1, True, xin, None, (N, H, W, CP), dtype, pad_c=CP)
+        H0, W0 = stem.desc.P, stem.desc.Q
+        P, Q = (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1
+        pooled = torch.empty(N, P, Q, 64, dtype=dtype, device=x.device)
+        amax = torch.empty(N, P, Q, 64, dtype=torch.uint8, device=x.device)
+        kn.stem_pool_fwd(stem.c, stem.st.scale, stem.st.shift, pooled, amax, N, H0, W0, 64)
+        y, h, w = pooled, P, Q
+        blocks: List[BlockRec] = []
+        feats: List[torch.Tensor] = []
+        for si, stage in enumerate(enc.stages()):
+            nb = len(stage)
+            for bi, blk in enumerate(stage):
+                cin = y.shape[-1]
+                units: List[Unit] = []
+                cur, cur_pro, gh, gw = y, None, h, w
+                main = blk.main_branch()
+                for ui, (conv, bn) in enumerate(main):
+                    u = self._unit_fwd(conv, bn, ui + 1 < len(main), cur, cur_pro, (N, gh, gw, cur.shape[-1]), dtype)
+                    units.append(u)
+                    cur, cur_pro, gh, gw = u.c, u.st, u.desc.P, u.desc.Q
+                last = units[-1]
+                ds = None
+                y_out = torch.empty_like(last.c)
+                if blk.downsample is not None:
+                    ds = self._unit_fwd(blk.downsample[0], blk.downsample[1], False, y, None, (N, h, w, cin), dtype)
+                    kn.bn_act(last.c, last.st.scale, last.st.shift, y_out, ident=ds.c, id_scale=ds.st.scale,
+                              id_shift=ds.st.shift, relu=True)
+                else:
+                    kn.bn_act(last.c, last.st.scale, last.st.shift, y_out, ident=y, relu=True)
+                blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1))
+                y, h, w = y_out, gh, gw
+            f = torch.empty(N, y.shape[-1], dtype=dtype, device=x.device)
+            kn.gap_fwd(y, f, N, h * w, y.shape[-1])
+            feats.append(f)
+        return EncPass(enc, N, H, W, xin, stem, pooled, amax, blocks, feats)
+
+    def encoder_backward(self, ps: EncPass, dfeats: Sequence[Optional[torch.Tensor]], grads: GradStore,
+                         dtype: torch.dtype):
+        dy = None
+        for rec in reversed(ps.blocks):
+            gapg = dfeats[rec.stage] if rec.stage_end else None
+            if dy is None and gapg is None:
+                raise RuntimeError("encoder_backward: no gradient reaches the last block")
+            dy = self._block_bwd(rec, dy, gapg, grads, dtype)
+            rec.units = []  # release activations
+            rec.ds = None
+        # stem: maxpool + relu + bn backward, then the 7x7 weight gradient
+        st, u = ps.stem.st, ps.stem
+        H0, W0 = u.desc.P, u.desc.Q
+        g0 = torch.empty_like(u.c)
+        sums = kn.new_stats(64, 2, g0.device)
+        kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, sums, ps.N, H0, W0, 64)
+        k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
+        kn.bn_bwd_apply(g0, u.c, k[0], k[1], k[2], g0)
+        self._unit_wgrad(u, g0, grads, dtype)
+
+    def _block_bwd(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype) -> torch.Tensor:
+        last = rec.units[-1]
+        Cn = last.c.shape[-1]
+        dev = last.c.device
+        g = torch.empty_like(rec.y_out)
+        sums = kn.new_stats(Cn, 3, dev)
+        kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, last.c, rec.ds.c if rec.ds is not None else None, g, sums,
+                         rec.HW)
+        k = self._bn_bwd_coeffs(sums, 3, 1, last.bn, last.st, grads)
+        dc = torch.empty_like(g)
+        kn.bn_bwd_apply(g, last.c, k[0], k[1], k[2], dc)
+        resid = g
+        if rec.ds is not None:
+            kd = self._bn_bwd_coeffs(sums, 3, 2, rec.ds.bn, rec.ds.st, grads)
+            kn.bn_bwd_apply(g, rec.ds.c, kd[0], kd[1], kd[2], g)  # g becomes d(downsample conv output)
+            self._unit_wgrad(rec.ds, g, grads, dtype)
+            resid = self._unit_dgrad(rec.ds, g, dtype)
+        cur = dc
+        for i in range(len(rec.units) - 1, 0, -1):
+            u, prev = rec.units[i], rec.units[i - 1]
+            self._unit_wgrad(u, cur, grads, dtype)
+            da = self._unit_dgrad(u, cur, dtype)
+            s2 = kn.new_stats(prev.c.shape[-1], 2, dev)
+            kn.act_bwd_reduce(da, prev.c, prev.st.scale, prev.st.shift, da, s2)
+            kp = self._bn_bwd_coeffs(s2, 2, 1, prev.bn, prev.st, grads)
+            kn.bn_bwd_apply(da, prev.c, kp[0], kp[1], kp[2], da)
+            cur = da
+        first = rec.units[0]
+        self._unit_wgrad(first, cur, grads, dtype)
+        return self._unit_dgrad(first, cur, dtype, resid=resid)
+
+    # ---- MLP heads -----------------------------------------------------------------------------
+    @staticmethod
+    def _parse_chain(seq: nn.Sequential):
+        plan, cur = [], None
+        for m in seq:
+            if isinstance(m, nn.Linear):
+                if cur is not None:
+                    plan.append(cur)
+                cur = [m, None, False]
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                cur[1] = m
+            elif isinstance(m, nn.ReLU):
+                cur[2] = True
+            else:
+                raise NotImplementedError(f"unsupported head layer {type(m).__name__}")
+        plan.append(cur)
+        return plan
+
+    def chain_forward(self, seq: nn.Sequential, x: torch.Tensor, dtype) -> ChainRec:
+        rows = x.shape[0]
+        cur, cur_pro = x, None
+        units: List[Unit] = []
+        out = None
+        for lin, bn, relu in self._parse_chain(seq):
+            u = self._unit_fwd(lin, bn, relu, cur, cur_pro, (rows, 1, 1, lin.in_features), dtype)
+            units.append(u)
+            if bn is not None and not relu:
+                out = torch.empty_like(u.c)
+                kn.bn_act(u.c, u.st.scale, u.st.shift, out, relu=False)
+                cur, cur_pro = out, None
+            elif bn is not None:
+                cur, cur_pro, out = u.c, u.st, None
+            else:
+                cur, cur_pro, out = u.c, None, u.c
+        if out is None:
+            raise NotImplementedError("a head must end in Linear or BatchNorm (no trailing ReLU)")
+        return ChainRec(units, out.view(rows, -1))
+
+    def chain_backward(self, rec: ChainRec, d_out: torch.Tensor, grads: GradStore, dtype, need_dx=True):
+        """d_out: engine-owned buffer (overwritten in place)."""
+        cur = d_out
+        dev = d_out.device
+        for i in range(len(rec.units) - 1, -1, -1):
+            u = rec.units[i]
+            if u.bn is not None:
+                Cn = u.c.shape[-1]
+                s2 = kn.new_stats(Cn, 2, dev)
+                c2 = u.c.view(-1, Cn)
+                cur2 = cur.view(-1, Cn)
+                if u.relu:
+                    kn.act_bwd_reduce(cur2, c2, u.st.scale, u.st.shift, cur2, s2)
+                else:
+                    kn.act_bwd_reduce(cur2, c2, None, None, None, s2)
+                k = self._bn_bwd_coeffs(s2, 2, 1, u.bn, u.st, grads)
+                kn.bn_bwd_apply(cur2, c2, k[0], k[1], k[2], cur2)
+            self._unit_wgrad(u, cur, grads, dtype)
+            if i > 0 or need_dx:
+                cur = self._unit_dgrad(u, cur, dtype)
+        return cur.view(cur.shape[0], -1) if need_dx else None
+
+    # ---- whole model -----------------------------------------------------------------------------
+    def model_forward(self, model: nn.Module, x1, x2, jigsaw_idx, dtype) -> Tuple[tuple, StepRec]:
+        B = x1[0].shape[0]
+        K, n_keep = model.K, model.n_keep
+        if x1[1].shape[0] != B * K or x2[1].shape[0] != B * K or x2[0].shape[0] != B:
+            raise ValueError("target batches must hold B*K tiles")
+        if jigsaw_idx is None or len(jigsaw_idx) != 2:
+            raise ValueError("jigsaw_idx must be the two [B,K] index tensors")
+        dev = x1[0].device
+        rec = StepRec(B)
+        for v, idx in enumerate(jigsaw_idx):
+            # the only in-path assertion of the reference (backbone.py:152)
+            assert tuple(idx.shape) == (B, K), f"jigsaw_idx[{v}] must be [B,K]"
+            rec.idx.append(idx.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous())
+        # reference call order (backbone.py:140-145): separate BatchNorm batches per call
+        rec.enc["c0"] = self.encoder_forward(model.context_encoder, x1[0], dtype)
+        rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype)
+        rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype)
+        rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype)
+        outs = {}
+        for grp in ("context", "target", "inter"):
+            proj = getattr(model, f"{grp}_projector")
+            pred = getattr(model, f"{grp}_predictor")
+            for s in range(4):
+                for v in range(2):
+                    cf = rec.enc[f"c{v}"].feats[s]
+                    tf = rec.enc[f"t{v}"].feats[s]
+                    Cs = cf.shape[-1]
+                    if grp == "context":
+                        f = cf
+                    elif grp == "target":
+                        f = torch.empty_like(tf)
+                        kn.rows_permute(tf, rec.idx[v], f, B, K, Cs)
+                        rec.tgt_sorted[(s, v)] = f
+                    else:
+                        D = (n_keep + 1) * Cs
+                        f = torch.empty(B, D, dtype=dtype, device=dev)
+                        kn.copy2d(cf, 0, Cs, f, 0, D, B, Cs)
+                        kn.copy2d(tf, 0, K * Cs, f, Cs, D, B, n_keep * Cs)
+                    zrec = self.chain_forward(proj[s], f, dtype)
+                    prec = self.chain_forward(pred[s], zrec.out, dtype)
+                    rec.heads[(grp, s, v)] = (zrec, prec)
+                    outs[(grp, s, v)] = (prec.out, zrec.out)
+        result = []
+        for grp in ("context", "target", "inter"):
+            result.append((tuple(outs[(grp, s, 0)][0] for s in range(4)), tuple(outs[(grp, s, 1)][0] for s in range(4)),
+                           tuple(outs[(grp, s, 0)][1] for s in range(4)), tuple(outs[(grp, s, 1)][1] for s in range(4))))
+        return tuple(result), rec
+
+    def model_backward(self, model: nn.Module, rec: StepRec, dps: Dict[Tuple[str, int, int], torch.Tensor],
+                       grads: GradStore, dtype, on_group_done=None):
+        """dps[(group, scale, view)] = dLoss/dp (engine-owned, storage dtype).  Fills `grads`."""
+        B, K, n_keep = rec.B, model.K, model.n_keep
+        dcf = [[None] * 4 for _ in range(2)]
+        dtf = [[None] * 4 for _ in range(2)]
+        for grp in ("context", "target", "inter"):
+            for s in range(4):
+                for v in range(2):
+                    zrec, prec = rec.heads.pop((grp, s, v))
+                    dp = dps[(grp, s, v)]
+                    dz = self.chain_backward(prec, dp, grads, dtype)
+                    df = self.chain_backward(zrec, dz.contiguous(), grads, dtype)
+                    Cs = rec.enc[f"c{v}"].feats[s].shape[-1]
+                    if grp == "context":
+                        dcf[v][s] = df
+                    elif grp == "target":
+                        out = torch.empty_like(df)
+                        kn.rows_permute(df, rec.idx[v], out, B, K, Cs, scatter=True)
+                        dtf[v][s] = out
+                    else:
+                        D = (n_keep + 1) * Cs
+                        kn.copy2d(df, 0, D, dcf[v][s], 0, Cs, B, Cs, accumulate=True)
+                        kn.copy2d(df, Cs, D, dtf[v][s], 0, K * Cs, B, n_keep * Cs, accumulate=True)
+            if grp == "inter" and on_group_done is not None:
+                on_group_done("inter")
+        for name, df in (("t1", dtf[1]), ("t0", dtf[0])):
+            self.encoder_backward(rec.enc.pop(name), df, grads, dtype)
+        if on_group_done is not None:
+            on_group_done("target")
+        for name, df in (("c1", dcf[1]), ("c0", dcf[0])):
+            self.encoder_backward(rec.enc.pop(name), df, grads, dtype)
+        if on_group_done is not None:
+            on_group_done("context")
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd bridges (the drop-in boundary)
+# ------------------------------------------------------------------------------------------------
+_default_engine: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _default_engine
+    if _default_engine is None:
+        _lib.load()  # fail loudly before anything else if the HIP library is absent
+        _default_engine = Engine()
+    return _default_engine
+
+
+def _as_engine_grad(g: Optional[torch.Tensor], like: torch.Tensor) -> torch.Tensor:
+    if g is None:
+        return torch.zeros_like(like)
+    return g.to(dtype=like.dtype).contiguous().clone()
+
+
+class _ModelFn(torch.autograd.Function):
+    """Whole-model node: inputs = images + every parameter; outputs = 24 p (differentiable) + 24 z."""
+
+    @staticmethod
+    def forward(ctx, model, engine, dtype, x1c, x1t, x2c, x2t, idx1, idx2, *params):
+        outs, rec = engine.model_forward(model, (x1c, x1t), (x2c, x2t), [idx1, idx2], dtype)
+        ctx.model, ctx.engine, ctx.dtype, ctx.rec = model, engine, dtype, rec
+        ctx.params_ref = params
+        flat_p, flat_z = [], []
+        for grp in outs:
+            flat_p += list(grp[0]) + list(grp[1])
+            flat_z += list(grp[2]) + list(grp[3])
+        ctx.mark_non_differentiable(*flat_z)
+        return tuple(flat_p + flat_z)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        model, engine, dtype, rec = ctx.model, ctx.engine, ctx.dtype, ctx.rec
+        if rec is None:
+            raise RuntimeError("the MSF-WSI HIP node supports a single backward pass")
+        ctx.rec = None
+        dps = {}
+        i = 0
+        for grp in ("context", "target", "inter"):
+            for v in range(2):
+                for s in range(4):
+                    like = rec.heads[(grp, s, v)][1].out
+                    dps[(grp, s, v)] = _as_engine_grad(gouts[i], like)
+                    i += 1
+        grads = GradStore()
+        engine.model_backward(model, rec, dps, grads, dtype)
+        pgrads = tuple(grads.logical(p) for p in ctx.params_ref)
+        return (None,) * 9 + pgrads
+
+
+def msfwsi_apply(model: nn.Module, x1, x2, jigsaw_idx):
+    eng = getattr(model, "_engine", None) or default_engine()
+    dtype = eng.compute_dtype()
+    params = [p for p in model.parameters()]
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    if not need_grad:
+        outs, _ = eng.model_forward(model, x1, x2, jigsaw_idx, dtype)
+        return outs
+    if jigsaw_idx is None or len(jigsaw_idx) != 2:
+        raise ValueError("jigsaw_idx must be the two [B,K] index tensors")
+    flat = _ModelFn.apply(model, eng, dtype, x1[0], x1[1], x2[0], x2[1], jigsaw_idx[0], jigsaw_idx[1], *params)
+    p, z = flat[:24], flat[24:]
+    res = []
+    for gi in range(3):
+        res.append((tuple(p[gi * 8:gi * 8 + 4]), tuple(p[gi * 8 + 4:gi * 8 + 8]), tuple(z[gi * 8:gi * 8 + 4]),
+                    tuple(z[gi * 8 + 4:gi * 8 + 8])))
+    return tuple(res)
+
+
+class _EncoderFn(torch.autograd.Function):
+    """Stand-alone encoder node (ResNet.forward outside MSFWSI)."""
+
+    @staticmethod
+    def forward(ctx, enc, engine, dtype, x, *params):
+        ps = engine.encoder_forward(enc, x, dtype)
+        ctx.enc, ctx.engine, ctx.dtype, ctx.ps, ctx.params = enc, engine, dtype, ps, params
+        return tuple(ps.feats)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ps = ctx.ps
+        if ps is None:
+            raise RuntimeError("the MSF-WSI HIP node supports a single backward pass")
+        ctx.ps = None
+        df = [_as_engine_grad(g, f) for g, f in zip(gouts, ps.feats)]
+        grads = GradStore()
+        ctx.engine.encoder_backward(ps, df, grads, ctx.dtype)
+        return (None,) * 4 + tuple(grads.logical(p) for p in ctx.params)
+
+
+def encoder_apply(enc: nn.Module, x: torch.Tensor):
+    eng = getattr(enc, "_engine", None) or default_engine()
+    dtype = eng.compute_dtype()
+    params = [p for n, p in enc.named_parameters() if not n.startswith("fc.")]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _EncoderFn.apply(enc, eng, dtype, x, *params)
+    return tuple(eng.encoder_forward(enc, x, dtype).feats)

@@ -1,0 +1,245 @@
+"""Generates the golden vectors under tests/golden/ by running the REAL reference.
+
+Run only in the build container (needs /root/reference; never runs on the GPU box):
+    python tests/golden/make_golden.py [case ...]
+
+For every case it
+  1. imports the reference's src/models (torch.hub download stubbed: offline) and builds MSFWSI under a seed,
+  2. runs forward + the ssl_train.py loss + backward + torch.optim.Adam (3 prefix groups) in fp64 and fp32,
+  3. asserts that oracle/msfwsi_oracle.py reproduces the reference (outputs, loss, grads, updated weights),
+  4. asserts that the product's module tree (msf_wsi_amd.models) built under the same seed has the identical
+     state dict (keys, order, shapes, dtypes, values),
+  5. writes <case>.npz (vectors) and <case>.json (manifest: seeds, key list, shapes).
+The npz files hold data only (inputs are regenerated from seeds by oracle.synthetic_batch).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+MODEL_SEED, HUB_SEED, DATA_SEED = 3407, 1234, 0
+WEIGHTS = (0.1, 0.4, 0.7, 1.0)
+LR = 1e-3
+
+CASES = {
+    # name: (arch, B, image size, run adam?, run fp64?)
+    "r18_b2_s64": ("resnet18", 2, 64, True, True),
+    "r18_b8_s64": ("resnet18", 8, 64, True, True),
+    "r18_b8_s224": ("resnet18", 8, 224, True, False),
+    "r50_b2_s64": ("resnet50", 2, 64, False, False),
+}
+
+
+def hub_stub(resnet_mod):
+    """offline stand-in for torch.hub.load_state_dict_from_url: a fresh un-pretrained net of the same arch
+    under HUB_SEED; the caller's RNG stream is left untouched."""
+
+    def fake(url, progress=True, **kw):
+        arch = [k for k, v in resnet_mod.model_urls.items() if v == url][0]
+        state = torch.random.get_rng_state()
+        torch.manual_seed(HUB_SEED)
+        sd = resnet_mod.__dict__[arch](pretrained=False).state_dict()
+        torch.random.set_rng_state(state)
+        return sd
+
+    return fake
+
+
+def build_reference(arch):
+    sys.path.insert(0, REF)
+    from src.models import resnet as ref_resnet
+    from src.models import backbone as ref_backbone
+
+    torch.hub.load_state_dict_from_url = hub_stub(ref_resnet)
+    torch.manual_seed(MODEL_SEED)
+    if arch == "resnet50":
+        # derived oracle: reference trunk + reference head factories + reference forward;
+        # only the width list of backbone.py:67 is scaled by the block expansion.
+        import torch.nn as nn
+
+        m = ref_backbone.MSFWSI.__new__(ref_backbone.MSFWSI)
+        nn.Module.__init__(m)
+        m.K, m.n_keep = 16, 8
+        m.context_encoder = ref_resnet.resnet50(zero_init_residual=True, pretrained=True, return_features=True)
+        m.target_encoder = ref_resnet.resnet50(zero_init_residual=True, pretrained=True, return_features=True)
+        m.context_encoder.fc = nn.Identity()
+        m.target_encoder.fc = nn.Identity()
+        m.inter_dim = torch.as_tensor([64, 128, 256, 512]) * 4
+        m.ms_inter_dim = m.inter_dim * (m.n_keep + 1)
+        mk, mp = ref_backbone.make_projector, ref_backbone.make_predictor
+        m.context_projector = nn.ModuleList([mk(d, d) for d in m.inter_dim])
+        m.target_projector = nn.ModuleList([mk(d, d) for d in m.inter_dim])
+        m.inter_projector = nn.ModuleList([mk(d, d) for d in m.ms_inter_dim])
+        m.context_predictor = nn.ModuleList([mp(d, torch.div(d, 4, rounding_mode="floor")) for d in m.inter_dim])
+        m.target_predictor = nn.ModuleList([mp(d, torch.div(d, 4, rounding_mode="floor")) for d in m.inter_dim])
+        m.inter_predictor = nn.ModuleList([mp(d, torch.div(d, 4, rounding_mode="floor")) for d in m.ms_inter_dim])
+        return m
+    return ref_backbone.MSFWSI(ref_resnet.__dict__[arch], 4)
+
+
+def build_product(arch):
+    from msf_wsi_amd.models import resnet as my_resnet
+    from msf_wsi_amd.models.backbone import MSFWSI
+
+    torch.hub.load_state_dict_from_url = hub_stub(my_resnet)
+    torch.manual_seed(MODEL_SEED)
+    return MSFWSI(my_resnet.__dict__[arch], 4)
+
+
+def reference_step(model, batch, B, do_adam):
+    """restates tools/ssl_train.py:281-310 (optimizer) and :441-474 (step) around the reference model"""
+    import torch.nn as nn
+
+    (c1, c2), (t1, t2), idx = batch
+    named = list(model.named_parameters())
+    groups = [[p for n, p in named if n.startswith(pre)] for pre in ("context_", "target_", "inter_")]
+    lr = LR * (B ** 0.5) / (32 ** 0.5)
+    opt = torch.optim.Adam([{"params": g, "lr": lr} for g in groups], lr=lr)
+    cos = nn.CosineSimilarity(dim=1)
+    model.train()
+    out = model((c1, t1), (c2, t2), idx)
+    loss = 0
+    terms = []
+    for grp in out:
+        for i, (p1, p2, z1, z2) in enumerate(zip(*grp)):
+            t = -(cos(p1, z2).mean() + cos(p2, z1).mean()) * 0.5
+            terms.append(t.detach().clone())
+            loss = loss + t * WEIGHTS[i]
+    opt.zero_grad()
+    loss.backward()
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in named}
+    if do_adam:
+        opt.step()
+    return loss.detach(), torch.stack(terms), out, grads
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def run_case(name):
+    from oracle import msfwsi_oracle as orc
+
+    arch, B, size, do_adam, do_f64 = CASES[name]
+    t0 = time.time()
+    ref = build_reference(arch)
+    sd0 = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    print(f"[{name}] reference built in {time.time() - t0:.1f}s, {len(sd0)} entries")
+
+    # (4) product module tree under the same seed -> identical state dict
+    prod = build_product(arch)
+    psd = prod.state_dict()
+    assert list(psd.keys()) == list(sd0.keys()), "state-dict key order differs"
+    for k in sd0:
+        assert psd[k].shape == sd0[k].shape and psd[k].dtype == sd0[k].dtype, k
+        assert torch.equal(psd[k], sd0[k]), f"init mismatch at {k}"
+    del prod, psd
+    print(f"[{name}] product init == reference init")
+
+    batch = orc.synthetic_batch(B, size, 16, DATA_SEED)
+    vec = {}
+    manifest = {"case": name, "arch": arch, "B": B, "size": size, "model_seed": MODEL_SEED, "hub_seed": HUB_SEED,
+                "data_seed": DATA_SEED, "lr": LR, "weights": WEIGHTS, "adam": do_adam,
+                "keys": [[k, list(v.shape), str(v.dtype)] for k, v in sd0.items()],
+                "provenance": "reference src/models imported from /root/reference"
+                + ("; resnet50 = derived oracle (width list x4), SURVEY.md 8c" if arch == "resnet50" else "")}
+    vec["init_sum"] = np.array([float(v.double().sum()) for v in sd0.values()])
+    vec["init_abs"] = np.array([float(v.double().abs().sum()) for v in sd0.values()])
+
+    # ---- fp32 reference run
+    loss32, terms32, out32, grads32 = reference_step(ref, batch, B, do_adam)
+    sd1 = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    print(f"[{name}] fp32 reference step done ({time.time() - t0:.1f}s) loss={loss32.item():.9f}")
+
+    # ---- (3) oracle vs reference, fp32, same initial state
+    osd = {k: v.clone() for k, v in sd0.items()}
+    lr = orc.init_lr(LR, B)
+    opt = orc.Adam(osd, [lr, lr, lr])
+    if not do_adam:
+        opt.step = lambda *a, **k: None
+    oloss, oterms, oout, ograds = orc.train_step(osd, batch, opt, 4, 0.5, WEIGHTS)
+    assert abs(oloss.item() - loss32.item()) < 1e-6, (oloss.item(), loss32.item())
+    flat_o = [t for grp in oout for tup in grp for t in tup]
+    flat_r = [t for grp in out32 for tup in grp for t in tup]
+    for a, b in zip(flat_o, flat_r):
+        assert rel(a, b) < 1e-5
+    worst = 0.0
+    for k, gref in grads32.items():
+        if gref is None:
+            assert ograds[k] is None
+            continue
+        worst = max(worst, rel(ograds[k], gref))
+    assert worst < 1e-4, worst
+    for k in sd1:
+        if sd1[k].dtype.is_floating_point:
+            assert rel(osd[k], sd1[k]) < 1e-5, k
+        else:
+            assert torch.equal(osd[k], sd1[k]), k
+    print(f"[{name}] oracle == reference (worst grad rel {worst:.2e})")
+
+    gold_loss, gold_terms, gold_out, gold_grads, gold_sd1 = loss32, terms32, out32, grads32, sd1
+    if do_f64:
+        del ref
+        ref64 = build_reference(arch).double()
+        b64 = orc.synthetic_batch(B, size, 16, DATA_SEED, torch.float64)
+        loss64, terms64, out64, grads64 = reference_step(ref64, b64, B, do_adam)
+        sd1_64 = {k: v.detach().clone() for k, v in ref64.state_dict().items()}
+        gold_loss, gold_terms, gold_out, gold_grads, gold_sd1 = loss64, terms64, out64, grads64, sd1_64
+        print(f"[{name}] fp64 reference loss={loss64.item():.12f}")
+        # the reference's own fp32<->fp64 spread: the parity noise floor per tensor
+        vec["spread_grad"] = np.array([rel(grads32[k], grads64[k]) if grads64[k] is not None else 0.0
+                                       for k in grads64])
+        vec["spread_terms"] = (terms32.double() - terms64).abs().numpy()
+
+    vec["loss"] = np.array([float(gold_loss)])
+    vec["loss_fp32"] = np.array([float(loss32)])
+    vec["terms"] = gold_terms.double().numpy()
+    names = ["p1", "p2", "z1", "z2"]
+    for gi, gname in enumerate(("context", "target", "fuser")):
+        for ti in range(4):
+            for s in range(4):
+                t = gold_out[gi][ti][s].detach()
+                rows = t if gname != "target" else t[:: max(1, t.shape[0] // 8)][:8]
+                vec[f"out/{gname}/{names[ti]}/{s}"] = rows.float().numpy()
+                vec[f"outnorm/{gname}/{names[ti]}/{s}"] = np.array([float(t.double().norm())])
+    pkeys = [k for k in gold_grads]
+    manifest["param_keys"] = pkeys
+    vec["grad_norm"] = np.array([float(gold_grads[k].double().norm()) if gold_grads[k] is not None else 0.0
+                                 for k in pkeys])
+    vec["grad_sum"] = np.array([float(gold_grads[k].double().sum()) if gold_grads[k] is not None else 0.0
+                                for k in pkeys])
+    for k in pkeys:  # a few full small gradients
+        if gold_grads[k] is not None and gold_grads[k].numel() <= 512 and ("bn" in k or k.endswith(".bias")
+                                                                           or ".1." in k or ".4." in k):
+            if k.startswith(("context_encoder.bn1", "target_encoder.layer4.1.bn2", "inter_predictor.3.3.bias",
+                             "context_projector.0.1", "target_predictor.2.1")):
+                vec[f"grad/{k}"] = gold_grads[k].float().numpy()
+    if do_adam:
+        vec["step_norm"] = np.array([float((gold_sd1[k].double() - sd0[k].double()).norm()) for k in pkeys])
+        vec["w1_sum"] = np.array([float(gold_sd1[k].double().sum()) for k in pkeys])
+    for k in ("context_encoder.bn1", "target_encoder.layer2.0.downsample.1", "target_encoder.layer4.1.bn2",
+              "inter_projector.0.1", "context_predictor.3.1"):
+        key = k if arch != "resnet50" else k.replace("layer4.1.bn2", "layer4.1.bn3")
+        vec[f"bn/{key}/running_mean"] = gold_sd1[key + ".running_mean"].float().numpy()
+        vec[f"bn/{key}/running_var"] = gold_sd1[key + ".running_var"].float().numpy()
+        vec[f"bn/{key}/nbt"] = np.array([int(gold_sd1[key + ".num_batches_tracked"])])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **vec)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump(manifest, f, indent=0)
+    print(f"[{name}] wrote fixtures ({time.time() - t0:.1f}s)")
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ["r18_b2_s64", "r18_b8_s64", "r18_b8_s224"]
+    torch.set_num_threads(8)
+    for c in todo:
+        run_case(c)
