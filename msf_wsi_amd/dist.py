@@ -1,0 +1,148 @@
+"""Data-parallel host logic for the MSF-WSI pre-train step: one process per GPU, torch.distributed
+("nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+What the reference does (tools/ssl_train.py:160-170, :262-275): DistributedSampler shards whole samples,
+SyncBatchNorm makes an N-rank step identical to a 1-rank step on the concatenated batch, DDP averages
+gradients with 25 MB buckets.  Here:
+  * `FlatGroups`   lays the three optimizer groups (context_/target_/inter_, ssl_train.py:281-300) out as flat
+                   fp32 buffers (weights, grads, Adam moments [+ bf16 copy]) so one kernel / one collective
+                   covers a whole group; parameters become views (conv weights keep channels_last order).
+  * `GradReducer`  launches one asynchronous all-reduce per group as soon as the backward schedule finishes
+                   it (heads first = 80 % of the bytes), i.e. large messages that RCCL can spread over all
+                   seven xGMI links, overlapped with the remaining encoder backward.
+  * `sync_sums`    the cross-replica BatchNorm exchange: a SUM all-reduce of packed fp64 [sum, sumsq] vectors
+                   (sums are associative, so the result equals full-batch statistics exactly).
+None of this touches the GPU directly: it is plain tensor/collective plumbing and runs under gloo on CPU.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+GROUP_PREFIXES = ("context_", "target_", "inter_")
+ALIGN = 64  # elements: every parameter starts on a 256-byte boundary of the flat buffer
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_range(n_samples: int, world: int, r: int) -> Tuple[int, int]:
+    """contiguous per-rank slice of whole samples (a sample = 1 context + K target tiles, both views)"""
+    if n_samples % world != 0:
+        raise ValueError(f"global batch {n_samples} is not divisible by world size {world} (drop_last semantics)")
+    per = n_samples // world
+    return r * per, (r + 1) * per
+
+
+def sync_sums(packed: torch.Tensor, group=None) -> torch.Tensor:
+    """in-place SUM all-reduce of a packed statistics vector"""
+    if world_size(group) > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed
+
+
+class FlatGroups:
+    """Flat storage of the model parameters by optimizer group."""
+
+    def __init__(self, model: nn.Module, with_bf16: bool, device=None):
+        named = list(model.named_parameters())
+        self.names: List[List[str]] = [[n for n, _ in named if n.startswith(p)] for p in GROUP_PREFIXES]
+        self.params: List[List[nn.Parameter]] = [[p for n, p in named if n.startswith(pre)] for pre in GROUP_PREFIXES]
+        covered = sum(len(g) for g in self.params)
+        if covered != len(named):
+            raise ValueError("every parameter must belong to one of the context_/target_/inter_ groups")
+        self.offsets: List[List[int]] = []
+        self.sizes: List[int] = []
+        self.w: List[torch.Tensor] = []
+        self.g: List[torch.Tensor] = []
+        self.m: List[torch.Tensor] = []
+        self.v: List[torch.Tensor] = []
+        self.w16: List[Optional[torch.Tensor]] = []
+        for plist in self.params:
+            offs, total = [], 0
+            for p in plist:
+                offs.append(total)
+                total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            dev = device if device is not None else plist[0].device
+            self.offsets.append(offs)
+            self.sizes.append(total)
+            self.w.append(torch.zeros(total, dtype=torch.float32, device=dev))
+            self.g.append(torch.zeros(total, dtype=torch.float32, device=dev))
+            self.m.append(torch.zeros(total, dtype=torch.float32, device=dev))
+            self.v.append(torch.zeros(total, dtype=torch.float32, device=dev))
+            self.w16.append(torch.zeros(total, dtype=torch.bfloat16, device=dev) if with_bf16 else None)
+        self._grad_views: Dict[int, torch.Tensor] = {}
+        self._w16_views: Dict[int, torch.Tensor] = {}
+        for gi, plist in enumerate(self.params):
+            for p, off in zip(plist, self.offsets[gi]):
+                phys_shape = self.physical_shape(p)
+                n = p.numel()
+                src = p.data.permute(0, 2, 3, 1) if p.dim() == 4 else p.data
+                self.w[gi][off:off + n].view(phys_shape).copy_(src)
+                p.data = self._logical(self.w[gi][off:off + n].view(phys_shape), p)
+                self._grad_views[id(p)] = self.g[gi][off:off + n].view(phys_shape)
+                if with_bf16:
+                    self._w16_views[id(p)] = self.w16[gi][off:off + n].view(phys_shape)
+
+    @staticmethod
+    def physical_shape(p: torch.Tensor):
+        return (p.shape[0], p.shape[2], p.shape[3], p.shape[1]) if p.dim() == 4 else tuple(p.shape)
+
+    @staticmethod
+    def _logical(phys: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+        return phys.permute(0, 3, 1, 2) if p.dim() == 4 else phys
+
+    def grad_view(self, p: torch.Tensor) -> torch.Tensor:
+        return self._grad_views[id(p)]
+
+    def w16_view(self, p: torch.Tensor) -> Optional[torch.Tensor]:
+        return self._w16_views.get(id(p))
+
+    def state_views(self, gi: int, pi: int):
+        """(exp_avg, exp_avg_sq) of one parameter in its logical shape"""
+        p = self.params[gi][pi]
+        off, n = self.offsets[gi][pi], p.numel()
+        shp = self.physical_shape(p)
+        return (self._logical(self.m[gi][off:off + n].view(shp), p), self._logical(self.v[gi][off:off + n].view(shp), p))
+
+    def zero_grads(self):
+        for g in self.g:
+            g.zero_()
+
+
+class GradReducer:
+    """Per-group asynchronous gradient averaging (the DDP reduction of tools/ssl_train.py:170)."""
+
+    def __init__(self, flats: FlatGroups, group=None):
+        self.flats = flats
+        self.group = group
+        self.pending: List[Tuple[int, object]] = []
+        self.world = world_size(group)
+
+    def launch(self, group_name: str):
+        if self.world == 1:
+            return
+        gi = {"context": 0, "target": 1, "inter": 2}[group_name]
+        buf = self.flats.g[gi]
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            work = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            self.pending.append((-1, work))
+        else:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append((gi, work))
+
+    def wait(self):
+        for gi, work in self.pending:
+            work.wait()
+            if gi >= 0:
+                self.flats.g[gi].mul_(1.0 / self.world)
+        self.pending = []

@@ -1,0 +1,235 @@
+"""The MSF-WSI pre-train step as one fused, graph-free schedule on MI355X.
+
+`PretrainStep.step(batch)` performs exactly one iteration of the reference's hot loop
+(tools/ssl_train.py:425-474): forward of MSFWSI (src/models/backbone.py:129-222), the weighted
+negative-cosine loss over 3 groups x 4 scales (:448-466), backward, gradient averaging across data-parallel
+ranks (DDP, :170), GradScaler protocol (:100, :472-474) and the 3-group Adam update (:281-310) -- with every
+arithmetic operation in the hand-written gfx950 kernels, no host synchronisation inside the step (the
+reference's per-step `loss.item()`, :467, is replaced by a device-side accumulator), flat parameter groups
+(one Adam launch and one RCCL all-reduce per group) and the heads' gradients in flight over xGMI while the
+encoders are still in backward.
+
+Checkpoints keep the reference's dict layout (:375-386): {"epoch","arch","state_dict" (keys prefixed
+"module."),"optimizer" (torch.optim.Adam format, 3 groups),"scaler" (GradScaler format)}; `resume` reproduces
+the reference's quirk of forcing eps=0.1 afterwards (:325-326).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import kernels as kn
+from .dist import FlatGroups, GradReducer, world_size
+from .engine import Engine, GradStore, WeightStore
+
+FUSER_WEIGHTS = (0.1, 0.4, 0.7, 1.0)  # tools/ssl_train.py:623-625
+
+
+class _FlatGradStore(GradStore):
+    """gradient accumulators that live inside the flat per-group buffers"""
+
+    def __init__(self, flats: FlatGroups):
+        super().__init__()
+        self.flats = flats
+
+    def get(self, param):
+        return self.flats.grad_view(param)
+
+    def logical(self, param):
+        b = self.flats.grad_view(param)
+        return b.permute(0, 3, 1, 2) if param.dim() == 4 else b
+
+
+class PretrainStep:
+    def __init__(self, model: nn.Module, lr: float = 1e-3, global_batch: int = 32, ms_lr: Sequence[float] = (1, 1, 1),
+                 fuser_weights: Sequence[float] = FUSER_WEIGHTS, dtype: torch.dtype = torch.bfloat16,
+                 use_scaler: Optional[bool] = None, init_scale: float = 65536.0, process_group=None,
+                 sync_bn: bool = True, arch: str = "resnet18"):
+        _lib.load()
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.MsfwsiHipError("PretrainStep needs the model on a HIP device (model.cuda()); no CPU path")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.MsfwsiHipError(f"unsupported compute dtype {dtype}")
+        self.model = model
+        self.arch = arch
+        self.dtype = dtype
+        self.device = dev
+        self.group = process_group
+        self.weights_per_scale = tuple(float(w) for w in fuser_weights)
+        self.init_lr = lr * math.sqrt(global_batch) / math.sqrt(32)  # ssl_train.py:155 (GLOBAL batch)
+        self.lrs = [self.init_lr * float(m) for m in ms_lr]
+        self.betas = (0.9, 0.999)
+        self.eps = [1e-8, 1e-8, 1e-8]
+        self.t = 0
+        self.flats = FlatGroups(model, with_bf16=(dtype == torch.bfloat16))
+        self.engine = Engine(process_group=process_group, sync_bn=sync_bn)
+        model._engine = self.engine
+        if dtype == torch.bfloat16:
+            for plist in self.flats.params:
+                for p in plist:
+                    if p.dim() >= 2 and not (p.dim() == 4 and p.shape[1] == 3):  # stem: padded copy, cached
+                        self.engine.weights.register(p, torch.bfloat16, self.flats.w16_view(p))
+            for gi in range(3):
+                kn.cast_bf16(self.flats.w[gi], self.flats.w16[gi])
+        self.grads = _FlatGradStore(self.flats)
+        self.reducer = GradReducer(self.flats, process_group)
+        # GradScaler state, resident on the device (the reference enables it whenever --amp, also for bf16)
+        self.use_scaler = (dtype != torch.float32) if use_scaler is None else bool(use_scaler)
+        self.scale = torch.full((1,), init_scale if self.use_scaler else 1.0, dtype=torch.float32, device=dev)
+        self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)
+        # epoch meter of ssl_train.py:421,467-468,483-486: [sum loss*bs, sum bs], kept on the device
+        self.epoch_meter = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    # ---------------------------------------------------------------------------------------
+    def forward_loss(self, batch, want_grad: bool = True):
+        """forward + loss (+ dLoss/dp).  batch = ((ctx_v1, ctx_v2), (tgt_v1, tgt_v2), [idx_v1, idx_v2]) with
+        tgt_v* already flattened to [B*K,3,H,W] (ssl_train.py:433-438)."""
+        (c1, c2), (t1, t2), idx = batch
+        outs, rec = self.engine.model_forward(self.model, (c1, t1), (c2, t2), idx, self.dtype)
+        self.loss_accum.zero_()
+        dps: Dict[Tuple[str, int, int], torch.Tensor] = {}
+        ls = self.scale if self.use_scaler else None
+        for gi, grp in enumerate(("context", "target", "inter")):
+            p1s, p2s, z1s, z2s = outs[gi]
+            for s in range(4):
+                rows = p1s[s].shape[0]
+                coef = -0.5 * self.weights_per_scale[s] / rows
+                for v, (p, z) in enumerate(((p1s[s], z2s[s]), (p2s[s], z1s[s]))):
+                    dp = torch.empty_like(p) if want_grad else None
+                    kn.cosine_loss(p, z, coef, self.loss_accum, dp, ls)
+                    if want_grad:
+                        dps[(grp, s, v)] = dp
+        return outs, rec, dps
+
+    def step(self, batch) -> torch.Tensor:
+        """one optimisation step; returns the (device-resident, fp64) loss of this minibatch"""
+        bs = batch[0][0].shape[0]
+        self.flats.zero_grads()
+        outs, rec, dps = self.forward_loss(batch, want_grad=True)
+        loss = self.loss_accum.clone()
+        self.engine.model_backward(self.model, rec, dps, self.grads, self.dtype, on_group_done=self.reducer.launch)
+        self.reducer.wait()
+        self.optimizer_step()
+        self.epoch_meter[0] += loss[0] * bs
+        self.epoch_meter[1] += bs
+        return loss
+
+    def optimizer_step(self):
+        self.t += 1
+        found = None
+        ls = None
+        if self.use_scaler:
+            self.found_inf.zero_()
+            for g in self.flats.g:
+                kn.nonfinite_check(g, self.found_inf)
+            found, ls = self.found_inf, self.scale
+        for gi in range(3):
+            kn.adam(self.flats.w[gi], self.flats.g[gi], self.flats.m[gi], self.flats.v[gi], self.lrs[gi],
+                    self.betas[0], self.betas[1], self.eps[gi], self.t, loss_scale=ls, found=found,
+                    p_bf16=self.flats.w16[gi])
+        if self.use_scaler:
+            kn.scaler_update(self.scale, self.growth_tracker, self.found_inf, self.growth_factor,
+                             self.backoff_factor, self.growth_interval)
+        # padded / cast copies keyed on torch's version counter do not see raw-pointer updates
+        self.engine.weights._cache.clear()
+
+    def epoch_loss(self) -> float:
+        """sample-weighted mean loss over ranks (ssl_train.py:483-486); syncs once per epoch"""
+        m = self.epoch_meter.clone()
+        if world_size(self.group) > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(m, group=self.group)
+        self.epoch_meter.zero_()
+        return float(m[0] / m[1])
+
+    # ---------------------------------------------------------------------------------------
+    # checkpoint interop (reference dict layout)
+    # ---------------------------------------------------------------------------------------
+    def _torch_adam(self) -> torch.optim.Adam:
+        groups = [{"params": plist, "lr": lr, "eps": eps} for plist, lr, eps in zip(self.flats.params, self.lrs, self.eps)]
+        return torch.optim.Adam(groups, lr=self.init_lr)
+
+    def optimizer_state_dict(self) -> dict:
+        opt = self._torch_adam()
+        if self.t > 0:
+            for gi, plist in enumerate(self.flats.params):
+                for pi, p in enumerate(plist):
+                    m, v = self.flats.state_views(gi, pi)
+                    opt.state[p] = {"step": torch.tensor(float(self.t)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        return opt.state_dict()
+
+    def load_optimizer_state_dict(self, sd: dict):
+        opt = self._torch_adam()
+        opt.load_state_dict(sd)
+        steps = set()
+        for gi, plist in enumerate(self.flats.params):
+            grp = opt.param_groups[gi]
+            self.lrs[gi], self.eps[gi] = float(grp["lr"]), float(grp["eps"])
+            for pi, p in enumerate(plist):
+                st = opt.state.get(p)
+                if not st:
+                    continue
+                m, v = self.flats.state_views(gi, pi)
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ; not a checkpoint of this training loop")
+        self.t = steps.pop() if steps else 0
+
+    def scaler_state_dict(self) -> dict:
+        if not self.use_scaler:
+            return {}
+        return {"scale": float(self.scale.item()), "growth_factor": self.growth_factor,
+                "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
+                "_growth_tracker": int(self.growth_tracker.item())}
+
+    def load_scaler_state_dict(self, sd: dict):
+        if not sd:
+            return
+        self.scale.fill_(float(sd["scale"]))
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+        self.growth_tracker.fill_(int(sd["_growth_tracker"]))
+
+    def checkpoint(self, epoch: int) -> dict:
+        """the dict the reference passes to save_checkpoint (ssl_train.py:375-386); DDP's "module." prefix kept"""
+        sd = {"module." + k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        return {"epoch": epoch + 1, "arch": self.arch, "state_dict": sd, "optimizer": self.optimizer_state_dict(),
+                "scaler": self.scaler_state_dict()}
+
+    def save_checkpoint(self, path: str, epoch: int):
+        torch.save(self.checkpoint(epoch), path)
+
+    def resume(self, ckpt: dict) -> int:
+        """ssl_train.py:313-335 incl. the hard-coded eps=0.1 after loading"""
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt["state_dict"].items()}
+        self.model.load_state_dict(sd)  # copies into the flat-buffer views in place
+        self.load_optimizer_state_dict(ckpt["optimizer"])
+        self.eps = [0.1, 0.1, 0.1]
+        self.load_scaler_state_dict(ckpt.get("scaler", {}))
+        if self.dtype == torch.bfloat16:
+            for gi in range(3):
+                kn.cast_bf16(self.flats.w[gi], self.flats.w16[gi])
+        self.engine.weights._cache.clear()
+        return int(ckpt["epoch"])
+
+
+def synthetic_batch(B: int, size: int = 224, K: int = 16, seed: int = 0, device="cuda"):
+    """Synthetic input with the reference's batch contract (src/utils/data/bcss.py:164-182 after collate and
+    the H2D of ssl_train.py:430-438): N(0,1) images and inverse jigsaw permutations, generated on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    mk = lambda n: torch.randn(n, 3, size, size, generator=g, device=device)
+    c1, c2, t1, t2 = mk(B), mk(B), mk(B * K), mk(B * K)
+    cg = torch.Generator().manual_seed(seed)
+    idx = [torch.stack([torch.argsort(torch.randperm(K, generator=cg)) for _ in range(B)]) for _ in range(2)]
+    return (c1, c2), (t1, t2), idx

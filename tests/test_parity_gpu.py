@@ -5,7 +5,9 @@ against the committed golden vectors produced from the real reference.
 Tolerances (north star: 1e-3 relative, fp32):
   outputs p/z  : rel-L2 <= 1e-3 (expected ~1e-5)
   loss terms   : |d| <= 1e-3 * max(|ref|, 1e-2)
-  gradients    : per-tensor rel-L2 <= max(1e-3, 2 x the reference's own fp32<->fp64 spread for that tensor)
+  gradients    : per-tensor rel-L2 vs the fp64 oracle <= max(1e-3, 2 x the reference's own fp32<->fp64
+                 spread for that tensor) -- early-layer gradients of the reference itself are only good to
+                 ~2.5e-3 in fp32, so the truth is the fp64 run
   Adam update  : per-tensor rel-L2 of the weight DELTA vs oracle, same bound (first step ~ lr*sign(g))
 """
 import numpy as np
@@ -20,7 +22,9 @@ pytestmark = pytest.mark.gpu
 def _oracle_step(sd0, batch, B, adam=True):
     from oracle import msfwsi_oracle as orc
 
-    osd = {k: v.clone() for k, v in sd0.items()}
+    osd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    (c1, c2), (t1, t2), idx = batch
+    batch = ((c1.double(), c2.double()), (t1.double(), t2.double()), idx)
     lr = orc.init_lr(LR, B)
     opt = orc.Adam(osd, [lr, lr, lr])
     if not adam:

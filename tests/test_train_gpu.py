@@ -1,0 +1,146 @@
+"""The fused pre-train step (msf_wsi_amd.train.PretrainStep: HIP loss + backward + flat Adam + scaler) on a
+real MI355X against the fp64 CPU oracle, plus checkpoint interop in the reference's dict layout."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import LR, WEIGHTS, build_product, load_golden, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(sd0, batch, B, steps=1):
+    from oracle import msfwsi_oracle as orc
+
+    osd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    (c1, c2), (t1, t2), idx = batch
+    b64 = ((c1.double(), c2.double()), (t1.double(), t2.double()), idx)
+    lr = orc.init_lr(LR, B)
+    opt = orc.Adam(osd, [lr, lr, lr])
+    losses = []
+    for _ in range(steps):
+        loss, terms, outs, grads = orc.train_step(osd, b64, opt, 4, 0.5, WEIGHTS)
+        losses.append(float(loss))
+    return losses, osd
+
+
+def _gpu_batch(batch):
+    (c1, c2), (t1, t2), idx = batch
+    return (c1.cuda(), c2.cuda()), (t1.cuda(), t2.cuda()), idx
+
+
+def test_fused_step_fp32_matches_oracle(hip_lib):
+    from msf_wsi_amd.train import PretrainStep
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden("r18_b8_s64")
+    B, size = man["B"], man["size"]
+    model = build_product("resnet18")
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
+    olosses, osd = _oracle(sd0, batch, B, steps=2)
+    model = model.cuda().train()
+    ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=True, init_scale=1024.0)
+    gb = _gpu_batch(batch)
+    l1 = ts.step(gb)
+    l2 = ts.step(gb)
+    torch.cuda.synchronize()
+    assert abs(float(l1) - olosses[0]) <= 1e-3 * max(abs(olosses[0]), 1e-2)
+    assert abs(float(l1) - float(vec["loss"][0])) <= 2e-3 * max(abs(float(vec["loss"][0])), 1e-2)
+    # second step sees the updated weights: loose bound (Adam's first steps are sign-like, noise amplifies)
+    assert abs(float(l2) - olosses[1]) <= 5e-2 * max(abs(olosses[1]), 1e-1)
+    assert ts.scale.item() == 1024.0 and ts.found_inf.item() == 0
+    now = model.state_dict()
+    for k, v in osd.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(now[k]) == int(v) == 4
+
+
+def test_fused_single_step_weights_fp32(hip_lib):
+    from msf_wsi_amd.train import PretrainStep
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden("r18_b8_s64")
+    B, size = man["B"], man["size"]
+    spread = dict(zip(man["param_keys"], vec["spread_grad"]))
+    model = build_product("resnet18")
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
+    _, osd = _oracle(sd0, batch, B, steps=1)
+    model = model.cuda().train()
+    ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False)
+    ts.step(_gpu_batch(batch))
+    torch.cuda.synchronize()
+    bad = []
+    for n, p in model.named_parameters():
+        ref_delta = osd[n].double() - sd0[n].double()
+        if ref_delta.norm() == 0:
+            continue
+        delta = p.detach().cpu().double() - sd0[n].double()
+        r = float((delta - ref_delta).norm() / ref_delta.norm())
+        lim = max(2e-3, 4.0 * float(spread.get(n, 0.0)))
+        if r > lim:
+            bad.append((n, r, lim))
+    assert not bad, bad[:10]
+    for k, v in osd.items():
+        if k.endswith("running_var"):
+            assert rel(model.state_dict()[k], v) < 1e-4, k
+
+
+def test_fused_step_bf16_tracks_fp32(hip_lib):
+    """bf16 storage / bf16 MFMA: loss-level agreement only (as for the reference under autocast)"""
+    from msf_wsi_amd.train import PretrainStep
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden("r18_b8_s64")
+    B, size = man["B"], man["size"]
+    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
+    model = build_product("resnet18").cuda().train()
+    ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.bfloat16)
+    losses = [float(ts.step(_gpu_batch(batch))) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses))
+    assert abs(losses[0] - float(vec["loss"][0])) < 3e-2
+    assert ts.found_inf.item() == 0 and ts.scale.item() == 65536.0
+    # the bf16 compute copies follow the fp32 master weights
+    for gi in range(3):
+        assert torch.equal(ts.flats.w16[gi].float(), ts.flats.w[gi].bfloat16().float())
+
+
+def test_checkpoint_layout_and_resume(hip_lib):
+    from msf_wsi_amd.train import PretrainStep
+    from oracle import msfwsi_oracle as orc
+
+    batch = _gpu_batch(orc.synthetic_batch(2, 64, 16, 3))
+    model = build_product("resnet18").cuda().train()
+    ts = PretrainStep(model, lr=LR, global_batch=2, dtype=torch.float32, use_scaler=True)
+    ts.step(batch)
+    ck = ts.checkpoint(epoch=4)
+    assert set(ck) == {"epoch", "arch", "state_dict", "optimizer", "scaler"} and ck["epoch"] == 5
+    assert all(k.startswith("module.") for k in ck["state_dict"]) and len(ck["state_dict"]) == 528
+    assert len(ck["optimizer"]["param_groups"]) == 3
+    assert [len(g["params"]) for g in ck["optimizer"]["param_groups"]] == [108, 108, 48]
+    assert set(ck["scaler"]) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    # a stock torch Adam / GradScaler accept these dicts (what the reference's --resume does)
+    named = list(model.named_parameters())
+    groups = [[p for n, p in named if n.startswith(pre)] for pre in ("context_", "target_", "inter_")]
+    topt = torch.optim.Adam([{"params": g} for g in groups], lr=1e-3)
+    topt.load_state_dict(ck["optimizer"])
+    torch.amp.GradScaler("cuda").load_state_dict(ck["scaler"])
+    buf = io.BytesIO()
+    torch.save(ck, buf)
+    buf.seek(0)
+    ck2 = torch.load(buf, map_location="cuda", weights_only=False)
+    model2 = build_product("resnet18").cuda().train()
+    ts2 = PretrainStep(model2, lr=LR, global_batch=2, dtype=torch.float32, use_scaler=True)
+    assert ts2.resume(ck2) == 5
+    assert ts2.eps == [0.1, 0.1, 0.1] and ts2.t == 1
+    for (n, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), n
+    assert torch.equal(ts2.flats.m[2], ts.flats.m[2])
+    # the fine-tune script's consumption of the encoder keys (ssl_finetune.py:153-170): torchvision names
+    enc = {k[len("module.context_encoder."):]: v for k, v in ck["state_dict"].items()
+           if k.startswith("module.context_encoder.") and ".fc" not in k}
+    assert "layer2.0.downsample.1.running_var" in enc and "conv1.weight" in enc and len(enc) == 120
