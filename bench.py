@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Headline benchmark: tile-pairs/s through one MSF-WSI pre-train step on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Workload = BASELINE.json configs[1]: ResNet-50 dual-stream, bf16, 256 synthetic tile pairs per GPU
+(1 tile pair = 1 context + 16 target tiles x 2 views = 34 image passes of 224x224x3), weak scaling.
+A "step" = forward + 12-term cosine loss + backward + gradient averaging + Adam, inputs resident in HBM.
+Besides the contract line it reports
+  roofline     : the dominant dense kernel family, timed live with HIP events on the launch stream
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference step) on a bounded sample, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_PAIR = {"resnet18": 363.37e9, "resnet50": 848.8e9}  # SURVEY.md 8(d), fwd+bwd per tile pair
+
+
+def hub_stub():
+    """random-init 'pretrained' weights: the GPU box has no network (data/weights are synthetic)"""
+    from msf_wsi_amd.models import resnet as R
+
+    def fake(url, progress=True, **kw):
+        arch = [k for k, v in R.model_urls.items() if v == url][0]
+        return R.__dict__[arch](pretrained=False).state_dict()
+
+    torch.hub.load_state_dict_from_url = fake
+
+
+def build(arch, device):
+    from msf_wsi_amd.models import resnet as R
+    from msf_wsi_amd.models.backbone import MSFWSI
+
+    hub_stub()
+    torch.manual_seed(3407)
+    with torch.device(device):
+        model = MSFWSI(R.__dict__[arch], 4)
+    return model.train()
+
+
+def cpu_baseline(arch, size, budget_s, threads):
+    """the oracle's train_step on B=2 tile pairs of the same architecture, timed on the host cores"""
+    from oracle import msfwsi_oracle as orc
+
+    torch.set_num_threads(threads)
+    hub_stub()
+    torch.manual_seed(3407)
+    from msf_wsi_amd.models import resnet as R
+    from msf_wsi_amd.models.backbone import MSFWSI
+
+    model = MSFWSI(R.__dict__[arch], 4)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    B = 2
+    batch = orc.synthetic_batch(B, size, 16, 0)
+    lr = orc.init_lr(1e-3, B)
+    opt = orc.Adam(sd, [lr, lr, lr])
+    orc.train_step(sd, batch, opt)  # warm-up (allocator, oneDNN primitive caches)
+    n, t0 = 0, time.time()
+    while True:
+        orc.train_step(sd, batch, opt)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 5:
+            break
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 4), "unit": "tile-pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n} step(s) of the oracle (port of the reference step) on {B} tile pairs, {arch}, fp32, "
+                      f"{size}x{size}, after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--batch", type=int, default=256, help="tile pairs per GPU")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the MSF-WSI hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from msf_wsi_amd import _lib, kernels as kn
+    from msf_wsi_amd.train import PretrainStep, synthetic_batch
+
+    _lib.load()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dev = torch.device("cuda", local)
+    model = build(args.arch, dev)
+    ts = PretrainStep(model, lr=1e-3, global_batch=args.batch * world, dtype=dtype, arch=args.arch)
+    ts.engine.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")
+    batch = synthetic_batch(args.batch, args.size, 16, seed=rank, device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(batch)
+    timer = None if args.no_kernel_timer else kn.KernelTimer()
+    sync()
+    kn.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ts.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    kn.TIMER = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        out = {
+            "metric": "tile-pairs/sec per pretrain step", "value": round(pairs / dt, 3), "unit": "tile-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.arch} dual-stream MSF-WSI pre-train step, {args.batch} tile pairs/GPU "
+                                   f"(34 image passes of {args.size}x{args.size}x3 each), {args.dtype}, "
+                                   f"Adam + GradScaler, SyncBN+DP over {world} GPU(s)",
+                       "arch": args.arch, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "image_size": args.size, "parallelism": f"dp{world}",
+                       "images_per_s": round(34 * pairs / dt, 1), "loss": float(loss),
+                       "peak_mem_GiB": round(peak_mem, 1),
+                       "step_TFLOPs_algorithmic": round(FLOP_PER_PAIR.get(args.arch, 0) * pairs / dt / 1e12, 1)},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom = max(summ, key=lambda k: summ[k]["seconds"])
+            s = summ[dom]
+            tf = s["flops"] / s["seconds"] / 1e12
+            gbs = s["bytes"] / s["seconds"] / 1e9
+            frac_m, frac_h = tf / PEAK_TFLOPS[args.dtype], gbs / PEAK_HBM_GBS
+            bound = "mfma" if frac_m >= frac_h else "hbm"
+            out["roofline"] = {
+                "kernel": dom, "bound": bound,
+                "achieved": round(tf if bound == "mfma" else gbs, 2),
+                "peak": PEAK_TFLOPS[args.dtype] if bound == "mfma" else PEAK_HBM_GBS,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": round(max(frac_m, frac_h), 4), "traffic": None,
+                "launches": s["launches"], "avg_launch_ms": round(1e3 * s["seconds"] / s["launches"], 4),
+                "alt": {"TFLOP/s": round(tf, 2), "frac_mfma": round(frac_m, 4), "GB/s": round(gbs, 1),
+                        "frac_hbm": round(frac_h, 4)},
+                "families": {k: {"launches": v["launches"], "ms": round(1e3 * v["seconds"], 2),
+                                 "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 2),
+                                 "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in summ.items()},
+                "timed_fraction_of_step": round(sum(v["seconds"] for v in summ.values()) / dt, 3),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            del ts, model, batch
+            torch.cuda.empty_cache()
+            threads = max(1, (os.cpu_count() or 2) // 2)
+            try:
+                threads = min(threads, len(os.sched_getaffinity(0)))
+            except AttributeError:
+                pass
+            out["cpu_baseline"] = cpu_baseline(args.arch, args.size, args.cpu_budget, threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

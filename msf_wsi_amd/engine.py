@@ -75,6 +75,8 @@ class EncPass:
     amax: torch.Tensor
     blocks: List[BlockRec]
     feats: List[torch.Tensor]
+    x_src: Optional[torch.Tensor] = None  # original NCHW input, kept when the pass must be recomputed
+    saved: bool = True
 
 
 @dataclass
@@ -90,6 +92,7 @@ class StepRec:
     idx: List[torch.Tensor] = field(default_factory=list)
     heads: Dict[Tuple[str, int, int], Tuple[ChainRec, ChainRec]] = field(default_factory=dict)
     tgt_sorted: Dict[Tuple[int, int], torch.Tensor] = field(default_factory=dict)
+    nosave: set = field(default_factory=set)
 
 
 def chan_pad(dtype: torch.dtype) -> int:
@@ -179,6 +182,7 @@ class Engine:
         self.group = process_group
         self._sync_bn = sync_bn
         self.update_running = True
+        self.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")  # off | t1 | targets | auto
 
     # ---- configuration ---------------------------------------------------------------------
     @staticmethod
@@ -297,7 +301,9 @@ class Engine:
         return dx
 
     # ---- encoder -------------------------------------------------------------------------------
-    def encoder_forward(self, enc: nn.Module, x: torch.Tensor, dtype: torch.dtype) -> EncPass:
+    def encoder_forward(self, enc: nn.Module, x: torch.Tensor, dtype: torch.dtype, save: bool = True) -> EncPass:
+        """save=False: features only; activations are dropped block by block and the pass is recomputed
+        right before its backward (pass-level recompute, the engine's answer to the reference's --use-ac)."""
         if not x.is_cuda:
             raise _lib.MsfwsiHipError("the MSF-WSI encoders run only on a HIP device (no CPU path)")
         if x.dim() != 4 or x.shape[1] != 3:
@@ -339,12 +345,48 @@ class Engine:
                               id_shift=ds.st.shift, relu=True)
                 else:
                     kn.bn_act(last.c, last.st.scale, last.st.shift, y_out, ident=y, relu=True)
-                blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1))
+                if save:
+                    blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1))
                 y, h, w = y_out, gh, gw
             f = torch.empty(N, y.shape[-1], dtype=dtype, device=x.device)
             kn.gap_fwd(y, f, N, h * w, y.shape[-1])
             feats.append(f)
+        if not save:
+            return EncPass(enc, N, H, W, None, None, None, None, [], feats, x_src=x, saved=False)
         return EncPass(enc, N, H, W, xin, stem, pooled, amax, blocks, feats)
+
+    def _materialise(self, ps: EncPass, dtype: torch.dtype) -> EncPass:
+        """re-run a features-only pass with activations kept; BatchNorm running statistics are not
+        touched a second time"""
+        if ps.saved:
+            return ps
+        keep = self.update_running
+        self.update_running = False
+        try:
+            full = self.encoder_forward(ps.enc, ps.x_src, dtype, save=True)
+        finally:
+            self.update_running = keep
+        return full
+
+    def _plan_recompute(self, per_image_bytes: float, B: int, K: int, device) -> set:
+        """which encoder passes run features-only in forward (engine.recompute = off | t1 | targets | auto)"""
+        mode = getattr(self, "recompute", "off")
+        if mode == "off":
+            return set()
+        if mode == "t1":
+            return {"t1"}
+        if mode == "targets":
+            return {"t0", "t1"}
+        free, _ = torch.cuda.mem_get_info(device)
+        avail = free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        budget = 0.80 * avail
+        # backward transients (gradient tensors of the two largest activations) ~ 10 % of one target pass
+        one_target = per_image_bytes * B * K * 1.10
+        if per_image_bytes * B + 2 * one_target < budget:
+            return set()
+        if per_image_bytes * B + one_target < budget:
+            return {"t1"}
+        return {"t0", "t1"}
 
     def encoder_backward(self, ps: EncPass, dfeats: Sequence[Optional[torch.Tensor]], grads: GradStore,
                          dtype: torch.dtype):
@@ -458,7 +500,8 @@ class Engine:
         return cur.view(cur.shape[0], -1) if need_dx else None
 
     # ---- whole model -----------------------------------------------------------------------------
-    def model_forward(self, model: nn.Module, x1, x2, jigsaw_idx, dtype) -> Tuple[tuple, StepRec]:
+    def model_forward(self, model: nn.Module, x1, x2, jigsaw_idx, dtype,
+                      need_backward: bool = True) -> Tuple[tuple, StepRec]:
         B = x1[0].shape[0]
         K, n_keep = model.K, model.n_keep
         if x1[1].shape[0] != B * K or x2[1].shape[0] != B * K or x2[0].shape[0] != B:
@@ -472,10 +515,17 @@ class Engine:
             assert tuple(idx.shape) == (B, K), f"jigsaw_idx[{v}] must be [B,K]"
             rec.idx.append(idx.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous())
         # reference call order (backbone.py:140-145): separate BatchNorm batches per call
+        m0 = torch.cuda.memory_allocated(dev)
         rec.enc["c0"] = self.encoder_forward(model.context_encoder, x1[0], dtype)
-        rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype)
-        rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype)
-        rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype)
+        per_image = (torch.cuda.memory_allocated(dev) - m0) / max(1, B)
+        nosave = self._plan_recompute(per_image, B, K, dev) if need_backward else {"c1", "t0", "t1"}
+        if not need_backward:
+            rec.enc["c0"] = EncPass(model.context_encoder, B, 0, 0, None, None, None, None, [], rec.enc["c0"].feats,
+                                    saved=False)
+        rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
+        rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
+        rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype, save="t1" not in nosave)
+        rec.nosave = nosave
         outs = {}
         for grp in ("context", "target", "inter"):
             proj = getattr(model, f"{grp}_projector")
@@ -532,12 +582,14 @@ class Engine:
                         kn.copy2d(df, Cs, D, dtf[v][s], 0, K * Cs, B, n_keep * Cs, accumulate=True)
             if grp == "inter" and on_group_done is not None:
                 on_group_done("inter")
-        for name, df in (("t1", dtf[1]), ("t0", dtf[0])):
-            self.encoder_backward(rec.enc.pop(name), df, grads, dtype)
+        # saved passes first (frees their activations), then the features-only ones are re-materialised
+        order = sorted((("t0", dtf[0]), ("t1", dtf[1])), key=lambda nd: not rec.enc[nd[0]].saved)
+        for name, df in order:
+            self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
         if on_group_done is not None:
             on_group_done("target")
         for name, df in (("c1", dcf[1]), ("c0", dcf[0])):
-            self.encoder_backward(rec.enc.pop(name), df, grads, dtype)
+            self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
         if on_group_done is not None:
             on_group_done("context")
 
@@ -603,7 +655,7 @@ def msfwsi_apply(model: nn.Module, x1, x2, jigsaw_idx):
     params = [p for p in model.parameters()]
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     if not need_grad:
-        outs, _ = eng.model_forward(model, x1, x2, jigsaw_idx, dtype)
+        outs, _ = eng.model_forward(model, x1, x2, jigsaw_idx, dtype, need_backward=False)
         return outs
     if jigsaw_idx is None or len(jigsaw_idx) != 2:
         raise ValueError("jigsaw_idx must be the two [B,K] index tensors")

@@ -67,6 +67,44 @@ def new_stats(C_: int, slots: int = 2, device=None) -> torch.Tensor:
     return torch.zeros(NSHARD, slots, C_, dtype=torch.float64, device=device or "cuda")
 
 
+class KernelTimer:
+    """Optional per-launch timing of the dense kernels with HIP events recorded on the launch stream
+    (bench.py's roofline leg).  For every launch it keeps the algorithmic FLOPs and the algorithmic HBM
+    bytes (each operand / result tensor counted once) next to the event pair."""
+
+    def __init__(self):
+        self.records = []  # (kind, flops, bytes, ev0, ev1)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, fl, by, e0, e1 in self.records:
+            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += fl
+            a[3] += by
+        return {k: {"launches": v[0], "seconds": v[1], "flops": v[2], "bytes": v[3]} for k, v in agg.items()}
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _timed(kind, d: ConvDesc, esize: int, fn):
+    if TIMER is None:
+        return fn()
+    M = d.N * d.P * d.Q
+    flops = 2.0 * M * d.K * d.R * d.S * d.C
+    nbytes = float(esize) * (d.N * d.H * d.W * d.C + M * d.K) + float(esize if kind != "conv_wgrad" else 4) * (
+        d.K * d.R * d.S * d.C)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    TIMER.records.append((kind, flops, nbytes, e0, e1))
+    return r
+
+
 # ------------------------------------------------------------------------------------------------
 def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
     """y = conv(act(x), w) (+bias); pro = (scale, shift) of the producer BatchNorm; stats [NSHARD,2,K]."""
@@ -87,8 +125,9 @@ def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
         nsh = stats.shape[0]
         if stats.numel() != nsh * 2 * d.K:
             raise ValueError("stats must be [nshard,2,K]")
-    _lib.check(lib.msfwsi_conv_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(ps), _p(psh), _p(bias), _p(stats), nsh,
-                                   _stream()), "conv_fwd")
+    _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
+        lib.msfwsi_conv_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(ps), _p(psh), _p(bias), _p(stats), nsh, _stream()),
+        "conv_fwd"))
     return y
 
 
@@ -100,8 +139,9 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0):
     _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
     _opt(resid, "resid", dt, d.N * d.H * d.W * d.C)
     _opt(gapg, "gapg", dt, d.N * d.C)
-    _lib.check(lib.msfwsi_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(gapg), float(gap_scale),
-                                     _stream()), "conv_dgrad")
+    _timed("conv_dgrad", d, dy.element_size(), lambda: _lib.check(
+        lib.msfwsi_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(gapg), float(gap_scale), _stream()),
+        "conv_dgrad"))
     return dx
 
 
@@ -116,8 +156,9 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=1024):
         ps, psh = pro
         _req(ps, "pro_scale", torch.float32, d.C)
         _req(psh, "pro_shift", torch.float32, d.C)
-    _lib.check(lib.msfwsi_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ps), _p(psh), int(target_blocks),
-                                     _stream()), "conv_wgrad")
+    _timed("conv_wgrad", d, x.element_size(), lambda: _lib.check(
+        lib.msfwsi_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ps), _p(psh), int(target_blocks), _stream()),
+        "conv_wgrad"))
     return dw
 
 

@@ -153,8 +153,9 @@ def loss_terms(outputs, weights: Sequence[float] = FUSER_WEIGHTS) -> Tuple[Tenso
     for grp in outputs:
         row = []
         for i, (p1, p2, z1, z2) in enumerate(zip(*grp)):
-            t = -(F.cosine_similarity(p1.float(), z2.float(), dim=1).mean()
-                  + F.cosine_similarity(p2.float(), z1.float(), dim=1).mean()) * 0.5
+            if p1.dtype in (torch.float16, torch.bfloat16):  # autocast runs cosine_similarity in fp32
+                p1, p2, z1, z2 = p1.float(), p2.float(), z1.float(), z2.float()
+            t = -(F.cosine_similarity(p1, z2, dim=1).mean() + F.cosine_similarity(p2, z1, dim=1).mean()) * 0.5
             row.append(t.detach())
             total = total + t * weights[i]
         terms.append(row)
