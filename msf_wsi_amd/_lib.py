@@ -84,6 +84,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; it must be the first HIP runtime mapped into the process, otherwise
+    # this library binds to /opt/rocm's copy and the two runtimes disagree about devices (hipErrorNoDevice)
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise MsfwsiHipError(
             f"{LIB_PATH} not found: build it with `make -C {CSRC_DIR}` (or __graft_entry__.build()). "

@@ -1,0 +1,116 @@
+"""CPU: the drop-in boundary (module tree, state-dict contract, C-ABI symbols).  No compute calls: the product
+has no CPU path, and these tests assert that too."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import build_product, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol(hip_lib):
+    """every function declared in include/msfwsi_hip.h is exported by the built library and bound in _lib.py"""
+    from msf_wsi_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "msfwsi_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(msfwsi_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 25
+    assert declared - {"msfwsi_target"} == set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.msfwsi_target().decode() == "gfx950"
+
+
+def test_no_product_import_of_oracle():
+    """the product must never route through the checker"""
+    pkg = os.path.join(ROOT, "msf_wsi_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dp, f)
+
+
+def test_model_api_matches_reference_contract():
+    from msf_wsi_amd.models import resnet
+    from msf_wsi_amd.models.backbone import MSFWSI, make_predictor, make_projector
+
+    sig = inspect.signature(MSFWSI.__init__)
+    assert list(sig.parameters) == ["self", "base_encoder", "scale", "dim", "pred_dim", "mask_ratio", "use_checkpoint"]
+    assert sig.parameters["dim"].default == 2048 and sig.parameters["pred_dim"].default == 512
+    assert list(inspect.signature(MSFWSI.forward).parameters) == ["self", "x1", "x2", "jigsaw_idx"]
+    for arch in ("resnet18", "resnet34", "resnet50", "resnet101", "resnet152"):
+        assert callable(resnet.__dict__[arch])
+    m = build_product("resnet18")
+    assert m.K == 16 and m.n_keep == 8
+    assert m.inter_dim.tolist() == [64, 128, 256, 512] and m.ms_inter_dim.tolist() == [576, 1152, 2304, 4608]
+    assert isinstance(m.context_encoder.fc, nn.Identity)
+    assert [type(x).__name__ for x in make_projector(64, 64)] == ["Linear", "BatchNorm1d", "ReLU", "Linear",
+                                                                 "BatchNorm1d", "ReLU", "Linear", "BatchNorm1d"]
+    pj = make_projector(64, 64)
+    assert pj[7].affine is False and pj[0].bias is None
+    pd = make_predictor(64, 16)
+    assert pd[0].bias is None and pd[3].bias is not None and pd[3].out_features == 64
+    # state-dict contract
+    vec, man = load_golden("r18_b8_s64")
+    sd = m.state_dict()
+    assert len(sd) == 528 and [k for k in sd] == [k for k, _, _ in man["keys"]]
+    assert "context_encoder.layer2.0.downsample.1.running_var" in sd and "inter_projector.3.6.weight" in sd
+    assert "target_predictor.0.3.bias" in sd and sd["context_encoder.bn1.num_batches_tracked"].dtype == torch.int64
+    assert sum(p.numel() for p in m.parameters()) == 123551584
+    named = [n for n, _ in m.named_parameters()]
+    assert [sum(n.startswith(p) for n in named) for p in ("context_", "target_", "inter_")] == [108, 108, 48]
+    # conv weights sit in the kernels' [K][R][S][C] order without changing logical shape / values
+    w = m.target_encoder.layer1[0].conv1.weight
+    assert tuple(w.shape) == (64, 64, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_survives_reference_wrappers():
+    """SyncBatchNorm conversion (ssl_train.py:160) keeps keys; repr works (ssl_train.py:172)"""
+    m = build_product("resnet18")
+    keys = list(m.state_dict())
+    m2 = nn.SyncBatchNorm.convert_sync_batchnorm(m)
+    assert list(m2.state_dict()) == keys
+    assert sum(isinstance(x, nn.SyncBatchNorm) for x in m2.modules()) == 88
+    assert "MSFWSI" in repr(m2)
+
+
+def test_resnet50_generalisation_builds():
+    from msf_wsi_amd.models import resnet
+
+    enc = resnet.resnet50(zero_init_residual=True, return_features=True)
+    assert enc.fc.in_features == 2048
+    keys = list(enc.state_dict())
+    assert "layer1.0.conv3.weight" in keys and "layer1.0.downsample.0.weight" in keys and len(keys) == 320
+    assert float(enc.layer1[0].bn3.weight.abs().sum()) == 0.0  # zero_init_residual
+    assert float(enc.layer1[0].bn2.weight.sum()) == 64.0
+
+
+def test_unsupported_variants_and_cpu_raise():
+    from msf_wsi_amd._lib import MsfwsiHipError
+    from msf_wsi_amd.models import resnet
+
+    with pytest.raises(NotImplementedError):
+        resnet.ResNet(resnet.Bottleneck, [1, 1, 1, 1], groups=32, width_per_group=4)
+    m = build_product("resnet18")
+    x = torch.zeros(2, 3, 64, 64)
+    t = torch.zeros(32, 3, 64, 64)
+    idx = [torch.arange(16).repeat(2, 1)] * 2
+    with pytest.raises(MsfwsiHipError):
+        m((x, t), (x, t), idx)
+
+
+def test_pretrained_offline_dir(tmp_path, monkeypatch):
+    from msf_wsi_amd.models import resnet
+
+    ref = resnet.resnet18()
+    torch.save(ref.state_dict(), tmp_path / "resnet18-f37072fd.pth")
+    monkeypatch.setenv("MSFWSI_PRETRAINED_DIR", str(tmp_path))
+    got = resnet.resnet18(pretrained=True)
+    for (k, a), (_, b) in zip(ref.state_dict().items(), got.state_dict().items()):
+        assert torch.equal(a, b), k

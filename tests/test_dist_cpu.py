@@ -1,0 +1,163 @@
+"""CPU / gloo: the data-parallel host logic (msf_wsi_amd/dist.py) with world_size 2.
+
+The arithmetic on each rank is done by the oracle (no GPU here); what is under test is the product's
+protocol: whole-sample sharding, the packed [sum, sumsq] SUM all-reduce for cross-replica BatchNorm
+(forward) and [sum g, sum g*x] (backward) with the same dx = k1*g + k2*x + k3 coefficients the HIP kernel
+`bn_bwd_finalize` uses, flat per-group gradient buffers and their averaging.  Claim verified: an N-rank step
+equals the single-process step on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import build_product
+
+SIZE, B_GLOBAL, K = 32, 4, 16
+
+
+class _SyncBN(torch.autograd.Function):
+    """train-mode BatchNorm over all ranks, restating the engine's kernels (bn_finalize / bn_bwd_finalize)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        from msf_wsi_amd.dist import sync_sums, world_size
+
+        C = x.shape[1]
+        xs = x.transpose(0, 1).reshape(C, -1)
+        packed = torch.cat([xs.sum(1), (xs * xs).sum(1)]).double()
+        sync_sums(packed)
+        total = xs.shape[1] * world_size()
+        mean = packed[:C] / total
+        var = (packed[C:] / total - mean * mean).clamp_min(0)
+        invstd = 1.0 / torch.sqrt(var + eps)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        g = w if w is not None else torch.ones(C, dtype=x.dtype)
+        bb = b if b is not None else torch.zeros(C, dtype=x.dtype)
+        scale = g * invstd
+        ctx.save_for_backward(x, mean, invstd, g)
+        ctx.total, ctx.affine = total, w is not None
+        return x * scale.view(shape) + (bb - mean * scale).view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from msf_wsi_amd.dist import sync_sums
+
+        x, mean, invstd, g = ctx.saved_tensors
+        C = x.shape[1]
+        shape = [1, C] + [1] * (x.dim() - 2)
+        dys = dy.transpose(0, 1).reshape(C, -1)
+        xs = x.transpose(0, 1).reshape(C, -1)
+        local = torch.cat([dys.sum(1), (dys * xs).sum(1)]).double()
+        dgamma = invstd * (local[C:] - mean * local[:C])  # LOCAL sums: DDP averages parameter grads later
+        dbeta = local[:C].clone()
+        glob = sync_sums(local.clone())
+        dot = invstd * (glob[C:] - mean * glob[:C])
+        a = g * invstd
+        m1, m2 = glob[:C] / ctx.total, dot / ctx.total
+        k1, k2, k3 = a, -a * m2 * invstd, -a * m1 + a * m2 * invstd * mean
+        dx = k1.view(shape) * dy + k2.view(shape) * x + k3.view(shape)
+        return dx, (dgamma if ctx.affine else None), (dbeta if ctx.affine else None), None
+
+
+def _grads(sd, batch, sync):
+    from oracle import msfwsi_oracle as orc
+
+    keep = orc._bn
+    if sync:
+        orc._bn = lambda s, key, x, train=True: _SyncBN.apply(x, s.get(key + ".weight"), s.get(key + ".bias"),
+                                                              orc.BN_EPS)
+    try:
+        opt = orc.Adam(sd, [0.0, 0.0, 0.0])
+        opt.step = lambda *a, **k: None
+        loss, terms, outs, grads = orc.train_step(sd, batch, opt)
+    finally:
+        orc._bn = keep
+    return loss, grads
+
+
+def _worker(rank, world, port, ret):
+    from msf_wsi_amd.dist import FlatGroups, GradReducer, shard_range
+    from oracle import msfwsi_oracle as orc
+
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        model = build_product("resnet18").double()
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        (c1, c2), (t1, t2), idx = orc.synthetic_batch(B_GLOBAL, SIZE, K, 0, torch.float64)
+        lo, hi = shard_range(B_GLOBAL, world, rank)
+        local = ((c1[lo:hi], c2[lo:hi]), (t1[lo * K:hi * K], t2[lo * K:hi * K]), [idx[0][lo:hi], idx[1][lo:hi]])
+        loss, grads = _grads({k: v.clone() for k, v in sd.items()}, local, sync=True)
+        # product plumbing: flat per-group gradient buffers + per-group averaging
+        for p in model.parameters():
+            p.data = p.data.float()
+        flats = FlatGroups(model, with_bf16=False, device="cpu")
+        for n, p in model.named_parameters():
+            gv = flats.grad_view(p)
+            gsrc = grads[n].float()
+            gv.copy_(gsrc.permute(0, 2, 3, 1) if gsrc.dim() == 4 else gsrc)
+        red = GradReducer(flats)
+        for name in ("inter", "target", "context"):  # the order the backward schedule releases them
+            red.launch(name)
+        red.wait()
+        lsum = torch.tensor([float(loss)], dtype=torch.float64)
+        dist.all_reduce(lsum)
+        if rank == 0:
+            full_loss, full = _grads({k: v.clone() for k, v in sd.items()},
+                                     ((c1, c2), (t1, t2), idx), sync=False)
+            worst = 0.0
+            for n, p in model.named_parameters():
+                gv = flats.grad_view(p)
+                got = gv.permute(0, 3, 1, 2) if p.dim() == 4 else gv
+                ref = full[n].float()
+                worst = max(worst, float((got - ref).norm() / (ref.norm() + 1e-30)))
+            ret["worst"] = worst
+            ret["loss"] = (float(lsum) / world, float(full_loss))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_ranks_equal_full_batch():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert abs(ret["loss"][0] - ret["loss"][1]) < 1e-9, ret["loss"]
+    assert ret["worst"] < 1e-5, ret["worst"]  # grads travelled as fp32 through the flat buffers
+
+
+def test_shard_range_and_layout():
+    from msf_wsi_amd.dist import ALIGN, FlatGroups, shard_range
+
+    assert shard_range(2048, 8, 3) == (768, 1024)
+    with pytest.raises(ValueError):
+        shard_range(10, 4, 0)
+    model = build_product("resnet18")
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    flats = FlatGroups(model, with_bf16=True, device="cpu")
+    assert [len(g) for g in flats.params] == [108, 108, 48]
+    for gi in range(3):
+        assert all(o % ALIGN == 0 for o in flats.offsets[gi]) and flats.sizes[gi] % ALIGN == 0
+        assert flats.w16[gi].dtype == torch.bfloat16 and flats.w16[gi].numel() == flats.sizes[gi]
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n  # values and logical shapes unchanged
+        gi = [i for i, names in enumerate(flats.names) if n in names][0]
+        lo = flats.w[gi].data_ptr()
+        assert lo <= p.data_ptr() < lo + flats.w[gi].numel() * 4  # the parameter IS a view of the flat buffer
+        if p.dim() == 4:
+            assert p.permute(0, 2, 3, 1).is_contiguous()
+        assert flats.grad_view(p).numel() == p.numel() and flats.grad_view(p).data_ptr() % 16 == 0
+    # load_state_dict writes through the views
+    sd = {k: torch.zeros_like(v) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    assert all(float(w.abs().sum()) == 0 for w in flats.w)

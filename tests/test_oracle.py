@@ -1,0 +1,88 @@
+"""CPU: the oracle (oracle/msfwsi_oracle.py) against the golden vectors generated from the REAL reference
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU parity tests then compare the product
+with the oracle.  Runs without a GPU and without /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import LR, WEIGHTS, build_product, load_golden, rel
+
+
+@pytest.fixture(scope="module")
+def case():
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden("r18_b8_s64")
+    model = build_product(man["arch"])
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    B = man["B"]
+    batch = orc.synthetic_batch(B, man["size"], 16, man["data_seed"])
+    osd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    (c1, c2), (t1, t2), idx = batch
+    b64 = ((c1.double(), c2.double()), (t1.double(), t2.double()), idx)
+    lr = orc.init_lr(LR, B)
+    loss, terms, outs, grads = orc.train_step(osd, b64, orc.Adam(osd, [lr, lr, lr]), 4, 0.5, WEIGHTS)
+    return vec, man, sd0, osd, loss, terms, outs, grads
+
+
+def test_seeded_init_matches_reference(case):
+    vec, man, sd0 = case[0], case[1], case[2]
+    assert [k for k in sd0] == [k for k, _, _ in man["keys"]]
+    for (k, shape, dt), v in zip(man["keys"], sd0.values()):
+        assert list(v.shape) == shape and str(v.dtype) == dt, k
+    assert np.allclose([float(v.double().sum()) for v in sd0.values()], vec["init_sum"], rtol=1e-12, atol=1e-12)
+    assert np.allclose([float(v.double().abs().sum()) for v in sd0.values()], vec["init_abs"], rtol=1e-12, atol=1e-12)
+
+
+def test_oracle_loss_and_outputs_match_reference(case):
+    vec, man, _, _, loss, terms, outs, _ = case
+    flat = torch.stack([t for row in terms for t in row])
+    assert torch.allclose(flat, torch.as_tensor(vec["terms"]), rtol=0, atol=1e-9)
+    assert abs(float(loss) - float(vec["loss"][0])) < 1e-9
+    names = ["p1", "p2", "z1", "z2"]
+    for gi, g in enumerate(("context", "target", "fuser")):
+        for ti in range(4):
+            for s in range(4):
+                t = outs[gi][ti][s]
+                rows = t if g != "target" else t[:: max(1, t.shape[0] // 8)][:8]
+                assert rel(rows, vec[f"out/{g}/{names[ti]}/{s}"]) < 1e-6
+                assert t.requires_grad == (ti < 2)
+
+
+def test_oracle_gradients_match_reference(case):
+    vec, man, _, _, _, _, _, grads = case
+    norms = np.array([float(grads[k].double().norm()) for k in man["param_keys"]])
+    sums = np.array([float(grads[k].double().sum()) for k in man["param_keys"]])
+    assert np.allclose(norms, vec["grad_norm"], rtol=1e-7, atol=1e-12)
+    assert np.allclose(sums, vec["grad_sum"], rtol=1e-6, atol=1e-9)
+    for k in ("context_encoder.bn1.weight", "context_encoder.bn1.bias"):
+        assert rel(grads[k], vec["grad/" + k]) < 1e-5  # stored as fp32
+
+
+def test_oracle_adam_and_running_stats_match_reference(case):
+    vec, man, sd0, osd = case[0], case[1], case[2], case[3]
+    step = np.array([float((osd[k].double() - sd0[k].double()).norm()) for k in man["param_keys"]])
+    assert np.allclose(step, vec["step_norm"], rtol=1e-6, atol=1e-12)
+    assert np.allclose([float(osd[k].double().sum()) for k in man["param_keys"]], vec["w1_sum"], rtol=1e-9, atol=1e-9)
+    for key in ("context_encoder.bn1", "target_encoder.layer2.0.downsample.1", "target_encoder.layer4.1.bn2",
+                "inter_projector.0.1", "context_predictor.3.1"):
+        for stat in ("running_mean", "running_var"):  # means of already-normalised inputs are ~1e-17: abs tol
+            assert np.allclose(osd[f"{key}.{stat}"].numpy(), vec[f"bn/{key}/{stat}"], rtol=1e-6, atol=1e-7)
+        assert int(osd[key + ".num_batches_tracked"]) == int(vec[f"bn/{key}/nbt"][0]) == 2
+
+
+def test_oracle_fp32_golden_c1_config():
+    """config 1 of BASELINE.json (ResNet-18, B=8, 224x224, fp32): loss of the real reference, fp32"""
+    vec, man = load_golden("r18_b8_s224")
+    assert man["B"] == 8 and man["size"] == 224 and abs(float(vec["loss"][0]) - 0.036828268) < 1e-6
+
+
+def test_param_groups_and_lr():
+    from oracle import msfwsi_oracle as orc
+
+    model = build_product("resnet18")
+    sd = model.state_dict()
+    groups = orc.param_groups(sd)
+    assert [len(g) for g in groups] == [108, 108, 48]
+    assert sum(sd[k].numel() for g in groups for k in g) == 123551584
+    assert abs(orc.init_lr(1e-3, 8) - 1e-3 * 8 ** 0.5 / 32 ** 0.5) < 1e-15
