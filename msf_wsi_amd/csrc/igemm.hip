@@ -12,15 +12,25 @@
 //         (the forward weight tensor read as a [k][n] operand -> no transposed weight copy).
 //
 // Activations are NHWC, weights are [Cout][R][S][Cin] (torch channels_last physical layout).
-// Tile: BM x BN outputs per 256-thread workgroup (4 waves), 64-byte k-slab per stage (32 bf16 /
-// 16 fp32), double-buffered LDS, register-staged global loads, MFMA 32x32 (bf16: 32x32x16,
-// fp32: 32x32x2 exact-fp32).  The weight tile is the MFMA A operand and the activation tile the
-// B operand, so a lane's 16 accumulator registers hold 4x4 consecutive output channels of ONE
-// pixel; the tile is then transposed through LDS and leaves as 16-byte row chunks.
+// Tile: BM x BN outputs per 256-thread workgroup (4 waves), 64-byte k-slab per stage (32 bf16 / 16 fp32),
+// two LDS stages.  Staging:
+//   * operand rows are 64 bytes = four 16-byte chunks, stored UNPADDED with the chunk index XOR-swizzled by
+//     (row>>2)&3, which makes every ds_read_b128 fragment read conflict-free (16-lane groups hit 16 distinct
+//     16-byte slots of the 256-byte bank row);
+//   * tiles that need no arithmetic on the way in (weights; activations without a BatchNorm prologue; dY) go
+//     global -> LDS directly with global_load_lds_dwordx4 (LDS-DMA: no VGPRs, no ds_write); the swizzle sits on
+//     the per-lane SOURCE address, out-of-image taps / out-of-range rows read a 16-byte zero page;
+//   * activations with a BatchNorm+ReLU prologue are register-staged: load, fma+max, ds_write_b128 into the same
+//     image (a lane writes the chunk the DMA would have written, so writes are linear per wave).
+// MFMA 32x32 (bf16: 32x32x16, fp32: 32x32x2 exact-fp32).  The weight tile is the MFMA A operand and the
+// activation tile the B operand, so a lane's 16 accumulator registers hold 4x4 consecutive output channels of
+// ONE pixel; the tile is then transposed through LDS and leaves as 16-byte row chunks.
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
 namespace {
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];  // 256 bytes of zeros (never written)
 
 struct IgemmParams {
     const void* src;
@@ -66,47 +76,56 @@ __device__ __forceinline__ void mma_step<float>(f32x16& acc, const f32x4& w, con
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
 }
 
+// 16 bytes global -> LDS without touching VGPRs; lds_wave_base is wave-uniform, lane l lands at base + 16*l
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
 struct IgemmCfg {
     static constexpr int VEC = ElemTraits<T>::VEC;
-    static constexpr int BK = ElemTraits<T>::BK;
-    static constexpr int CPRK = BK / VEC;  // 16-byte chunks per k-slab row (= 4)
-    static constexpr int LDK = BK + VEC;   // 80-byte rows: conflict-free ds_read_b128
+    static constexpr int BK = ElemTraits<T>::BK;  // 64-byte operand rows
     // natural [k][n] weight tile (DGRAD): row stride == 64 (mod 256) bytes for bf16 tr-reads
     static constexpr int LDN = (sizeof(T) == 2) ? (BN + 32) : (BN + 4);
     static constexpr int TM = BM / WM / 32;
     static constexpr int TN = BN / WN / 32;
-    static constexpr int A_CHUNKS = BM * CPRK / 256;
-    static constexpr int B_CHUNKS = BN * CPRK / 256;
+    static constexpr int A_IT = BM / 64;  // 16-row groups per wave (4 waves x 16 rows x A_IT = BM)
+    static constexpr int B_IT = BN / 64;
+    static constexpr int BNAT_CHUNKS = BN * 4 / 256;  // natural weight tile: 16-byte chunks per thread
     static constexpr int LDC = BN + VEC;
-    static constexpr int A_BYTES = BM * LDK * (int)sizeof(T);
-    static constexpr int B_BYTES = DGRAD ? BK * LDN * (int)sizeof(T) : BN * LDK * (int)sizeof(T);
+    static constexpr int A_BYTES = BM * 64;
+    static constexpr int B_BYTES = DGRAD ? BK * LDN * (int)sizeof(T) : BN * 64;
     static constexpr int AB_BYTES = 2 * (A_BYTES + B_BYTES);
     static constexpr int C_BYTES = BM * LDC * (int)sizeof(T);
     static constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
     static constexpr int RED_BYTES = 4 * BN * 2 * (int)sizeof(float);
     static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small");
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
 };
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
+// swizzled position of logical chunk c (0..3) of operand row `row`
+__device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 2) & 3); }
+
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD> Cfg;
-    constexpr int VEC = Cfg::VEC, BK = Cfg::BK, CPRK = Cfg::CPRK, LDK = Cfg::LDK, LDN = Cfg::LDN;
-    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_CHUNKS = Cfg::A_CHUNKS, B_CHUNKS = Cfg::B_CHUNKS;
+    constexpr int VEC = Cfg::VEC, BK = Cfg::BK, LDN = Cfg::LDN;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
+    constexpr int BNAT = Cfg::BNAT_CHUNKS;
     constexpr int LDC = Cfg::LDC;
     typedef typename Frag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* As = reinterpret_cast<T*>(smem);                        // [2][BM][LDK]
-    T* Bs = reinterpret_cast<T*>(smem + 2 * Cfg::A_BYTES);     // [2][BN][LDK] or [2][BK][LDN]
+    char* As = smem;                                           // [2][BM][64 B]
+    char* Bs = smem + 2 * Cfg::A_BYTES;                        // [2][BN][64 B] or [2][BK][LDN] elements
     T* Cs = reinterpret_cast<T*>(smem);                        // [BM][LDC]   (after the k loop)
     float* red = reinterpret_cast<float*>(smem + Cfg::MAIN_BYTES);  // [4][BN][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -117,19 +136,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
 
     const T* __restrict__ src = reinterpret_cast<const T*>(prm.src);
     const T* __restrict__ wgt = reinterpret_cast<const T*>(prm.wgt);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     const int PQ = prm.P * prm.Q;
     const bool fastk = (prm.C % BK) == 0;  // a k-slab never straddles two filter taps
-    const bool has_pro = prm.pro_scale != nullptr;
 
-    // ---- per-thread row descriptors for the activation chunks (fixed over the k loop) ----
-    int a_hb[A_CHUNKS], a_wb[A_CHUNKS];
-    long a_img[A_CHUNKS];
-    bool a_rowok[A_CHUNKS];
+    // ---- staging map: group g = it*4 + wave covers operand rows 16g .. 16g+15; lane -> (row, slot) ----
+    // lane l of the group owns LDS bytes [16g*64 + 16*l, +16): row = 16g + l/4, slot = l%4, and therefore
+    // fetches the logical chunk kc = slot ^ swizzle(row).
+    int a_hb[A_IT], a_wb[A_IT], a_kc[A_IT];
+    long a_img[A_IT];
+    bool a_rowok[A_IT];
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) {
-        const int c = tid + i * 256;
-        const int row = c / CPRK;
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        a_kc[i] = swz(row, lane & 3);
         const int m = m0 + row;
         a_rowok[i] = m < prm.M;
         const int mm = a_rowok[i] ? m : 0;
@@ -147,26 +168,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
         }
     }
 
-    uint4 a_reg[A_CHUNKS];
-    bool a_ok[A_CHUNKS];
-    float a_sc[A_CHUNKS][VEC], a_sh[A_CHUNKS][VEC];
-    uint4 b_reg[B_CHUNKS];
+    uint4 a_reg[A_IT];
+    bool a_ok[A_IT];
+    float a_sc[APRO ? A_IT : 1][VEC], a_sh[APRO ? A_IT : 1][VEC];
+    uint4 b_reg[DGRAD ? BNAT : 1];
 
     // running tap state for the fast path
     int tap_r = 0, tap_s = 0, tap_c = 0;
 
-    auto load_global = [&](int k0) {
+    // issue the global traffic of one k-slab: DMA straight into stage `buf`, or loads into registers
+    auto fetch = [&](int k0, int buf) {
+        char* Ab = As + buf * Cfg::A_BYTES;
+        char* Bb = Bs + buf * Cfg::B_BYTES;
         // ---------------- activation tile ----------------
 #pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
-            const int c = tid + i * 256;
-            const int kc = c % CPRK;
-            const int kk = k0 + kc * VEC;
+        for (int i = 0; i < A_IT; ++i) {
+            const int kk = k0 + a_kc[i] * VEC;
             int r, s, ch;
             if (fastk) {
                 r = tap_r;
                 s = tap_s;
-                ch = tap_c + kc * VEC;
+                ch = tap_c + a_kc[i] * VEC;
             } else if (prm.R * prm.S == 1) {
                 r = 0;
                 s = 0;
@@ -195,12 +217,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
                 w = a_wb[i] + s;
             }
             ok = ok && (unsigned)h < (unsigned)prm.H && (unsigned)w < (unsigned)prm.W;
-            a_ok[i] = ok;
-            a_reg[i] = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const long off = ((a_img[i] + (long)h * prm.W + w) * prm.C) + ch;
-                a_reg[i] = *reinterpret_cast<const uint4*>(src + off);
-                if (has_pro) {
+            const long off = ok ? ((a_img[i] + (long)h * prm.W + w) * prm.C) + ch : 0;
+            if (APRO) {
+                a_ok[i] = ok;
+                a_reg[i] = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    a_reg[i] = *reinterpret_cast<const uint4*>(src + off);
 #pragma unroll
                     for (int e = 0; e < VEC; e += 4) {
                         const float4 sc = *reinterpret_cast<const float4*>(prm.pro_scale + ch + e);
@@ -209,19 +231,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
                         a_sh[i][e + 0] = sh.x; a_sh[i][e + 1] = sh.y; a_sh[i][e + 2] = sh.z; a_sh[i][e + 3] = sh.w;
                     }
                 }
+            } else {
+                const void* g = ok ? reinterpret_cast<const void*>(src + off) : reinterpret_cast<const void*>(zero);
+                dma16(g, Ab + (i * 4 + wave) * 1024);
             }
         }
         // ---------------- weight tile ----------------
+        if (!DGRAD) {
 #pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) {
-            const int c = tid + i * 256;
-            b_reg[i] = make_uint4(0, 0, 0, 0);
-            if (!DGRAD) {
-                const int nrow = c / CPRK, kc = c % CPRK;
-                const int n = n0 + nrow, kk = k0 + kc * VEC;
-                if (n < prm.Nout && kk < prm.Ktot)
-                    b_reg[i] = *reinterpret_cast<const uint4*>(wgt + (long)n * prm.Ktot + kk);
-            } else {
+            for (int i = 0; i < B_IT; ++i) {
+                const int row = (i * 4 + wave) * 16 + (lane >> 2);
+                const int kc = swz(row, lane & 3);
+                const int n = n0 + row, kk = k0 + kc * VEC;
+                const bool ok = n < prm.Nout && kk < prm.Ktot;
+                const void* g = ok ? reinterpret_cast<const void*>(wgt + (long)n * prm.Ktot + kk)
+                                   : reinterpret_cast<const void*>(zero);
+                dma16(g, Bb + (i * 4 + wave) * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BNAT; ++i) {
+                const int c = tid + i * 256;
                 constexpr int CPN = BN / VEC;
                 const int krow = c / CPN, cn = c % CPN;
                 const int kk = k0 + krow, n = n0 + cn * VEC;
@@ -240,9 +270,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
                     r = rs / prm.S;
                     s = rs - r * prm.S;
                 }
+                b_reg[i] = make_uint4(0, 0, 0, 0);
                 if (kk < prm.Ktot && n < prm.Nout)
-                    b_reg[i] = *reinterpret_cast<const uint4*>(
-                        wgt + (((long)co * prm.R + r) * prm.S + s) * prm.Nout + n);
+                    b_reg[i] = *reinterpret_cast<const uint4*>(wgt + (((long)co * prm.R + r) * prm.S + s) * prm.Nout + n);
             }
         }
         if (fastk) {  // advance the tap for the next slab
@@ -257,30 +287,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
         }
     };
 
-    auto store_lds = [&](int buf) {
-        T* Ab = As + buf * (BM * LDK);
-        T* Bb = Bs + buf * (DGRAD ? BK * LDN : BN * LDK);
+    // write the register-staged part of a slab into stage `buf`
+    auto commit = [&](int buf) {
+        if (APRO) {
+            char* Ab = As + buf * Cfg::A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
-            const int c = tid + i * 256;
-            const int row = c / CPRK, kc = c % CPRK;
-            uint4 v = a_reg[i];
-            if (has_pro && a_ok[i]) {
-                float f[VEC];
-                unpack16<T>(v, f);
+            for (int i = 0; i < A_IT; ++i) {
+                uint4 v = a_reg[i];
+                if (a_ok[i]) {
+                    float f[VEC];
+                    unpack16<T>(v, f);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], a_sc[i][e], a_sh[i][e]), 0.f);
-                v = pack16<T>(f);
+                    for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], a_sc[i][e], a_sh[i][e]), 0.f);
+                    v = pack16<T>(f);
+                }
+                *reinterpret_cast<uint4*>(Ab + (i * 4 + wave) * 1024 + lane * 16) = v;
             }
-            *reinterpret_cast<uint4*>(Ab + row * LDK + kc * VEC) = v;
         }
+        if (DGRAD) {
+            T* Bb = reinterpret_cast<T*>(Bs + buf * Cfg::B_BYTES);
 #pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) {
-            const int c = tid + i * 256;
-            if (!DGRAD) {
-                const int nrow = c / CPRK, kc = c % CPRK;
-                *reinterpret_cast<uint4*>(Bb + nrow * LDK + kc * VEC) = b_reg[i];
-            } else {
+            for (int i = 0; i < BNAT; ++i) {
+                const int c = tid + i * 256;
                 constexpr int CPN = BN / VEC;
                 const int krow = c / CPN, cn = c % CPN;
                 *reinterpret_cast<uint4*>(Bb + krow * LDN + cn * VEC) = b_reg[i];
@@ -297,27 +325,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
             for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
 
     auto compute = [&](int buf) {
-        const T* Ab = As + buf * (BM * LDK);
-        const T* Bb = Bs + buf * (DGRAD ? BK * LDN : BN * LDK);
+        const char* Ab = As + buf * Cfg::A_BYTES;
+        const char* Bb = Bs + buf * Cfg::B_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < BK / (2 * VEC); ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
             frag_t xf[TM], wf[TN];
+            const int cidx = ks * 2 + lh;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int row = (wm * TM + tm) * 32 + l31;
-                xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * LDK + ks * 2 * VEC + lh * VEC);
+                xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * 64 + swz(row, cidx) * 16);
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int ncol = (wn * TN + tn) * 32;
                 if (!DGRAD) {
-                    wf[tn] = *reinterpret_cast<const frag_t*>(Bb + (ncol + l31) * LDK + ks * 2 * VEC + lh * VEC);
+                    const int row = ncol + l31;
+                    wf[tn] = *reinterpret_cast<const frag_t*>(Bb + row * 64 + swz(row, cidx) * 16);
                 } else if constexpr (sizeof(T) == 2) {
                     // transposed LDS read: 16-lane group G -> columns 16*(G&1).., k-half G>>1
+                    const T* Bn = reinterpret_cast<const T*>(Bb);
                     const int li = lane & 15, G = lane >> 4;
                     const int q = li >> 2, p = li & 3;
                     const int kbase = ks * 16 + (G >> 1) * 8 + q;
-                    const T* a0 = Bb + kbase * LDN + ncol + (G & 1) * 16 + p * 4;
+                    const T* a0 = Bn + kbase * LDN + ncol + (G & 1) * 16 + p * 4;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(a0));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -339,16 +370,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
         }
     };
 
-    // ---------------- main loop ----------------
+    // ---------------- main loop (__syncthreads drains the LDS-DMA: it waits vmcnt(0)) ----------------
     const int nk = (prm.Ktot + BK - 1) / BK;
-    load_global(0);
-    store_lds(0);
+    fetch(0, 0);
+    commit(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_global((kt + 1) * BK);
+        if (kt + 1 < nk) fetch((kt + 1) * BK, buf ^ 1);
         compute(buf);
-        if (kt + 1 < nk) store_lds(buf ^ 1);
+        if (kt + 1 < nk) commit(buf ^ 1);
         __syncthreads();
     }
 
@@ -447,7 +478,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
             const int col = i % BN, which = i / BN;
             if (n0 + col < prm.Nout) {
                 float t = 0.f;
-                // a wave covers 64/CPR rows per pass; all 4 waves contribute
 #pragma unroll
                 for (int w = 0; w < 4; ++w) t += red[(w * BN + col) * 2 + which];
                 double* dst = prm.stats + ((long)(tile_m % prm.nshard) * 2 + which) * prm.Nout + n0 + col;
@@ -457,14 +487,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 int launch_igemm(IgemmParams& prm, hipStream_t stream) {
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD> Cfg;
     const int ntm = (prm.M + BM - 1) / BM;
     prm.ntile_n = (prm.Nout + BN - 1) / BN;
     const long nblk = (long)ntm * prm.ntile_n;
     if (nblk <= 0 || nblk > 0x7fffffffL) return MSFWSI_EINVAL;
-    auto kern = igemm_kernel<T, BM, BN, WM, WN, DGRAD>;
+    auto kern = igemm_kernel<T, BM, BN, WM, WN, DGRAD, APRO>;
     if (Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -474,10 +504,10 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
     return msfwsi_launch_status();
 }
 
-template <typename T, bool DGRAD>
+template <typename T, bool DGRAD, bool APRO>
 int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
-    if (prm.Nout <= 64) return launch_igemm<T, 128, 64, 2, 2, DGRAD>(prm, stream);
-    return launch_igemm<T, 128, 128, 2, 2, DGRAD>(prm, stream);
+    if (prm.Nout <= 64) return launch_igemm<T, 128, 64, 2, 2, DGRAD, APRO>(prm, stream);
+    return launch_igemm<T, 128, 128, 2, 2, DGRAD, APRO>(prm, stream);
 }
 
 int check_desc(const msfwsi_conv_desc* d) {
@@ -515,8 +545,10 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
     prm.M = d->N * d->P * d->Q;
     prm.Ktot = d->R * d->S * d->C;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->dtype == MSFWSI_DT_BF16) return dispatch_tile<__bf16, false>(prm, st);
-    return dispatch_tile<float, false>(prm, st);
+    const bool pro = pro_scale != nullptr;
+    if (d->dtype == MSFWSI_DT_BF16)
+        return pro ? dispatch_tile<__bf16, false, true>(prm, st) : dispatch_tile<__bf16, false, false>(prm, st);
+    return pro ? dispatch_tile<float, false, true>(prm, st) : dispatch_tile<float, false, false>(prm, st);
 }
 
 extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
@@ -535,6 +567,6 @@ extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, cons
     prm.M = d->N * d->H * d->W;
     prm.Ktot = d->R * d->S * d->K;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->dtype == MSFWSI_DT_BF16) return dispatch_tile<__bf16, true>(prm, st);
-    return dispatch_tile<float, true>(prm, st);
+    if (d->dtype == MSFWSI_DT_BF16) return dispatch_tile<__bf16, true, false>(prm, st);
+    return dispatch_tile<float, true, false>(prm, st);
 }

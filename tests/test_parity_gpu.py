@@ -31,7 +31,7 @@ pytestmark = pytest.mark.gpu
 def oracle_step(sd0, batch, B, dt, adam=True):
     from oracle import msfwsi_oracle as orc
 
-    osd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    osd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}  # never alias sd0
     (c1, c2), (t1, t2), idx = batch
     b = ((c1.to(dt), c2.to(dt)), (t1.to(dt), t2.to(dt)), idx)
     lr = orc.init_lr(LR, B)
