@@ -86,24 +86,35 @@ template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
 struct IgemmCfg {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int BK = ElemTraits<T>::BK;  // 64-byte operand rows
-    // natural [k][n] weight tile (DGRAD): row stride == 64 (mod 256) bytes for bf16 tr-reads
-    static constexpr int LDN = (sizeof(T) == 2) ? (BN + 32) : (BN + 4);
+    // natural [k][n] weight tile (DGRAD): unpadded rows of ROWB bytes, 64-byte blocks XOR-swizzled by the
+    // row index so that the four rows of a transposed read hit the four quarters of the 256-byte bank row
+    static constexpr int ROWB = BN * (int)sizeof(T);
+    static constexpr int NAT_RPI = 1024 / ROWB;             // rows covered by one 1-KiB DMA instruction
+    static constexpr int NAT_IT = BK * ROWB / 1024 / 4;     // DMA instructions per wave per slab
     static constexpr int TM = BM / WM / 32;
     static constexpr int TN = BN / WN / 32;
     static constexpr int A_IT = BM / 64;  // 16-row groups per wave (4 waves x 16 rows x A_IT = BM)
     static constexpr int B_IT = BN / 64;
-    static constexpr int BNAT_CHUNKS = BN * 4 / 256;  // natural weight tile: 16-byte chunks per thread
     static constexpr int LDC = BN + VEC;
     static constexpr int A_BYTES = BM * 64;
-    static constexpr int B_BYTES = DGRAD ? BK * LDN * (int)sizeof(T) : BN * 64;
-    static constexpr int AB_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int B_BYTES = DGRAD ? BK * ROWB : BN * 64;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int NSTAGE_MAX = 3;
+    static constexpr int AB_BYTES = NSTAGE_MAX * STAGE_BYTES;
     static constexpr int C_BYTES = BM * LDC * (int)sizeof(T);
     static constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
     static constexpr int RED_BYTES = 4 * BN * 2 * (int)sizeof(float);
     static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
+    static_assert(A_IT >= 1 && B_IT >= 1 && NAT_IT >= 1, "tile too small");
 };
+
+// byte offset of element column byte `cb` (byte offset inside the logical row) of natural-tile row k
+template <int ROWB>
+__device__ __forceinline__ int nat_off(int k, int cb) {
+    const int g = (ROWB >= 256) ? (k & 3) : ((k >> 1) & 1);
+    return k * ROWB + ((((cb >> 6) ^ g) << 6) | (cb & 63));
+}
 
 // swizzled position of logical chunk c (0..3) of operand row `row`
 __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 2) & 3); }
@@ -111,15 +122,16 @@ __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 2) & 3)
 template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD> Cfg;
-    constexpr int VEC = Cfg::VEC, BK = Cfg::BK, LDN = Cfg::LDN;
+    constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
+    constexpr bool PD = !APRO;                 // pure-DMA staging: deep (3-stage) pipeline with counted vmcnt
+    constexpr int NST = PD ? 3 : 2;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
-    constexpr int BNAT = Cfg::BNAT_CHUNKS;
     constexpr int LDC = Cfg::LDC;
     typedef typename Frag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                                           // [2][BM][64 B]
-    char* Bs = smem + 2 * Cfg::A_BYTES;                        // [2][BN][64 B] or [2][BK][LDN] elements
+    char* As = smem;                                           // [NST][BM][64 B]
+    char* Bs = smem + Cfg::NSTAGE_MAX * Cfg::A_BYTES;          // [NST][BN][64 B] or [NST][BK][ROWB]
     T* Cs = reinterpret_cast<T*>(smem);                        // [BM][LDC]   (after the k loop)
     float* red = reinterpret_cast<float*>(smem + Cfg::MAIN_BYTES);  // [4][BN][2]
 
@@ -171,7 +183,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
     uint4 a_reg[A_IT];
     bool a_ok[A_IT];
     float a_sc[APRO ? A_IT : 1][VEC], a_sh[APRO ? A_IT : 1][VEC];
-    uint4 b_reg[DGRAD ? BNAT : 1];
 
     // running tap state for the fast path
     int tap_r = 0, tap_s = 0, tap_c = 0;
@@ -250,11 +261,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < BNAT; ++i) {
-                const int c = tid + i * 256;
-                constexpr int CPN = BN / VEC;
-                const int krow = c / CPN, cn = c % CPN;
-                const int kk = k0 + krow, n = n0 + cn * VEC;
+            for (int i = 0; i < Cfg::NAT_IT; ++i) {
+                constexpr int CPRW = ROWB / 16;  // 16-byte chunks per natural row
+                const int krow = (i * 4 + wave) * Cfg::NAT_RPI + lane / CPRW;
+                const int cp = lane % CPRW;      // physical chunk inside the row
+                const int g = (ROWB >= 256) ? (krow & 3) : ((krow >> 1) & 1);
+                const int cl = (((cp >> 2) ^ g) << 2) | (cp & 3);  // logical chunk this lane must fetch
+                const int kk = k0 + krow, n = n0 + cl * VEC;
                 int r, s, co;
                 if (fastk) {
                     r = tap_r;
@@ -270,9 +283,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
                     r = rs / prm.S;
                     s = rs - r * prm.S;
                 }
-                b_reg[i] = make_uint4(0, 0, 0, 0);
-                if (kk < prm.Ktot && n < prm.Nout)
-                    b_reg[i] = *reinterpret_cast<const uint4*>(wgt + (((long)co * prm.R + r) * prm.S + s) * prm.Nout + n);
+                const bool ok = kk < prm.Ktot && n < prm.Nout;
+                const void* gp = ok ? reinterpret_cast<const void*>(
+                                          wgt + (((long)co * prm.R + r) * prm.S + s) * prm.Nout + n)
+                                    : reinterpret_cast<const void*>(zero);
+                dma16(gp, Bb + (i * 4 + wave) * 1024);
             }
         }
         if (fastk) {  // advance the tap for the next slab
@@ -302,16 +317,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
                     v = pack16<T>(f);
                 }
                 *reinterpret_cast<uint4*>(Ab + (i * 4 + wave) * 1024 + lane * 16) = v;
-            }
-        }
-        if (DGRAD) {
-            T* Bb = reinterpret_cast<T*>(Bs + buf * Cfg::B_BYTES);
-#pragma unroll
-            for (int i = 0; i < BNAT; ++i) {
-                const int c = tid + i * 256;
-                constexpr int CPN = BN / VEC;
-                const int krow = c / CPN, cn = c % CPN;
-                *reinterpret_cast<uint4*>(Bb + krow * LDN + cn * VEC) = b_reg[i];
             }
         }
     };
@@ -344,22 +349,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
                     wf[tn] = *reinterpret_cast<const frag_t*>(Bb + row * 64 + swz(row, cidx) * 16);
                 } else if constexpr (sizeof(T) == 2) {
                     // transposed LDS read: 16-lane group G -> columns 16*(G&1).., k-half G>>1
-                    const T* Bn = reinterpret_cast<const T*>(Bb);
                     const int li = lane & 15, G = lane >> 4;
                     const int q = li >> 2, p = li & 3;
                     const int kbase = ks * 16 + (G >> 1) * 8 + q;
-                    const T* a0 = Bn + kbase * LDN + ncol + (G & 1) * 16 + p * 4;
+                    const int cb = (ncol + (G & 1) * 16 + p * 4) * 2;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a0));
+                        (__attribute__((address_space(3))) s16x4*)(Bb + nat_off<ROWB>(kbase, cb)));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a0 + 4 * LDN));
+                        (__attribute__((address_space(3))) s16x4*)(Bb + nat_off<ROWB>(kbase + 4, cb)));
                     const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     wf[tn] = __builtin_bit_cast(frag_t, both);
                 } else {
                     frag_t t;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        t[e] = reinterpret_cast<const float*>(Bb)[(ks * 8 + lh * 4 + e) * LDN + ncol + l31];
+                        t[e] = *reinterpret_cast<const float*>(Bb + nat_off<ROWB>(ks * 8 + lh * 4 + e, (ncol + l31) * 4));
                     wf[tn] = t;
                 }
             }
@@ -370,17 +374,43 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
         }
     };
 
-    // ---------------- main loop (__syncthreads drains the LDS-DMA: it waits vmcnt(0)) ----------------
+    // ---------------- main loop ----------------
     const int nk = (prm.Ktot + BK - 1) / BK;
-    fetch(0, 0);
-    commit(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) fetch((kt + 1) * BK, buf ^ 1);
-        compute(buf);
-        if (kt + 1 < nk) commit(buf ^ 1);
+    if constexpr (PD) {
+        // every byte arrives by LDS-DMA: keep TWO slabs in flight.  Per wave and slab exactly DMA_PER_SLAB
+        // instructions are issued, so "slab kt has landed" == at most DMA_PER_SLAB newer ones outstanding.
+        constexpr int DMA_PER_SLAB = A_IT + (DGRAD ? Cfg::NAT_IT : B_IT);
+        fetch(0, 0);
+        if (nk > 1) fetch(BK, 1);
+        int st_c = 0, st_f = 2;  // stage being computed / stage the next fetch goes to
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                if constexpr (DMA_PER_SLAB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (DMA_PER_SLAB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();  // slab kt visible to all waves; stage st_f (read in kt-1) is free
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) fetch((kt + 2) * BK, st_f);
+            compute(st_c);
+            st_c = st_c == 2 ? 0 : st_c + 1;
+            st_f = st_f == 2 ? 0 : st_f + 1;
+        }
         __syncthreads();
+    } else {
+        // register-staged activations (BatchNorm prologue): one slab ahead; __syncthreads drains the DMA too
+        fetch(0, 0);
+        commit(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) fetch((kt + 1) * BK, buf ^ 1);
+            compute(buf);
+            if (kt + 1 < nk) commit(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---------------- epilogue: accumulators -> LDS tile (storage type) ----------------

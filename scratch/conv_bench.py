@@ -1,0 +1,60 @@
+"""micro-benchmark of the dense kernels on ResNet-50 layer shapes (diagnostic, not part of the product)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from msf_wsi_amd import kernels as kn  # noqa: E402
+
+N = int(os.environ.get("NIMG", "1024"))
+REP = int(os.environ.get("REP", "5"))
+ONLY = os.environ.get("ONLY", "")
+dt = torch.bfloat16
+SHAPES = [  # name, H, C, K, R, stride, pro
+    ("l1.conv1 1x1 256->64", 56, 256, 64, 1, 1, False),
+    ("l1.conv2 3x3 64->64 pro", 56, 64, 64, 3, 1, True),
+    ("l1.conv2 3x3 64->64 nopro", 56, 64, 64, 3, 1, False),
+    ("l1.conv3 1x1 64->256 pro", 56, 64, 256, 1, 1, True),
+    ("l2.conv2 3x3 128->128 pro", 28, 128, 128, 3, 1, True),
+    ("l2.conv3 1x1 128->512 pro", 28, 128, 512, 1, 1, True),
+    ("l3.conv2 3x3 256->256 pro", 14, 256, 256, 3, 1, True),
+    ("l3.conv2 3x3 256->256 nopro", 14, 256, 256, 3, 1, False),
+    ("l3.conv1 1x1 1024->256", 14, 1024, 256, 1, 1, False),
+    ("l4.conv2 3x3 512->512 pro", 7, 512, 512, 3, 1, True),
+]
+
+
+def timeit(fn):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REP):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / REP
+
+
+for name, H, C, K, R, st, pro in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
+    d = kn.conv_desc(dt, N, H, H, C, K, R, R, st, R // 2)
+    x = torch.randn(N, H, H, C, device="cuda").to(dt)
+    w = (torch.randn(K, R, R, C, device="cuda") * 0.05).to(dt)
+    y = torch.empty(N, d.P, d.Q, K, dtype=dt, device="cuda")
+    dy = torch.randn(N, d.P, d.Q, K, device="cuda").to(dt)
+    dx = torch.empty_like(x)
+    dw = torch.zeros(K, R, R, C, device="cuda")
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    stats = kn.new_stats(K)
+    M = N * d.P * d.Q
+    fl = 2.0 * M * K * R * R * C
+    by = 2.0 * (x.numel() + y.numel() + w.numel())
+    p = (sc, sh) if pro else None
+    t_f = timeit(lambda: kn.conv_fwd(d, x, w, y, pro=p, stats=stats))
+    t_d = timeit(lambda: kn.conv_dgrad(d, dy, w, dx))
+    t_w = timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=p))
+    print(f"{name:30s} M={M:9d} fwd {t_f:7.3f} ms {fl / t_f / 1e9:7.1f} TF {by / t_f / 1e6:7.1f} GB/s | "
+          f"dgrad {t_d:7.3f} ms {fl / t_d / 1e9:7.1f} TF | wgrad {t_w:7.3f} ms {fl / t_w / 1e9:7.1f} TF", flush=True)

@@ -1,0 +1,77 @@
+"""GPU: the product's data-parallel path end to end with two ranks.  The GPU box has ONE card, and RCCL refuses
+two ranks on one device, so both ranks share cuda:0 over the gloo backend (it accepts device tensors); the
+engine's SyncBN exchange and the per-group gradient reducer run exactly as under RCCL, only the transport
+differs.  Claim: 2 ranks x B/2 tile pairs == 1 rank x B tile pairs (loss, updated weights, running stats)."""
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import LR, build_product
+
+pytestmark = pytest.mark.gpu
+B, SIZE, K = 4, 64, 16
+
+
+def _batch():
+    from oracle import msfwsi_oracle as orc
+
+    return orc.synthetic_batch(B, SIZE, K, 5)
+
+
+def _worker(rank, world, port, ret):
+    from msf_wsi_amd.dist import shard_range
+    from msf_wsi_amd.train import PretrainStep
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        model = build_product("resnet18").cuda().train()
+        ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False, sync_bn=True)
+        (c1, c2), (t1, t2), idx = _batch()
+        lo, hi = shard_range(B, world, rank)
+        local = ((c1[lo:hi].cuda(), c2[lo:hi].cuda()), (t1[lo * K:hi * K].cuda(), t2[lo * K:hi * K].cuda()),
+                 [idx[0][lo:hi], idx[1][lo:hi]])
+        loss = ts.step(local)
+        torch.cuda.synchronize()
+        mean_loss = ts.epoch_loss()
+        if rank == 0:
+            ret["loss"] = mean_loss
+            ret["sd"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process(hip_lib):
+    from msf_wsi_amd.train import PretrainStep
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+
+    model = build_product("resnet18").cuda().train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False)
+    (c1, c2), (t1, t2), idx = _batch()
+    loss = float(ts.step(((c1.cuda(), c2.cuda()), (t1.cuda(), t2.cuda()), idx)))
+    torch.cuda.synchronize()
+    assert abs(ret["loss"] - loss) <= 1e-5 * max(1.0, abs(loss)), (ret["loss"], loss)
+    sd2 = ret["sd"]
+    lr = LR * (B ** 0.5) / (32 ** 0.5)
+    for k, v in model.state_dict().items():
+        a, b = sd2[k].double(), v.detach().cpu().double()
+        if k.endswith("num_batches_tracked"):
+            assert int(a) == int(b) == 2
+        elif "running_" in k:
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), k
+        else:
+            # same arithmetic up to summation order; Adam's sign-like first step may flip noise-level elements
+            d = (a - b).abs()
+            assert float((d > 0.5 * lr).double().mean()) <= 0.02 or int((d > 0.5 * lr).sum()) <= 2, k
+            assert float((a - b).norm()) <= 0.35 * float((b - sd0[k].double()).norm()) + 1e-12, k
