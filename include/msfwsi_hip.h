@@ -159,6 +159,10 @@ int msfwsi_cast_bf16(const float* src, void* dst, long n, void* stream);
 int msfwsi_pad_cast(int dtype, const float* src, void* dst, long rows, int C, int CP, void* stream);
 int msfwsi_unpad_add(const float* src, float* dst, long rows, int C, int CP, void* stream);
 
+/* performance knobs (never change results): key 0 = minimum grid (in 256x128 tiles) from which the conv
+ * kernels switch from the 128x128 / 4-wave tile to the 256x128 / 8-wave tile. */
+int msfwsi_set_tuning(int key, long value);
+
 /* library identification: returns the gfx target string the code objects were built for */
 const char* msfwsi_target(void);
 

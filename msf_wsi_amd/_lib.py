@@ -57,6 +57,7 @@ SIGNATURES = {
     "msfwsi_cast_bf16": [_vp, _vp, _l, _vp],
     "msfwsi_pad_cast": [_i, _vp, _vp, _l, _i, _i, _vp],
     "msfwsi_unpad_add": [_vp, _vp, _l, _i, _i, _vp],
+    "msfwsi_set_tuning": [_i, _l],
 }
 
 _lib = None

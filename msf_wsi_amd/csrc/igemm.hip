@@ -82,7 +82,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 struct IgemmCfg {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int BK = ElemTraits<T>::BK;  // 64-byte operand rows
@@ -90,22 +90,23 @@ struct IgemmCfg {
     // row index so that the four rows of a transposed read hit the four quarters of the 256-byte bank row
     static constexpr int ROWB = BN * (int)sizeof(T);
     static constexpr int NAT_RPI = 1024 / ROWB;             // rows covered by one 1-KiB DMA instruction
-    static constexpr int NAT_IT = BK * ROWB / 1024 / 4;     // DMA instructions per wave per slab
+    static constexpr int NW = WM * WN;                      // wavefronts per workgroup (4 or 8)
+    static constexpr int NAT_IT = BK * ROWB / 1024 / NW;    // DMA instructions per wave per slab
     static constexpr int TM = BM / WM / 32;
     static constexpr int TN = BN / WN / 32;
-    static constexpr int A_IT = BM / 64;  // 16-row groups per wave (4 waves x 16 rows x A_IT = BM)
-    static constexpr int B_IT = BN / 64;
+    static constexpr int A_IT = BM / (16 * NW);  // 16-row groups per wave (NW waves x 16 rows x A_IT = BM)
+    static constexpr int B_IT = BN / (16 * NW);
     static constexpr int LDC = BN + VEC;
     static constexpr int A_BYTES = BM * 64;
     static constexpr int B_BYTES = DGRAD ? BK * ROWB : BN * 64;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int NSTAGE_MAX = 3;
+    static constexpr int NSTAGE_MAX = APRO ? 2 : 3;  // register-staged prologue: one slab ahead; pure DMA: two
     static constexpr int AB_BYTES = NSTAGE_MAX * STAGE_BYTES;
     static constexpr int C_BYTES = BM * LDC * (int)sizeof(T);
     static constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
-    static constexpr int RED_BYTES = 4 * BN * 2 * (int)sizeof(float);
+    static constexpr int RED_BYTES = NW * BN * 2 * (int)sizeof(float);
     static constexpr int LDS_BYTES = MAIN_BYTES + RED_BYTES;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(A_IT >= 1 && B_IT >= 1 && NAT_IT >= 1, "tile too small");
 };
 
@@ -120,12 +121,13 @@ __device__ __forceinline__ int nat_off(int k, int cb) {
 __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 2) & 3); }
 
 template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
-    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD> Cfg;
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams prm) {
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
     constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
     constexpr bool PD = !APRO;                 // pure-DMA staging: deep (3-stage) pipeline with counted vmcnt
     constexpr int NST = PD ? 3 : 2;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
+    constexpr int NW = Cfg::NW, NT = 64 * Cfg::NW;
     constexpr int LDC = Cfg::LDC;
     typedef typename Frag<T>::type frag_t;
 
@@ -151,7 +153,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     const int PQ = prm.P * prm.Q;
-    const bool fastk = (prm.C % BK) == 0;  // a k-slab never straddles two filter taps
+    const int RS = prm.R * prm.S;
+    // fast path: a k-slab never straddles two filter taps, and the taps fit a 32-bit validity mask
+    const bool fastk = (prm.C % BK) == 0 && RS <= 32;
 
     // ---- staging map: group g = it*4 + wave covers operand rows 16g .. 16g+15; lane -> (row, slot) ----
     // lane l of the group owns LDS bytes [16g*64 + 16*l, +16): row = 16g + l/4, slot = l%4, and therefore
@@ -159,9 +163,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
     int a_hb[A_IT], a_wb[A_IT], a_kc[A_IT];
     long a_img[A_IT];
     bool a_rowok[A_IT];
+    long a_base[A_IT];       // fast path: element offset of the (r=0,s=0) source pixel, channel a_kc*VEC
+    unsigned a_mask[A_IT];   // fast path: bit r*S+s set iff that tap's source pixel exists
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int row = (i * 4 + wave) * 16 + (lane >> 2);
+        const int row = (i * NW + wave) * 16 + (lane >> 2);
         a_kc[i] = swz(row, lane & 3);
         const int m = m0 + row;
         a_rowok[i] = m < prm.M;
@@ -178,57 +184,125 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
             a_hb[i] = p * prm.stride - prm.pad;
             a_wb[i] = q * prm.stride - prm.pad;
         }
+        a_mask[i] = 0;
+        a_base[i] = 0;
+        if (fastk) {
+            unsigned mask = 0;
+            for (int r = 0; r < prm.R; ++r)
+                for (int s2 = 0; s2 < prm.S; ++s2) {
+                    int h, w;
+                    bool ok = a_rowok[i];
+                    if (DGRAD) {
+                        const int th = a_hb[i] - r, tw = a_wb[i] - s2;
+                        if (prm.stride == 1) {
+                            h = th;
+                            w = tw;
+                        } else {
+                            ok = ok && (((th | tw) & 1) == 0);
+                            h = th >> 1;
+                            w = tw >> 1;
+                        }
+                        ok = ok && th >= 0 && tw >= 0;
+                    } else {
+                        h = a_hb[i] + r;
+                        w = a_wb[i] + s2;
+                    }
+                    ok = ok && (unsigned)h < (unsigned)prm.H && (unsigned)w < (unsigned)prm.W;
+                    mask |= (ok ? 1u : 0u) << (r * prm.S + s2);
+                }
+            a_mask[i] = mask;
+            // pixel of tap (0,0); other taps differ by a wave-uniform delta (see tap_delta below).  For the
+            // stride-2 input gradient valid taps have th, r of equal parity, so (th>>1) == (hb>>1) - (r>>1).
+            const int bh = (DGRAD && prm.stride == 2) ? (a_hb[i] >> 1) : a_hb[i];
+            const int bw = (DGRAD && prm.stride == 2) ? (a_wb[i] >> 1) : a_wb[i];
+            a_base[i] = (a_img[i] + (long)bh * prm.W + bw) * prm.C + a_kc[i] * VEC;
+        }
+    }
+    // weight-tile lane constants
+    long b_off[DGRAD ? Cfg::NAT_IT : B_IT];
+    bool b_nok[DGRAD ? Cfg::NAT_IT : B_IT];
+    if (!DGRAD) {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int row = (i * NW + wave) * 16 + (lane >> 2);
+            const int n = n0 + row;
+            b_nok[i] = n < prm.Nout;
+            b_off[i] = (long)n * prm.Ktot + swz(row, lane & 3) * VEC;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < Cfg::NAT_IT; ++i) {
+            constexpr int CPRW = ROWB / 16;
+            const int krow = (i * NW + wave) * Cfg::NAT_RPI + lane / CPRW;
+            const int cp = lane % CPRW;
+            const int g = (ROWB >= 256) ? (krow & 3) : ((krow >> 1) & 1);
+            const int n = n0 + ((((cp >> 2) ^ g) << 2) | (cp & 3)) * VEC;
+            b_nok[i] = n < prm.Nout;
+            b_off[i] = (long)krow * RS * prm.Nout + n;  // source channel co = krow at tap (0,0)
+        }
     }
 
     uint4 a_reg[A_IT];
     bool a_ok[A_IT];
     float a_sc[APRO ? A_IT : 1][VEC], a_sh[APRO ? A_IT : 1][VEC];
 
-    // running tap state for the fast path
+    // running tap state (wave-uniform)
     int tap_r = 0, tap_s = 0, tap_c = 0;
 
     // issue the global traffic of one k-slab: DMA straight into stage `buf`, or loads into registers
     auto fetch = [&](int k0, int buf) {
         char* Ab = As + buf * Cfg::A_BYTES;
         char* Bb = Bs + buf * Cfg::B_BYTES;
+        const int tap_t = tap_r * prm.S + tap_s;
+        long tap_delta;  // element offset of tap (r,s) relative to tap (0,0)
+        if (DGRAD)
+            tap_delta = prm.stride == 1 ? -((long)tap_r * prm.W + tap_s) * prm.C
+                                        : -((long)(tap_r >> 1) * prm.W + (tap_s >> 1)) * prm.C;
+        else
+            tap_delta = ((long)tap_r * prm.W + tap_s) * prm.C;
         // ---------------- activation tile ----------------
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int kk = k0 + a_kc[i] * VEC;
-            int r, s, ch;
+            bool ok;
+            long off;
+            int ch;
             if (fastk) {
-                r = tap_r;
-                s = tap_s;
+                ok = (a_mask[i] >> tap_t) & 1u;
                 ch = tap_c + a_kc[i] * VEC;
-            } else if (prm.R * prm.S == 1) {
-                r = 0;
-                s = 0;
-                ch = kk;
+                off = a_base[i] + tap_delta + tap_c;
             } else {
-                const int rs = kk / prm.C;
-                ch = kk - rs * prm.C;
-                r = rs / prm.S;
-                s = rs - r * prm.S;
-            }
-            int h, w;
-            bool ok = a_rowok[i] && (kk < prm.Ktot);
-            if (DGRAD) {
-                const int th = a_hb[i] - r, tw = a_wb[i] - s;
-                if (prm.stride == 1) {
-                    h = th;
-                    w = tw;
-                } else {  // stride 2
-                    ok = ok && (((th | tw) & 1) == 0);
-                    h = th >> 1;
-                    w = tw >> 1;
+                const int kk = k0 + a_kc[i] * VEC;
+                int r, s;
+                if (RS == 1) {
+                    r = 0;
+                    s = 0;
+                    ch = kk;
+                } else {
+                    const int rs = kk / prm.C;
+                    ch = kk - rs * prm.C;
+                    r = rs / prm.S;
+                    s = rs - r * prm.S;
                 }
-                ok = ok && th >= 0 && tw >= 0;
-            } else {
-                h = a_hb[i] + r;
-                w = a_wb[i] + s;
+                int h, w;
+                ok = a_rowok[i] && (kk < prm.Ktot);
+                if (DGRAD) {
+                    const int th = a_hb[i] - r, tw = a_wb[i] - s;
+                    if (prm.stride == 1) {
+                        h = th;
+                        w = tw;
+                    } else {  // stride 2
+                        ok = ok && (((th | tw) & 1) == 0);
+                        h = th >> 1;
+                        w = tw >> 1;
+                    }
+                    ok = ok && th >= 0 && tw >= 0;
+                } else {
+                    h = a_hb[i] + r;
+                    w = a_wb[i] + s;
+                }
+                ok = ok && (unsigned)h < (unsigned)prm.H && (unsigned)w < (unsigned)prm.W;
+                off = ok ? ((a_img[i] + (long)h * prm.W + w) * prm.C) + ch : 0;
             }
-            ok = ok && (unsigned)h < (unsigned)prm.H && (unsigned)w < (unsigned)prm.W;
-            const long off = ok ? ((a_img[i] + (long)h * prm.W + w) * prm.C) + ch : 0;
             if (APRO) {
                 a_ok[i] = ok;
                 a_reg[i] = make_uint4(0, 0, 0, 0);
@@ -244,50 +318,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
                 }
             } else {
                 const void* g = ok ? reinterpret_cast<const void*>(src + off) : reinterpret_cast<const void*>(zero);
-                dma16(g, Ab + (i * 4 + wave) * 1024);
+                dma16(g, Ab + (i * NW + wave) * 1024);
             }
         }
         // ---------------- weight tile ----------------
         if (!DGRAD) {
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                const int row = (i * 4 + wave) * 16 + (lane >> 2);
-                const int kc = swz(row, lane & 3);
-                const int n = n0 + row, kk = k0 + kc * VEC;
-                const bool ok = n < prm.Nout && kk < prm.Ktot;
-                const void* g = ok ? reinterpret_cast<const void*>(wgt + (long)n * prm.Ktot + kk)
+                bool ok = b_nok[i];
+                if (!fastk) ok = ok && (k0 + swz((i * NW + wave) * 16 + (lane >> 2), lane & 3) * VEC) < prm.Ktot;
+                const void* g = ok ? reinterpret_cast<const void*>(wgt + b_off[i] + k0)
                                    : reinterpret_cast<const void*>(zero);
-                dma16(g, Bb + (i * 4 + wave) * 1024);
+                dma16(g, Bb + (i * NW + wave) * 1024);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < Cfg::NAT_IT; ++i) {
                 constexpr int CPRW = ROWB / 16;  // 16-byte chunks per natural row
-                const int krow = (i * 4 + wave) * Cfg::NAT_RPI + lane / CPRW;
-                const int cp = lane % CPRW;      // physical chunk inside the row
-                const int g = (ROWB >= 256) ? (krow & 3) : ((krow >> 1) & 1);
-                const int cl = (((cp >> 2) ^ g) << 2) | (cp & 3);  // logical chunk this lane must fetch
-                const int kk = k0 + krow, n = n0 + cl * VEC;
-                int r, s, co;
+                bool ok = b_nok[i];
+                long off;
                 if (fastk) {
-                    r = tap_r;
-                    s = tap_s;
-                    co = tap_c + krow;
-                } else if (prm.R * prm.S == 1) {
-                    r = 0;
-                    s = 0;
-                    co = kk;
+                    off = b_off[i] + ((long)tap_c * RS + tap_t) * prm.Nout;
                 } else {
-                    const int rs = kk / prm.C;
-                    co = kk - rs * prm.C;
-                    r = rs / prm.S;
-                    s = rs - r * prm.S;
+                    const int krow = (i * NW + wave) * Cfg::NAT_RPI + lane / CPRW;
+                    const int kk = k0 + krow;
+                    int r, s, co;
+                    if (RS == 1) {
+                        r = 0;
+                        s = 0;
+                        co = kk;
+                    } else {
+                        const int rs = kk / prm.C;
+                        co = kk - rs * prm.C;
+                        r = rs / prm.S;
+                        s = rs - r * prm.S;
+                    }
+                    ok = ok && kk < prm.Ktot;
+                    off = b_off[i] + ((long)(co - krow) * RS + r * prm.S + s) * prm.Nout;
                 }
-                const bool ok = kk < prm.Ktot && n < prm.Nout;
-                const void* gp = ok ? reinterpret_cast<const void*>(
-                                          wgt + (((long)co * prm.R + r) * prm.S + s) * prm.Nout + n)
-                                    : reinterpret_cast<const void*>(zero);
-                dma16(gp, Bb + (i * 4 + wave) * 1024);
+                const void* gp = ok ? reinterpret_cast<const void*>(wgt + off) : reinterpret_cast<const void*>(zero);
+                dma16(gp, Bb + (i * NW + wave) * 1024);
             }
         }
         if (fastk) {  // advance the tap for the next slab
@@ -316,7 +386,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
                     for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], a_sc[i][e], a_sh[i][e]), 0.f);
                     v = pack16<T>(f);
                 }
-                *reinterpret_cast<uint4*>(Ab + (i * 4 + wave) * 1024 + lane * 16) = v;
+                *reinterpret_cast<uint4*>(Ab + (i * NW + wave) * 1024 + lane * 16) = v;
             }
         }
     };
@@ -438,7 +508,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
 
     // ---------------- row-chunk pass: coalesced 16-byte stores + per-channel statistics ----------------
     constexpr int CPR = BN / VEC;        // chunks per tile row
-    constexpr int RPP = 256 / CPR;       // rows per pass
+    constexpr int RPP = NT / CPR;        // rows per pass
     const int cc = tid % CPR;
     const int rr = tid / CPR;
     const int ncol = n0 + cc * VEC;
@@ -504,12 +574,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * BN; i += 256) {
+        for (int i = tid; i < 2 * BN; i += NT) {
             const int col = i % BN, which = i / BN;
             if (n0 + col < prm.Nout) {
                 float t = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) t += red[(w * BN + col) * 2 + which];
+                for (int w = 0; w < NW; ++w) t += red[(w * BN + col) * 2 + which];
                 double* dst = prm.stats + ((long)(tile_m % prm.nshard) * 2 + which) * prm.Nout + n0 + col;
                 atomicAdd(dst, (double)t);
             }
@@ -519,7 +589,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams prm) {
 
 template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 int launch_igemm(IgemmParams& prm, hipStream_t stream) {
-    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD> Cfg;
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
     const int ntm = (prm.M + BM - 1) / BM;
     prm.ntile_n = (prm.Nout + BN - 1) / BN;
     const long nblk = (long)ntm * prm.ntile_n;
@@ -530,13 +600,20 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, stream, prm);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), Cfg::LDS_BYTES, stream, prm);
     return msfwsi_launch_status();
 }
+
+long g_big_tile_min_blocks = 1024;  // tunable through msfwsi_set_tuning
 
 template <typename T, bool DGRAD, bool APRO>
 int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
     if (prm.Nout <= 64) return launch_igemm<T, 128, 64, 2, 2, DGRAD, APRO>(prm, stream);
+    // 256x128 / 8 waves moves 25 % fewer operand bytes through L1/LDS per MFMA (the per-CU 64 B/clk vector
+    // memory path, not HBM, bounds these kernels); keep 128x128 while the grid would not fill the chip
+    // (the register-staged BatchNorm-prologue variant loses with 8 waves: measured 0.55 -> 0.76 ms)
+    if (!APRO && sizeof(T) == 2 && (long)((prm.M + 255) / 256) * ((prm.Nout + 127) / 128) >= g_big_tile_min_blocks)
+        return launch_igemm<T, 256, 128, 4, 2, DGRAD, APRO>(prm, stream);
     return launch_igemm<T, 128, 128, 2, 2, DGRAD, APRO>(prm, stream);
 }
 
@@ -556,6 +633,14 @@ int check_desc(const msfwsi_conv_desc* d) {
 }
 
 }  // namespace
+
+extern "C" int msfwsi_set_tuning(int key, long value) {
+    if (key == 0) {
+        g_big_tile_min_blocks = value;
+        return MSFWSI_OK;
+    }
+    return MSFWSI_EINVAL;
+}
 
 extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y,
                                const float* pro_scale, const float* pro_shift, const float* bias,

@@ -4,15 +4,22 @@
 //
 // (the wgrad half of autograd's conv2d/linear backward that the reference reaches through
 // `scaler.scale(loss).backward()`, tools/ssl_train.py:472).  The reduction runs over output pixels m,
-// so both operand tiles are staged in their natural [m][channel] layout and the MFMA fragments are
+// so both operand tiles are staged in their natural [pixel][channel] layout and the MFMA fragments are
 // fetched with the gfx950 transposed LDS read (ds_read_b64_tr_b16) for bf16, plain b32 reads for fp32.
-// `act` is the producer's BatchNorm+ReLU recomputed on the fly from the saved raw conv output, so the
-// normalised activation is never stored.  Split over m across workgroups; partial tiles are added
-// with fp32 global atomics (one accumulator register = two 128-byte row segments per wave).
+// Rows are unpadded; their 64-byte blocks are XOR-swizzled with the pixel index so that the four rows of
+// one transposed read hit the four quarters of the 256-byte bank row.  The dY tile always arrives by LDS-DMA
+// (global_load_lds_dwordx4, swizzle on the per-lane source address); the activation tile does too unless
+// the producer's BatchNorm+ReLU has to be recomputed on the way in (`act`, from the saved raw conv output, so
+// the normalised activation is never stored) -- then it is register-staged into the same image.  With both
+// tiles on DMA the loop keeps two pixel-slabs in flight behind a counted vmcnt.  Split over m across
+// workgroups; partial tiles are added with fp32 global atomics (one accumulator register = two 128-byte row
+// segments per wave).
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
 namespace {
+
+__device__ __attribute__((aligned(256))) unsigned int g_wzero_page[64];
 
 struct WgradParams {
     const void* x;
@@ -28,23 +35,24 @@ struct WgradParams {
     int ntile_i;
 };
 
-template <typename T, int BI, int BJ>
+template <typename T, int BI, int BJ, bool XPRO = false>
 struct WgradCfg {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int BKM = ElemTraits<T>::BK;  // pixels per stage
-    static constexpr int LDI = (sizeof(T) == 2) ? (BI + 32) : (BI + 4);
-    static constexpr int LDJ = (sizeof(T) == 2) ? (BJ + 32) : (BJ + 4);
+    static constexpr int ROWI = BI * (int)sizeof(T);
+    static constexpr int ROWJ = BJ * (int)sizeof(T);
     static constexpr int WI = (BI >= 128 || BJ <= 64) ? 2 : 1;  // waves along co
     static constexpr int WJ = 4 / WI;
     static constexpr int TI = BI / WI / 32;
     static constexpr int TJ = BJ / WJ / 32;
-    static constexpr int A_CHUNKS = BKM * (BI / VEC) / 256;
-    static constexpr int B_CHUNKS = BKM * (BJ / VEC) / 256;
-    static constexpr int A_BYTES = BKM * LDI * (int)sizeof(T);
-    static constexpr int B_BYTES = BKM * LDJ * (int)sizeof(T);
-    static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int A_BYTES = BKM * ROWI;
+    static constexpr int B_BYTES = BKM * ROWJ;
+    static constexpr int A_IT = A_BYTES / 4096;  // 1-KiB DMA instructions per wave per slab
+    static constexpr int B_IT = B_BYTES / 4096;
+    static constexpr int NST = XPRO ? 2 : 3;
+    static constexpr int LDS_BYTES = NST * (A_BYTES + B_BYTES);
     static_assert(TI >= 1 && TJ >= 1, "tile too small");
-    static_assert(A_CHUNKS >= 1 && B_CHUNKS >= 1, "tile too small");
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
 };
 
 template <typename T>
@@ -58,41 +66,62 @@ struct WFrag<__bf16> {
     typedef bf16x8 type;
 };
 
+__device__ __forceinline__ void wdma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int ROWB>
+__device__ __forceinline__ int wswz(int k) {
+    return (ROWB >= 256) ? (k & 3) : ((k >> 1) & 1);
+}
+// byte offset of byte column `cb` of natural-tile row k
+template <int ROWB>
+__device__ __forceinline__ int wnat_off(int k, int cb) {
+    return k * ROWB + ((((cb >> 6) ^ wswz<ROWB>(k)) << 6) | (cb & 63));
+}
+
 // fragment of a natural-layout [k][col] LDS tile: 32 columns starting at col0, one k-group `ks`
-template <typename T, int LD>
-__device__ __forceinline__ typename WFrag<T>::type read_tr_frag(const T* tile, int ks, int col0, int lane) {
+template <typename T, int ROWB>
+__device__ __forceinline__ typename WFrag<T>::type read_tr_frag(const char* tile, int ks, int col0, int lane) {
     typedef typename WFrag<T>::type frag_t;
     if constexpr (sizeof(T) == 2) {
         const int li = lane & 15, G = lane >> 4;
         const int q = li >> 2, p = li & 3;
-        const T* a0 = tile + (ks * 16 + (G >> 1) * 8 + q) * LD + col0 + (G & 1) * 16 + p * 4;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * LD));
+        const int kb = ks * 16 + (G >> 1) * 8 + q;
+        const int cb = (col0 + (G & 1) * 16 + p * 4) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(tile + wnat_off<ROWB>(kb, cb)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(tile + wnat_off<ROWB>(kb + 4, cb)));
         const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(frag_t, both);
     } else {
         frag_t t;
         const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = reinterpret_cast<const float*>(tile)[(ks * 8 + lh * 4 + e) * LD + col0 + l31];
+        for (int e = 0; e < 4; ++e)
+            t[e] = *reinterpret_cast<const float*>(tile + wnat_off<ROWB>(ks * 8 + lh * 4 + e, (col0 + l31) * 4));
         return t;
     }
 }
 
-template <typename T, int BI, int BJ>
+template <typename T, int BI, int BJ, bool XPRO>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
-    typedef WgradCfg<T, BI, BJ> Cfg;
-    constexpr int VEC = Cfg::VEC, BKM = Cfg::BKM, LDI = Cfg::LDI, LDJ = Cfg::LDJ;
+    typedef WgradCfg<T, BI, BJ, XPRO> Cfg;
+    constexpr int VEC = Cfg::VEC, BKM = Cfg::BKM, ROWI = Cfg::ROWI, ROWJ = Cfg::ROWJ;
     constexpr int WI = Cfg::WI, TI = Cfg::TI, TJ = Cfg::TJ;
-    constexpr int A_CHUNKS = Cfg::A_CHUNKS, B_CHUNKS = Cfg::B_CHUNKS;
-    constexpr int CPI = BI / VEC, CPJ = BJ / VEC;
+    constexpr int A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
+    constexpr int CPI = ROWI / 16, CPJ = ROWJ / 16;      // 16-byte chunks per row
+    constexpr int RPI_A = 1024 / ROWI, RPI_B = 1024 / ROWJ;  // rows per DMA instruction
     typedef typename WFrag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* As = reinterpret_cast<T*>(smem);                     // [2][BKM][LDI]  dY tile
-    T* Bs = reinterpret_cast<T*>(smem + 2 * Cfg::A_BYTES);  // [2][BKM][LDJ]  activation tile
+    char* As = smem;                            // [NST][BKM][ROWI]  dY tile
+    char* Bs = smem + Cfg::NST * Cfg::A_BYTES;  // [NST][BKM][ROWJ]  activation tile
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave % WI, wj = wave / WI;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -104,86 +133,100 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
 
     const T* __restrict__ x = reinterpret_cast<const T*>(prm.x);
     const T* __restrict__ dy = reinterpret_cast<const T*>(prm.dy);
+    const char* zero = reinterpret_cast<const char*>(g_wzero_page);
     const int PQ = prm.P * prm.Q;
-    const bool has_pro = prm.pro_scale != nullptr;
 
-    // this thread's fixed activation column chunk: j -> (r, s, ci)
-    const int cj = tid % CPJ;
-    const int jcol = j0 + cj * VEC;
-    const bool j_ok = jcol < prm.Jtot;
-    int fr = 0, fs = 0, fc = 0;
-    if (j_ok) {
-        const int rs = jcol / prm.C;
-        fc = jcol - rs * prm.C;
-        fr = rs / prm.S;
-        fs = rs - fr * prm.S;
-    }
-    float psc[VEC], psh[VEC];
+    // ---- fixed per-lane staging map (the slab advances by BKM rows, a multiple of 4: swizzle unchanged) ----
+    int a_row[A_IT], a_col[A_IT];
+    bool a_colok[A_IT];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        psc[e] = 1.f;
-        psh[e] = 0.f;
+    for (int i = 0; i < A_IT; ++i) {
+        const int krow = (i * 4 + wave) * RPI_A + lane / CPI;
+        const int cp = lane % CPI;
+        const int cl = (((cp >> 2) ^ wswz<ROWI>(krow)) << 2) | (cp & 3);
+        a_row[i] = krow;
+        a_col[i] = i0 + cl * VEC;
+        a_colok[i] = a_col[i] < prm.K;
     }
-    if (has_pro && j_ok) {
+    int b_row[B_IT], b_r[B_IT], b_s[B_IT], b_c[B_IT];
+    bool b_colok[B_IT];
+    float psc[XPRO ? B_IT : 1][VEC], psh[XPRO ? B_IT : 1][VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            psc[e] = prm.pro_scale[fc + e];
-            psh[e] = prm.pro_shift[fc + e];
+    for (int i = 0; i < B_IT; ++i) {
+        const int krow = (i * 4 + wave) * RPI_B + lane / CPJ;
+        const int cp = lane % CPJ;
+        const int cl = (((cp >> 2) ^ wswz<ROWJ>(krow)) << 2) | (cp & 3);
+        const int jcol = j0 + cl * VEC;
+        b_row[i] = krow;
+        b_colok[i] = jcol < prm.Jtot;
+        const int jj = b_colok[i] ? jcol : 0;
+        const int rs = jj / prm.C;
+        b_c[i] = jj - rs * prm.C;
+        b_r[i] = rs / prm.S;
+        b_s[i] = rs - b_r[i] * prm.S;
+        if (XPRO) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                psc[i][e] = b_colok[i] ? prm.pro_scale[b_c[i] + e] : 1.f;
+                psh[i][e] = b_colok[i] ? prm.pro_shift[b_c[i] + e] : 0.f;
+            }
         }
     }
-    const int ci_a = tid % CPI;  // dY column chunk
-    const bool i_ok = (i0 + ci_a * VEC) < prm.K;
 
-    uint4 a_reg[A_CHUNKS], b_reg[B_CHUNKS];
-    bool b_ok[B_CHUNKS];
+    uint4 b_reg[XPRO ? B_IT : 1];
+    bool b_ok[XPRO ? B_IT : 1];
 
-    auto load_global = [&](int mb) {
+    auto fetch = [&](int mb, int st) {
+        char* Ab = As + st * Cfg::A_BYTES;
+        char* Bb = Bs + st * Cfg::B_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
-            const int krow = tid / CPI + i * (256 / CPI);
-            const int m = mb + krow;
-            a_reg[i] = make_uint4(0, 0, 0, 0);
-            if (m < mend && i_ok) a_reg[i] = *reinterpret_cast<const uint4*>(dy + (long)m * prm.K + i0 + ci_a * VEC);
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = mb + a_row[i];
+            const bool ok = m < mend && a_colok[i];
+            const void* g = ok ? reinterpret_cast<const void*>(dy + (long)m * prm.K + a_col[i])
+                               : reinterpret_cast<const void*>(zero);
+            wdma16(g, Ab + (i * 4 + wave) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) {
-            const int krow = tid / CPJ + i * (256 / CPJ);
-            const int m = mb + krow;
-            b_reg[i] = make_uint4(0, 0, 0, 0);
-            bool ok = (m < mend) && j_ok;
+        for (int i = 0; i < B_IT; ++i) {
+            const int m = mb + b_row[i];
+            bool ok = (m < mend) && b_colok[i];
+            long off = 0;
             if (ok) {
                 const int img = m / PQ;
                 const int rem = m - img * PQ;
                 const int p = rem / prm.Q;
                 const int q = rem - p * prm.Q;
-                const int h = p * prm.stride - prm.pad + fr;
-                const int w = q * prm.stride - prm.pad + fs;
+                const int h = p * prm.stride - prm.pad + b_r[i];
+                const int w = q * prm.stride - prm.pad + b_s[i];
                 ok = (unsigned)h < (unsigned)prm.H && (unsigned)w < (unsigned)prm.W;
-                if (ok) b_reg[i] = *reinterpret_cast<const uint4*>(x + (((long)img * prm.H + h) * prm.W + w) * prm.C + fc);
+                off = (((long)img * prm.H + h) * prm.W + w) * prm.C + b_c[i];
             }
-            b_ok[i] = ok;
+            if (XPRO) {
+                b_ok[i] = ok;
+                b_reg[i] = make_uint4(0, 0, 0, 0);
+                if (ok) b_reg[i] = *reinterpret_cast<const uint4*>(x + off);
+            } else {
+                const void* g = ok ? reinterpret_cast<const void*>(x + off) : reinterpret_cast<const void*>(zero);
+                wdma16(g, Bb + (i * 4 + wave) * 1024);
+            }
         }
     };
-    auto store_lds = [&](int buf) {
-        T* Ab = As + buf * (BKM * LDI);
-        T* Bb = Bs + buf * (BKM * LDJ);
+    auto commit = [&](int st) {
+        if (XPRO) {
+            char* Bb = Bs + st * Cfg::B_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
-            const int krow = tid / CPI + i * (256 / CPI);
-            *reinterpret_cast<uint4*>(Ab + krow * LDI + ci_a * VEC) = a_reg[i];
-        }
+            for (int i = 0; i < B_IT; ++i) {
+                uint4 v = b_reg[i];
+                if (b_ok[i]) {
+                    float f[VEC];
+                    unpack16<T>(v, f);
 #pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) {
-            const int krow = tid / CPJ + i * (256 / CPJ);
-            uint4 v = b_reg[i];
-            if (has_pro && b_ok[i]) {
-                float f[VEC];
-                unpack16<T>(v, f);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], psc[e], psh[e]), 0.f);
-                v = pack16<T>(f);
+                    for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], psc[i][e], psh[i][e]), 0.f);
+                    v = pack16<T>(f);
+                }
+                *reinterpret_cast<uint4*>(Bb + (i * 4 + wave) * 1024 + lane * 16) = v;
             }
-            *reinterpret_cast<uint4*>(Bb + krow * LDJ + cj * VEC) = v;
         }
     };
 
@@ -195,16 +238,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
 
-    auto compute = [&](int buf) {
-        const T* Ab = As + buf * (BKM * LDI);
-        const T* Bb = Bs + buf * (BKM * LDJ);
+    auto compute = [&](int st) {
+        const char* Ab = As + st * Cfg::A_BYTES;
+        const char* Bb = Bs + st * Cfg::B_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BKM / (2 * VEC); ++ks) {
             frag_t af[TI], bf[TJ];
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) af[ti] = read_tr_frag<T, LDI>(Ab, ks, (wi * TI + ti) * 32, lane);
+            for (int ti = 0; ti < TI; ++ti) af[ti] = read_tr_frag<T, ROWI>(Ab, ks, (wi * TI + ti) * 32, lane);
 #pragma unroll
-            for (int tj = 0; tj < TJ; ++tj) bf[tj] = read_tr_frag<T, LDJ>(Bb, ks, (wj * TJ + tj) * 32, lane);
+            for (int tj = 0; tj < TJ; ++tj) bf[tj] = read_tr_frag<T, ROWJ>(Bb, ks, (wj * TJ + tj) * 32, lane);
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -222,15 +265,38 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
 
     const int nk = (mend - mbeg + BKM - 1) / BKM;
     if (nk <= 0) return;
-    load_global(mbeg);
-    store_lds(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_global(mbeg + (kt + 1) * BKM);
-        compute(buf);
-        if (kt + 1 < nk) store_lds(buf ^ 1);
+    if constexpr (!XPRO) {
+        constexpr int DMA_PER_SLAB = A_IT + B_IT;
+        static_assert(DMA_PER_SLAB >= 2 && DMA_PER_SLAB <= 4, "vmcnt literal table");
+        fetch(mbeg, 0);
+        if (nk > 1) fetch(mbeg + BKM, 1);
+        int st_c = 0, st_f = 2;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                if constexpr (DMA_PER_SLAB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (DMA_PER_SLAB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) fetch(mbeg + (kt + 2) * BKM, st_f);
+            compute(st_c);
+            st_c = st_c == 2 ? 0 : st_c + 1;
+            st_f = st_f == 2 ? 0 : st_f + 1;
+        }
+    } else {
+        fetch(mbeg, 0);
+        commit(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) fetch(mbeg + (kt + 1) * BKM, buf ^ 1);
+            compute(buf);
+            if (kt + 1 < nk) commit(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // epilogue: D[co][j]: lane -> j (contiguous in dW rows), registers -> co
@@ -263,8 +329,14 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
     splits = (prm.M + rows - 1) / rows;
     prm.rows_per_split = (int)rows;
     if (tiles > 0x7fffffffL) return MSFWSI_EINVAL;
-    hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
-                       Cfg::LDS_BYTES, stream, prm);
+    constexpr int lds_pro = WgradCfg<T, BI, BJ, true>::LDS_BYTES;
+    constexpr int lds_dma = WgradCfg<T, BI, BJ, false>::LDS_BYTES;
+    if (prm.pro_scale != nullptr)
+        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, true>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
+                           lds_pro, stream, prm);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, false>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
+                           lds_dma, stream, prm);
     return msfwsi_launch_status();
 }
 

@@ -183,6 +183,7 @@ class Engine:
         self._sync_bn = sync_bn
         self.update_running = True
         self.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")  # off | t1 | targets | auto
+        self.materialize_3x3 = os.environ.get("MSFWSI_MATERIALIZE_3X3", "1") != "0"
 
     # ---- configuration ---------------------------------------------------------------------
     @staticmethod
@@ -270,8 +271,14 @@ class Engine:
         c = torch.empty(N, d.P, d.Q, K, dtype=dtype, device=x.device)
         stats = kn.new_stats(K, 2, x.device) if bn is not None else None
         bias = getattr(op, "bias", None)
-        kn.conv_fwd(d, x, w, c, pro=(x_pro.scale, x_pro.shift) if x_pro is not None else None,
-                    bias=bias.data if bias is not None else None, stats=stats)
+        xin, pro = x, (x_pro.scale, x_pro.shift) if x_pro is not None else None
+        if pro is not None and R * S > 1 and self.materialize_3x3:
+            # a 3x3 gather reads every input element 9 times: normalising it once into a transient tensor and
+            # letting the conv stage by pure LDS-DMA is cheaper than re-applying BatchNorm+ReLU per tap
+            xin = torch.empty_like(x)
+            kn.bn_act(x, pro[0], pro[1], xin, relu=True)
+            pro = None
+        kn.conv_fwd(d, xin, w, c, pro=pro, bias=bias.data if bias is not None else None, stats=stats)
         u = Unit(op, bn, relu, d, x, x_pro, c)
         if bn is not None:
             u.st = self._bn_finalize(stats, N * d.P * d.Q, bn)
