@@ -49,10 +49,14 @@ int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, voi
 /* dx = conv_transpose(dy, w) [+ resid] [+ gap_scale * gapg[image]]  (input gradient).  w is the forward
  * weight [K][R][S][C], read in place as the [k][n] operand.  resid: [N,H,W,C] added element-wise (the
  * identity-path gradient of a residual block); gapg: [N][C] broadcast over H*W (global-average-pool
- * gradient).  Replaces: autograd's convolution_backward(input) / linear backward(input) reached through
- * scaler.scale(loss).backward(), tools/ssl_train.py:472. */
+ * gradient).  mask_c != NULL fuses the backward of the activation that produced the conv input,
+ * a = relu(mask_scale*c + mask_shift): dx is gated by (mask_scale*c + mask_shift > 0) and
+ * sums[shard][2][C] += {sum dx, sum dx*c} (what msfwsi_act_bwd_reduce would compute in a second pass).
+ * Replaces: autograd's convolution_backward(input) / linear backward(input) (+ threshold_backward and the
+ * reduction half of batch_norm_backward) reached through scaler.scale(loss).backward(), ssl_train.py:472. */
 int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx, const void* resid,
-                      const void* gapg, float gap_scale, void* stream);
+                      const void* gapg, float gap_scale, const void* mask_c, const float* mask_scale,
+                      const float* mask_shift, double* sums, int nshard, void* stream);
 
 /* dw[K][R][S][C] (fp32) += dy^T * act(x)   (weight gradient, split over pixels, fp32 atomics).
  * target_blocks: workgroup budget used to pick the split factor (<=0: default).

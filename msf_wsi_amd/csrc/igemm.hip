@@ -43,6 +43,9 @@ struct IgemmParams {
     const void* resid;       // [M][Nout], nullable (added in the epilogue)
     const void* gapg;        // [Nimg][Nout] storage type, nullable (added, times gap_scale)
     float gap_scale;
+    const void* mask_c;      // [M][Nout] raw conv output whose BatchNorm+ReLU gates this gradient, nullable
+    const float* mask_scale; // with mask_c: out = acc * (mask_scale*c + mask_shift > 0), stats = {sum g, sum g*c}
+    const float* mask_shift;
     int N, H, W, C;          // source tensor
     int P, Q, Nout;          // output tensor
     int R, S, stride, pad;
@@ -518,6 +521,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     float ssum[VEC], ssq[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
+    const T* __restrict__ mask_c = reinterpret_cast<const T*>(prm.mask_c);
+    float msc[VEC], msh[VEC];
+    if (mask_c != nullptr && col_ok) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            msc[e] = prm.mask_scale[ncol + e];
+            msh[e] = prm.mask_shift[ncol + e];
+        }
+    }
 
 #pragma unroll 2
     for (int pass = 0; pass < BM / RPP; ++pass) {
@@ -544,14 +556,29 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
                 }
                 v = pack16<T>(f);
             }
-            *reinterpret_cast<uint4*>(out + off) = v;
-            if (prm.stats != nullptr) {
-                float f[VEC];
+            if (mask_c != nullptr) {
+                // fused backward of the producer's relu(bn(c)): gate, then accumulate {sum g, sum g*c}
+                float f[VEC], cv[VEC];
                 unpack16<T>(v, f);
+                unpack16<T>(*reinterpret_cast<const uint4*>(mask_c + off), cv);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
+                    if (!(fmaf(cv[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
                     ssum[e] += f[e];
-                    ssq[e] = fmaf(f[e], f[e], ssq[e]);
+                    ssq[e] = fmaf(f[e], cv[e], ssq[e]);
+                }
+                v = pack16<T>(f);
+                *reinterpret_cast<uint4*>(out + off) = v;
+            } else {
+                *reinterpret_cast<uint4*>(out + off) = v;
+                if (prm.stats != nullptr) {
+                    float f[VEC];
+                    unpack16<T>(v, f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        ssum[e] += f[e];
+                        ssq[e] = fmaf(f[e], f[e], ssq[e]);
+                    }
                 }
             }
         }
@@ -667,14 +694,19 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
 }
 
 extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
-                                 const void* resid, const void* gapg, float gap_scale, void* stream) {
+                                 const void* resid, const void* gapg, float gap_scale, const void* mask_c,
+                                 const float* mask_scale, const float* mask_shift, double* sums, int nshard,
+                                 void* stream) {
     int rc = check_desc(d);
     if (rc != MSFWSI_OK) return rc;
     MSFWSI_CHECK_ARG(dy != nullptr && w != nullptr && dx != nullptr);
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
     IgemmParams prm{};
     prm.src = dy; prm.wgt = w; prm.out = dx;
     prm.resid = resid; prm.gapg = gapg; prm.gap_scale = gap_scale;
-    prm.nshard = 1;
+    prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
+    prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
     // source = dY [N,P,Q,K]; output = dX [N,H,W,C]
     prm.N = d->N; prm.H = d->P; prm.W = d->Q; prm.C = d->K;
     prm.P = d->H; prm.Q = d->W; prm.Nout = d->C;

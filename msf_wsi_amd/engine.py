@@ -300,11 +300,12 @@ class Engine:
             kn.colsum(dc, cs)
             kn.add_f64_to_f32(cs, grads.get(bias), 1.0)
 
-    def _unit_dgrad(self, u: Unit, dc: torch.Tensor, dtype: torch.dtype, resid=None, gapg=None, gap_scale=0.0):
+    def _unit_dgrad(self, u: Unit, dc: torch.Tensor, dtype: torch.dtype, resid=None, gapg=None, gap_scale=0.0,
+                    mask=None, sums=None):
         d = u.desc
         dx = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dc.device)
         w = self.weights.get(u.op.weight, dtype)
-        kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale)
+        kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale, mask=mask, sums=sums)
         return dx
 
     # ---- encoder -------------------------------------------------------------------------------
@@ -436,9 +437,9 @@ class Engine:
         for i in range(len(rec.units) - 1, 0, -1):
             u, prev = rec.units[i], rec.units[i - 1]
             self._unit_wgrad(u, cur, grads, dtype)
-            da = self._unit_dgrad(u, cur, dtype)
             s2 = kn.new_stats(prev.c.shape[-1], 2, dev)
-            kn.act_bwd_reduce(da, prev.c, prev.st.scale, prev.st.shift, da, s2)
+            # ReLU gate of prev and its BatchNorm-backward sums are fused into the dgrad epilogue
+            da = self._unit_dgrad(u, cur, dtype, mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2)
             kp = self._bn_bwd_coeffs(s2, 2, 1, prev.bn, prev.st, grads)
             kn.bn_bwd_apply(da, prev.c, kp[0], kp[1], kp[2], da)
             cur = da

@@ -131,7 +131,9 @@ def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
     return y
 
 
-def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0):
+def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mask=None, sums=None):
+    """mask = (c, scale, shift) of the activation that produced the conv input: fuses its ReLU gate and the
+    BatchNorm-backward sums {sum g, sum g*c} (-> sums [nshard,2,C]) into the epilogue."""
     lib = _lib.load()
     dt = dy.dtype
     _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
@@ -139,9 +141,22 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0):
     _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
     _opt(resid, "resid", dt, d.N * d.H * d.W * d.C)
     _opt(gapg, "gapg", dt, d.N * d.C)
+    mc = msc = msh = None
+    nsh = 1
+    if mask is not None:
+        mc, msc, msh = mask
+        _req(mc, "mask_c", dt, d.N * d.H * d.W * d.C)
+        _req(msc, "mask_scale", torch.float32, d.C)
+        _req(msh, "mask_shift", torch.float32, d.C)
+        _req(sums, "sums", torch.float64)
+        nsh = sums.numel() // (2 * d.C)
+        if nsh * 2 * d.C != sums.numel():
+            raise ValueError("sums must be [nshard,2,C]")
+    elif sums is not None:
+        raise ValueError("sums without mask")
     _timed("conv_dgrad", d, dy.element_size(), lambda: _lib.check(
-        lib.msfwsi_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(gapg), float(gap_scale), _stream()),
-        "conv_dgrad"))
+        lib.msfwsi_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(gapg), float(gap_scale), _p(mc),
+                              _p(msc), _p(msh), _p(sums), nsh, _stream()), "conv_dgrad"))
     return dx
 
 

@@ -98,6 +98,34 @@ def test_conv_dgrad(hip_lib, dt, geom):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [CONVS[0], CONVS[1], CONVS[2], CONVS[8]])
+def test_conv_dgrad_fused_activation_backward(hip_lib, dt, geom):
+    """dgrad epilogue gating by the producer's relu(bn(c)) and accumulating {sum g, sum g*c}"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K, R, st, pad = geom
+    g = torch.Generator().manual_seed(12)
+    d = kn.conv_desc(dt, N, H, W, Cc, K, R, R, st, pad)
+    w = rnd((K, Cc, R, R), dt, g, 1.0 / math.sqrt(K * R * R))
+    dy = rnd((N, K, d.P, d.Q), dt, g)
+    c = rnd((N, Cc, H, W), dt, g)
+    sc, sh = torch.rand(Cc, generator=g) - 0.3, torch.randn(Cc, generator=g) * 0.3  # some negative scales
+    ref = torch.nn.grad.conv2d_input((N, Cc, H, W), w.double(), dy.double(), stride=st, padding=pad)
+    gate = (c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0
+    ref = ref * gate
+    dx = torch.empty(N, H, W, Cc, dtype=dt, device="cuda")
+    sums = kn.new_stats(Cc)
+    cd = nhwc(c).to(dt).cuda()
+    kn.conv_dgrad(d, nhwc(dy).to(dt).cuda(), nhwc(w).to(dt).cuda(), dx, mask=(cd, sc.cuda(), sh.cuda()), sums=sums)
+    torch.cuda.synchronize()
+    assert rel(dx.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt)
+    s = sums.sum(0).cpu()
+    gd = dx.double().cpu().reshape(-1, Cc)
+    assert torch.allclose(s[0], gd.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(s[1], (gd * cd.double().cpu().reshape(-1, Cc)).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", CONVS)
 @pytest.mark.parametrize("pro", [False, True])
 def test_conv_wgrad(hip_lib, dt, geom, pro):
