@@ -313,26 +313,42 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
 // global average pool over H*W (resnet.py:244-250): one wave per (image, 16-byte channel chunk)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void gap_fwd_kernel(const T* __restrict__ y, T* __restrict__ out, int N, int HW, int C) {
+__global__ void gap_fwd_kernel(const T* __restrict__ y, T* __restrict__ out, int N, int HW, int C, int cw,
+                               int nrl) {
+    // one workgroup per (channel block, image): lanes run along channels (coalesced 16-byte chunks of a pixel
+    // row), `nrl` row lanes stride over the pixels, partial sums meet in LDS
     constexpr int VEC = ElemTraits<T>::VEC;
-    const int cpr = C / VEC;
-    const int lane = threadIdx.x & 63;
-    const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
-    if (wid >= (long)N * cpr) return;
-    const int n = (int)(wid / cpr), cv = (int)(wid % cpr);
+    extern __shared__ float smem_f[];
+    const int tid = threadIdx.x;
+    const int cc = tid % cw, rl = tid / cw;
+    const int chunk = blockIdx.x * cw + cc;
+    const int n = blockIdx.y;
+    const bool active = rl < nrl && chunk * VEC < C;
     float acc[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-    for (int i = lane; i < HW; i += 64) {
-        float f[VEC];
-        unpack16<T>(*reinterpret_cast<const uint4*>(y + ((long)n * HW + i) * C + cv * VEC), f);
+    if (active) {
+        const T* base = y + (long)n * HW * C + chunk * VEC;
+        for (int i = rl; i < HW; i += nrl) {
+            float f[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(base + (long)i * C), f);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+            for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+        }
     }
-    const float inv = 1.f / (float)HW;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = wave_sum(acc[e]) * inv;
-    if (lane == 0) *reinterpret_cast<uint4*>(out + (long)n * C + cv * VEC) = pack16<T>(acc);
+    for (int e = 0; e < VEC; ++e) smem_f[e * kThreads + tid] = active ? acc[e] : 0.f;
+    __syncthreads();
+    if (active && rl == 0) {
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float t = 0.f;
+            for (int r = 0; r < nrl; ++r) t += smem_f[e * kThreads + r * cw + cc];
+            acc[e] = t * inv;
+        }
+        *reinterpret_cast<uint4*>(out + (long)n * C + chunk * VEC) = pack16<T>(acc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,14 +680,20 @@ extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned ch
 
 extern "C" int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW, int C, void* stream) {
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && y && out && N > 0 && HW > 0 && C % vec_of(dtype) == 0);
-    const long waves = (long)N * (C / vec_of(dtype));
-    const long blocks = (waves + 3) / 4;
+    MSFWSI_CHECK_ARG(N <= 65535);
+    const int vec = vec_of(dtype);
+    const int cpr = C / vec;
+    const int cw = cpr < kThreads ? cpr : kThreads;
+    int nrl = kThreads / cw;
+    if (nrl > HW) nrl = HW;
+    const dim3 grid((unsigned)((cpr + cw - 1) / cw), (unsigned)N);
+    const size_t lds = (size_t)kThreads * vec * sizeof(float);
     if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(gap_fwd_kernel<__bf16>, dim3((unsigned)blocks), dim3(kThreads), 0, ST(stream),
-                           (const __bf16*)y, (__bf16*)out, N, HW, C);
+        hipLaunchKernelGGL(gap_fwd_kernel<__bf16>, grid, dim3(kThreads), lds, ST(stream), (const __bf16*)y,
+                           (__bf16*)out, N, HW, C, cw, nrl);
     else
-        hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((unsigned)blocks), dim3(kThreads), 0, ST(stream),
-                           (const float*)y, (float*)out, N, HW, C);
+        hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(kThreads), lds, ST(stream), (const float*)y,
+                           (float*)out, N, HW, C, cw, nrl);
     return msfwsi_launch_status();
 }
 

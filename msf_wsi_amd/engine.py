@@ -184,6 +184,7 @@ class Engine:
         self.update_running = True
         self.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")  # off | t1 | targets | auto
         self.materialize_3x3 = os.environ.get("MSFWSI_MATERIALIZE_3X3", "1") != "0"
+        self.materialize_wgrad = os.environ.get("MSFWSI_MATERIALIZE_WGRAD", "1") != "0"
 
     # ---- configuration ---------------------------------------------------------------------
     @staticmethod
@@ -286,14 +287,21 @@ class Engine:
 
     def _unit_wgrad(self, u: Unit, dc: torch.Tensor, grads: GradStore, dtype: torch.dtype):
         pro = (u.x_pro.scale, u.x_pro.shift) if u.x_pro is not None else None
+        x = u.x
+        if pro is not None and self.materialize_wgrad and u.desc.N * u.desc.H * u.desc.W >= 8192:
+            # normalise the operand once into a transient tensor: the weight-gradient kernel then stages both
+            # tiles by LDS-DMA (3-stage pipeline) instead of register-staging with the BatchNorm prologue
+            x = torch.empty_like(u.x)
+            kn.bn_act(u.x, pro[0], pro[1], x, relu=True)
+            pro = None
         if u.desc.C != u.op.weight.shape[1]:  # channel-padded stem
             CP = u.desc.C
             dwp = torch.zeros(u.desc.K, u.desc.R, u.desc.S, CP, dtype=torch.float32, device=dc.device)
-            kn.conv_wgrad(u.desc, u.x, dc, dwp, pro=pro)
+            kn.conv_wgrad(u.desc, x, dc, dwp, pro=pro)
             rows = u.desc.K * u.desc.R * u.desc.S
             kn.unpad_add(dwp, grads.get(u.op.weight), rows, u.op.weight.shape[1], CP)
         else:
-            kn.conv_wgrad(u.desc, u.x, dc, grads.get(u.op.weight), pro=pro)
+            kn.conv_wgrad(u.desc, x, dc, grads.get(u.op.weight), pro=pro)
         bias = getattr(u.op, "bias", None)
         if bias is not None:
             cs = torch.zeros(u.desc.K, dtype=torch.float64, device=dc.device)
