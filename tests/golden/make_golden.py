@@ -238,8 +238,71 @@ def run_case(name):
     print(f"[{name}] wrote fixtures ({time.time() - t0:.1f}s)")
 
 
-if __name__ == "__main__":
-    todo = sys.argv[1:] or ["r18_b2_s64", "r18_b8_s64", "r18_b8_s224"]
+def main():
+    todo = sys.argv[1:] or ["r18_b2_s64", "r18_b8_s64", "r18_b8_s224", "encoder"]
     torch.set_num_threads(8)
     for c in todo:
-        run_case(c)
+        if c == "encoder":
+            run_encoder_case()
+        else:
+            run_case(c)
+
+
+def run_encoder_case(name="r50enc_b4_s64", arch="resnet50", B=4, size=64):
+    """Bottleneck-path pin: the reference's ResNet-50 trunk alone (return_features=True), features of a seeded
+    batch and the gradients of  L = sum_s <features_s, R_s>  for seeded random R_s (fp64 reference)."""
+    from oracle import msfwsi_oracle as orc
+
+    sys.path.insert(0, REF)
+    from src.models import resnet as ref_resnet
+    from msf_wsi_amd.models import resnet as my_resnet
+
+    torch.manual_seed(MODEL_SEED)
+    ref = ref_resnet.__dict__[arch](zero_init_residual=False, return_features=True)
+    ref.fc = torch.nn.Identity()
+    torch.manual_seed(MODEL_SEED)
+    mine = my_resnet.__dict__[arch](zero_init_residual=False, return_features=True)
+    mine.fc = torch.nn.Identity()
+    sd0 = {k: v.detach().clone() for k, v in ref.state_dict().items() if not k.startswith("fc.")}
+    msd = {k: v for k, v in mine.state_dict().items() if not k.startswith("fc.")}
+    assert list(msd) == list(sd0) and all(torch.equal(msd[k], sd0[k]) for k in sd0), "init mismatch"
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x = torch.randn(B, 3, size, size, generator=g)
+    dims = [t.shape[1] for t in ref.double()(x.double())]
+    Rs = [torch.randn(B, d, generator=g) for d in dims]
+    ref = ref.double().train()
+    for k, v in sd0.items():  # ref.double() above already consumed one forward (running stats): reset
+        ref.state_dict()[k].copy_(v.double() if v.is_floating_point() else v)
+    feats = ref(x.double())
+    loss = sum((f * r.double()).sum() for f, r in zip(feats, Rs))
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if not n.startswith("fc.")}
+    # oracle restatement reproduces it
+    osd = {"e." + k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    for k, v in osd.items():
+        if orc.is_param(k):
+            v.requires_grad_(True)
+    of = orc.encoder_forward(osd, "e.", x.double())
+    ol = sum((f * r.double()).sum() for f, r in zip(of, Rs))
+    ol.backward()
+    assert abs(float(ol) - float(loss)) < 1e-9 * max(1.0, abs(float(loss)))
+    for n, gr in grads.items():
+        assert rel(osd["e." + n].grad, gr) < 1e-9, n
+    vec = {"loss": np.array([float(loss)])}
+    for s, f in enumerate(feats):
+        vec[f"feat/{s}"] = f.detach().float().numpy()
+    vec["grad_norm"] = np.array([float(g_.norm()) for g_ in grads.values()])
+    for k in ("conv1.weight", "layer1.0.downsample.1.weight", "layer2.0.bn2.bias", "layer4.2.bn3.weight"):
+        if grads[k].numel() <= 4096:
+            vec[f"grad/{k}"] = grads[k].float().numpy()
+    vec["bn/layer3.0.downsample.1/running_var"] = ref.state_dict()["layer3.0.downsample.1.running_var"].float().numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **vec)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump({"case": name, "arch": arch, "B": B, "size": size, "model_seed": MODEL_SEED, "data_seed": DATA_SEED,
+                   "param_keys": list(grads), "feature_dims": dims,
+                   "provenance": "reference src/models/resnet.py imported from /root/reference (trunk only)"}, f)
+    print(f"[{name}] wrote fixtures, loss={float(loss):.9f}")
+
+
+if __name__ == "__main__":
+    main()

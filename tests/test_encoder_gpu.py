@@ -1,0 +1,58 @@
+"""GPU: the stand-alone encoder node (ResNet.forward outside MSFWSI) on the Bottleneck family, pinned to the
+reference's own ResNet-50 trunk through tests/golden/r50enc_b4_s64 (features, loss, gradient norms; fp64)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import MODEL_SEED, load_golden, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resnet50_trunk_matches_reference(hip_lib):
+    from msf_wsi_amd.models import resnet
+
+    vec, man = load_golden("r50enc_b4_s64")
+    B, size = man["B"], man["size"]
+    torch.manual_seed(MODEL_SEED)
+    enc = resnet.resnet50(zero_init_residual=False, return_features=True)
+    enc.fc = torch.nn.Identity()
+    enc = enc.cuda().train()
+    g = torch.Generator().manual_seed(man["data_seed"])
+    x = torch.randn(B, 3, size, size, generator=g)
+    Rs = [torch.randn(B, d, generator=g) for d in man["feature_dims"]]
+    feats = enc(x.cuda())
+    assert len(feats) == 4 and [f.shape[1] for f in feats] == man["feature_dims"] == [256, 512, 1024, 2048]
+    loss = sum((f * r.cuda()).sum() for f, r in zip(feats, Rs))
+    loss.backward()
+    torch.cuda.synchronize()
+    for s, f in enumerate(feats):
+        assert rel(f, vec[f"feat/{s}"]) < 1e-3, (s, rel(f, vec[f"feat/{s}"]))
+    assert abs(float(loss) - float(vec["loss"][0])) <= 1e-3 * abs(float(vec["loss"][0]))
+    named = dict(enc.named_parameters())
+    norms = np.array([float(named[k].grad.double().norm()) for k in man["param_keys"]])
+    rn = np.abs(norms - vec["grad_norm"]) / (vec["grad_norm"] + 1e-30)
+    # same statistical gate as the whole-step test (ReLU gate flips at the fp32 noise floor)
+    assert np.median(rn) < 1e-3 and rn.max() < 5e-2, (float(np.median(rn)), float(rn.max()))
+    for k in ("conv1.weight", "layer1.0.downsample.1.weight", "layer2.0.bn2.bias", "layer4.2.bn3.weight"):
+        if f"grad/{k}" in vec:
+            assert rel(named[k].grad, vec[f"grad/{k}"]) < 2e-2, k
+    rv = enc.state_dict()["layer3.0.downsample.1.running_var"].cpu().numpy()
+    assert np.allclose(rv, vec["bn/layer3.0.downsample.1/running_var"], rtol=1e-3, atol=1e-6)
+
+
+def test_encoder_inference_mode_and_bf16(hip_lib):
+    from msf_wsi_amd.models import resnet
+
+    torch.manual_seed(MODEL_SEED)
+    enc = resnet.resnet18(return_features=True).cuda().train()
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        f32 = enc(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            f16 = enc(x)
+    assert f32[3].shape == (4, 1000) and f32[0].dtype == torch.float32 and f16[0].dtype == torch.bfloat16
+    assert rel(f16[0].float(), f32[0]) < 3e-2
+    with pytest.raises(Exception):
+        with torch.autocast("cuda", dtype=torch.float16):
+            enc(x)
