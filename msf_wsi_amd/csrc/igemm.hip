@@ -85,7 +85,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, bool K2 = false>
 struct IgemmCfg {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int BK = ElemTraits<T>::BK;  // 64-byte operand rows
@@ -103,7 +103,7 @@ struct IgemmCfg {
     static constexpr int A_BYTES = BM * 64;
     static constexpr int B_BYTES = DGRAD ? BK * ROWB : BN * 64;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int NSTAGE_MAX = APRO ? 2 : 3;  // register-staged prologue: one slab ahead; pure DMA: two
+    static constexpr int NSTAGE_MAX = APRO ? 2 : (K2 ? 4 : 3);  // slab slots: prologue 2; DMA 3; DMA two-slab stages 2x2
     static constexpr int AB_BYTES = NSTAGE_MAX * STAGE_BYTES;
     static constexpr int C_BYTES = BM * LDC * (int)sizeof(T);
     static constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
@@ -123,9 +123,9 @@ __device__ __forceinline__ int nat_off(int k, int cb) {
 // swizzled position of logical chunk c (0..3) of operand row `row`
 __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 2) & 3); }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, bool K2>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams prm) {
-    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO, K2> Cfg;
     constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
     constexpr bool PD = !APRO;                 // pure-DMA staging: deep (3-stage) pipeline with counted vmcnt
     constexpr int NST = PD ? 3 : 2;
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     auto fetch = [&](int k0, int buf) {
         char* Ab = As + buf * Cfg::A_BYTES;
         char* Bb = Bs + buf * Cfg::B_BYTES;
-        const int tap_t = tap_r * prm.S + tap_s;
+        const int tap_t = (tap_r * prm.S + tap_s) & 31;
+        const bool slab_ok = k0 < prm.Ktot;  // wave-uniform: the tail slab of a two-slab stage may not exist
         long tap_delta;  // element offset of tap (r,s) relative to tap (0,0)
         if (DGRAD)
             tap_delta = prm.stride == 1 ? -((long)tap_r * prm.W + tap_s) * prm.C
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
             long off;
             int ch;
             if (fastk) {
-                ok = (a_mask[i] >> tap_t) & 1u;
+                ok = slab_ok && ((a_mask[i] >> tap_t) & 1u);
                 ch = tap_c + a_kc[i] * VEC;
                 off = a_base[i] + tap_delta + tap_c;
             } else {
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         if (!DGRAD) {
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                bool ok = b_nok[i];
+                bool ok = b_nok[i] && slab_ok;
                 if (!fastk) ok = ok && (k0 + swz((i * NW + wave) * 16 + (lane >> 2), lane & 3) * VEC) < prm.Ktot;
                 const void* g = ok ? reinterpret_cast<const void*>(wgt + b_off[i] + k0)
                                    : reinterpret_cast<const void*>(zero);
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 #pragma unroll
             for (int i = 0; i < Cfg::NAT_IT; ++i) {
                 constexpr int CPRW = ROWB / 16;  // 16-byte chunks per natural row
-                bool ok = b_nok[i];
+                bool ok = b_nok[i] && slab_ok;
                 long off;
                 if (fastk) {
                     off = b_off[i] + ((long)tap_c * RS + tap_t) * prm.Nout;
@@ -449,7 +450,25 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 
     // ---------------- main loop ----------------
     const int nk = (prm.Ktot + BK - 1) / BK;
-    if constexpr (PD) {
+    if constexpr (PD && K2) {
+        // two slabs per stage, two stages: one barrier per 2*BK of depth (16 MFMAs per wave between barriers)
+        const int nk2 = (nk + 1) / 2;
+        fetch(0, 0);
+        fetch(BK, 1);
+        for (int kt2 = 0; kt2 < nk2; ++kt2) {
+            const int cb = (kt2 & 1) * 2, nb = 2 - cb;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt2 + 1 < nk2) {
+                fetch((2 * kt2 + 2) * BK, nb);
+                fetch((2 * kt2 + 3) * BK, nb + 1);
+            }
+            compute(cb);
+            compute(cb + 1);
+        }
+        __syncthreads();
+    } else if constexpr (PD) {
         // every byte arrives by LDS-DMA: keep TWO slabs in flight.  Per wave and slab exactly DMA_PER_SLAB
         // instructions are issued, so "slab kt has landed" == at most DMA_PER_SLAB newer ones outstanding.
         constexpr int DMA_PER_SLAB = A_IT + (DGRAD ? Cfg::NAT_IT : B_IT);
@@ -614,14 +633,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, bool K2 = false>
 int launch_igemm(IgemmParams& prm, hipStream_t stream) {
-    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO, K2> Cfg;
     const int ntm = (prm.M + BM - 1) / BM;
     prm.ntile_n = (prm.Nout + BN - 1) / BN;
     const long nblk = (long)ntm * prm.ntile_n;
     if (nblk <= 0 || nblk > 0x7fffffffL) return MSFWSI_EINVAL;
-    auto kern = igemm_kernel<T, BM, BN, WM, WN, DGRAD, APRO>;
+    auto kern = igemm_kernel<T, BM, BN, WM, WN, DGRAD, APRO, K2>;
     if (Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -632,6 +651,7 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
 }
 
 long g_big_tile_min_blocks = 1024;  // tunable through msfwsi_set_tuning
+long g_k2_mode = 0;                 // 0: one slab per barrier; 1: two slabs per barrier (128x128); 2: also 256x128
 
 template <typename T, bool DGRAD, bool APRO>
 int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
@@ -640,7 +660,15 @@ int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
     // memory path, not HBM, bounds these kernels); keep 128x128 while the grid would not fill the chip
     // (the register-staged BatchNorm-prologue variant loses with 8 waves: measured 0.55 -> 0.76 ms)
     if (!APRO && sizeof(T) == 2 && (long)((prm.M + 255) / 256) * ((prm.Nout + 127) / 128) >= g_big_tile_min_blocks)
+    {
+        if constexpr (!APRO) {
+            if (g_k2_mode >= 2) return launch_igemm<T, 256, 128, 4, 2, DGRAD, APRO, true>(prm, stream);
+        }
         return launch_igemm<T, 256, 128, 4, 2, DGRAD, APRO>(prm, stream);
+    }
+    if constexpr (!APRO) {
+        if (g_k2_mode >= 1) return launch_igemm<T, 128, 128, 2, 2, DGRAD, APRO, true>(prm, stream);
+    }
     return launch_igemm<T, 128, 128, 2, 2, DGRAD, APRO>(prm, stream);
 }
 
@@ -664,6 +692,10 @@ int check_desc(const msfwsi_conv_desc* d) {
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 0) {
         g_big_tile_min_blocks = value;
+        return MSFWSI_OK;
+    }
+    if (key == 1) {
+        g_k2_mode = value;
         return MSFWSI_OK;
     }
     return MSFWSI_EINVAL;

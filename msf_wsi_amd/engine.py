@@ -182,6 +182,7 @@ class Engine:
         self.group = process_group
         self._sync_bn = sync_bn
         self.update_running = True
+        self._drop_c3 = False
         self.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")  # off | t1 | targets | auto
         self.materialize_3x3 = os.environ.get("MSFWSI_MATERIALIZE_3X3", "1") != "0"
         self.materialize_wgrad = os.environ.get("MSFWSI_MATERIALIZE_WGRAD", "1") != "0"
@@ -362,6 +363,10 @@ class Engine:
                 else:
                     kn.bn_act(last.c, last.st.scale, last.st.shift, y_out, ident=y, relu=True)
                 if save:
+                    if self._drop_c3 and len(units) == 3:
+                        # Bottleneck: the 4x-wide conv3 output is 1/3 of the kept bytes and cheap to redo (1x1):
+                        # drop it, _block_bwd re-runs conv3 from the kept c2 with the kept statistics
+                        last.c = None
                     blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1))
                 y, h, w = y_out, gh, gw
             f = torch.empty(N, y.shape[-1], dtype=dtype, device=x.device)
@@ -384,10 +389,15 @@ class Engine:
             self.update_running = keep
         return full
 
-    def _plan_recompute(self, per_image_bytes: float, B: int, K: int, device) -> set:
-        """which encoder passes run features-only in forward (engine.recompute = off | t1 | targets | auto)"""
+    def _plan_recompute(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float = 0.0) -> set:
+        """which encoder passes run features-only in forward, and whether bottleneck conv3 outputs are dropped
+        (engine.recompute = off | c3 | t1 | targets | auto).  Sets self._drop_c3 for the remaining passes."""
         mode = getattr(self, "recompute", "off")
+        self._drop_c3 = False
         if mode == "off":
+            return set()
+        if mode == "c3":
+            self._drop_c3 = c3_fraction > 0
             return set()
         if mode == "t1":
             return {"t1"}
@@ -395,12 +405,22 @@ class Engine:
             return {"t0", "t1"}
         free, _ = torch.cuda.mem_get_info(device)
         avail = free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
-        budget = 0.80 * avail
-        # backward transients (gradient tensors of the two largest activations) ~ 10 % of one target pass
-        one_target = per_image_bytes * B * K * 1.10
-        if per_image_bytes * B + 2 * one_target < budget:
+        budget = avail - (6 << 30)
+        # calibration (ResNet-50, 256 tile pairs, bf16): kept activations 180 GiB, measured peak 240.8 GiB with
+        # 28 GiB of weights/optimizer -> backward transients (gradient tensors, re-normalised operands, the
+        # recomputed conv3) are about a quarter of one full target pass
+        one_target = per_image_bytes * B * K
+        transients = 0.26 * one_target
+        ctx = per_image_bytes * B  # the second context pass
+        if ctx + 2 * one_target + transients < budget:
             return set()
-        if per_image_bytes * B + one_target < budget:
+        slim = 1.0
+        if c3_fraction > 0:
+            slim = 1.0 - c3_fraction
+            self._drop_c3 = True
+            if ctx * slim + 2 * one_target * slim + transients < budget:
+                return set()
+        if ctx * slim + one_target * slim + transients < budget:
             return {"t1"}
         return {"t0", "t1"}
 
@@ -426,6 +446,11 @@ class Engine:
 
     def _block_bwd(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype) -> torch.Tensor:
         last = rec.units[-1]
+        if last.c is None:  # dropped bottleneck conv3 output: same kernel, same operands -> same bits
+            d = last.desc
+            last.c = torch.empty(d.N, d.P, d.Q, d.K, dtype=dtype, device=rec.y_out.device)
+            kn.conv_fwd(d, last.x, self.weights.get(last.op.weight, dtype), last.c,
+                        pro=(last.x_pro.scale, last.x_pro.shift) if last.x_pro is not None else None)
         Cn = last.c.shape[-1]
         dev = last.c.device
         g = torch.empty_like(rec.y_out)
@@ -531,10 +556,14 @@ class Engine:
             assert tuple(idx.shape) == (B, K), f"jigsaw_idx[{v}] must be [B,K]"
             rec.idx.append(idx.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous())
         # reference call order (backbone.py:140-145): separate BatchNorm batches per call
+        self._drop_c3 = False  # the first (small) context pass keeps everything and calibrates the planner
         m0 = torch.cuda.memory_allocated(dev)
         rec.enc["c0"] = self.encoder_forward(model.context_encoder, x1[0], dtype)
         per_image = (torch.cuda.memory_allocated(dev) - m0) / max(1, B)
-        nosave = self._plan_recompute(per_image, B, K, dev) if need_backward else {"c1", "t0", "t1"}
+        c3_bytes = sum(b.units[-1].c.numel() * b.units[-1].c.element_size() for b in rec.enc["c0"].blocks
+                       if len(b.units) == 3 and b.units[-1].c is not None)
+        c3_frac = (c3_bytes / max(1, B)) / per_image if per_image > 0 else 0.0
+        nosave = self._plan_recompute(per_image, B, K, dev, c3_frac) if need_backward else {"c1", "t0", "t1"}
         if not need_backward:
             rec.enc["c0"] = EncPass(model.context_encoder, B, 0, 0, None, None, None, None, [], rec.enc["c0"].feats,
                                     saved=False)
