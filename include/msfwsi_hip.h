@@ -58,6 +58,17 @@ int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, 
                       const void* gapg, float gap_scale, const void* mask_c, const float* mask_scale,
                       const float* mask_shift, double* sums, int nshard, void* stream);
 
+/* Specialised 3x3 / stride 1 / pad 1 path: the input patch of 256 raster pixels (+ halo) is staged once per
+ * channel slab in LDS and reused by all nine taps (see csrc/conv3x3.hip).  Same results as msfwsi_conv_fwd /
+ * msfwsi_conv_dgrad without prologue/bias/gapg; `supported` tells whether a geometry qualifies.
+ * Replaces: conv3x3 forward / backward(input), src/models/resnet.py:25-28. */
+int msfwsi_conv3x3_supported(const msfwsi_conv_desc* d);
+int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, double* stats, int nshard,
+                       void* stream);
+int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx, const void* resid,
+                         const void* mask_c, const float* mask_scale, const float* mask_shift, double* sums,
+                         int nshard, void* stream);
+
 /* dw[K][R][S][C] (fp32) += dy^T * act(x)   (weight gradient, split over pixels, fp32 atomics).
  * target_blocks: workgroup budget used to pick the split factor (<=0: default).
  * Replaces: convolution_backward(weight) / linear backward(weight), tools/ssl_train.py:472. */

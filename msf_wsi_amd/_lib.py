@@ -58,6 +58,9 @@ SIGNATURES = {
     "msfwsi_pad_cast": [_i, _vp, _vp, _l, _i, _i, _vp],
     "msfwsi_unpad_add": [_vp, _vp, _l, _i, _i, _vp],
     "msfwsi_set_tuning": [_i, _l],
+    "msfwsi_conv3x3_supported": [_desc],
+    "msfwsi_conv3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_conv3x3_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
 }
 
 _lib = None

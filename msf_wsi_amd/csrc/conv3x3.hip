@@ -1,0 +1,441 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and input-gradient) with the input patch staged ONCE per channel
+// slab in LDS and reused by all nine filter taps -- the gfx950 kernel for the convs that carry 45 % (ResNet-50)
+// to 92 % (ResNet-18) of the encoder FLOPs (reference: conv3x3, src/models/resnet.py:25-28, and its
+// convolution_backward(input) reached through tools/ssl_train.py:472).
+//
+// Why: the generic gather-GEMM (igemm.hip) fetches every input element once per tap, i.e. nine times through
+// L2 -> LDS, and waits on that traffic (measured: LDS-DMA latency-bound, ~30 % MFMA utilisation).  Here a
+// workgroup owns BM = 256 consecutive raster pixels of ONE image and BN output channels.  Per 64-byte channel
+// slab it DMAs the BM + 2W + 2 input pixels those outputs touch ("halo rows": raster order makes tap (r,s) a
+// CONSTANT row offset (r-1)*W + (s-1)), a whole slab (= nine tap steps) ahead of use, while the nine per-tap
+// weight tiles stream through a 4-slot ring three steps ahead.  Vertical padding = halo rows outside the
+// image read a zero page; horizontal padding = lanes whose pixel sits in column 0 / W-1 zero their fragment for
+// the s=0 / s=2 taps.  Every byte arrives by global_load_lds_dwordx4; each wave counts its own DMA
+// instructions so the per-step wait is an exact `s_waitcnt vmcnt(n)`.
+//
+// Layout, swizzle, MFMA operand roles and the epilogue (LDS transpose -> 16-byte row stores, BatchNorm sums,
+// fused ReLU-gate + BatchNorm-backward sums for DGRAD) are those of igemm.hip.
+#include "common.h"
+#include "../../include/msfwsi_hip.h"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page3[64];
+
+struct C3Params {
+    const void* src;   // [N][H][W][C]   (forward: x; dgrad: dY with C = forward Cout)
+    const void* wgt;   // forward weight [K][3][3][Cin]
+    void* out;         // [N][H][W][Nout]
+    double* stats;     // [nshard][2][Nout], nullable
+    const void* resid; // [M][Nout], nullable
+    const void* mask_c;
+    const float* mask_scale;
+    const float* mask_shift;
+    int N, H, W, C, Nout;
+    int nshard, ntile_n, tiles_per_img;
+};
+
+template <typename T>
+struct Frag3;
+template <>
+struct Frag3<float> {
+    typedef f32x4 type;
+};
+template <>
+struct Frag3<__bf16> {
+    typedef bf16x8 type;
+};
+
+__device__ __forceinline__ void dma16c(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int swz3(int row, int c) { return c ^ ((row >> 2) & 3); }
+template <int ROWB>
+__device__ __forceinline__ int nat_off3(int k, int cb) {
+    const int g = (ROWB >= 256) ? (k & 3) : ((k >> 1) & 1);
+    return k * ROWB + ((((cb >> 6) ^ g) << 6) | (cb & 63));
+}
+
+__device__ __forceinline__ void wait_vmcnt(int allowed) {
+    // exact counted wait; `allowed` is wave-uniform
+    if (allowed <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (allowed == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (allowed == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (allowed == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (allowed == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (allowed == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (allowed == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+template <typename T, int BN, bool DGRAD>
+struct C3Cfg {
+    static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int BK = ElemTraits<T>::BK;
+    static constexpr int BM = 256, NW = 8, WM = 4, WN = 2;
+    static constexpr int TM = BM / WM / 32;  // 2
+    static constexpr int TN = BN / WN / 32;  // 2 (BN=128) or 1 (BN=64)
+    static constexpr int MAXW = 56;
+    static constexpr int HALO_ROWS = ((BM + 2 * MAXW + 2 + 15) / 16) * 16;  // 384
+    static constexpr int A_BYTES = HALO_ROWS * 64;                          // 24 KiB per slab
+    static constexpr int ROWB = BN * (int)sizeof(T);                        // natural weight row (DGRAD)
+    static constexpr int B_BYTES = DGRAD ? BK * ROWB : BN * 64;             // one tap: 8 KiB (BN=128)
+    static constexpr int NRING = 4;
+    static constexpr int LDC = BN + VEC;
+    static constexpr int AB_BYTES = 2 * A_BYTES + NRING * B_BYTES;
+    static constexpr int C_BYTES = BM * LDC * (int)sizeof(T) + NW * BN * 2 * (int)sizeof(float);
+    static constexpr int LDS_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
+};
+
+template <typename T, int BN, bool DGRAD>
+__global__ __launch_bounds__(512) void conv3x3_kernel(const C3Params prm) {
+    typedef C3Cfg<T, BN, DGRAD> Cfg;
+    constexpr int VEC = Cfg::VEC, BK = Cfg::BK, BM = Cfg::BM, NW = Cfg::NW, WM = Cfg::WM;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, LDC = Cfg::LDC, ROWB = Cfg::ROWB;
+    constexpr int NT = 64 * NW;
+    typedef typename Frag3<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                        // [2][HALO_ROWS][64 B]
+    char* Bs = smem + 2 * Cfg::A_BYTES;     // [NRING][B_BYTES]
+    T* Cs = reinterpret_cast<T*>(smem);     // epilogue: [BM][LDC] then red[NW][BN][2]
+    float* red = reinterpret_cast<float*>(smem + BM * LDC * (int)sizeof(T));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tile_n = blockIdx.x % prm.ntile_n;
+    const int tile_mi = blockIdx.x / prm.ntile_n;
+    const int img = tile_mi / prm.tiles_per_img;
+    const int p0 = (tile_mi - img * prm.tiles_per_img) * BM;  // first output pixel (raster index in the image)
+    const int n0 = tile_n * BN;
+    const int HW = prm.H * prm.W, W = prm.W;
+    const int halo_rows = BM + 2 * W + 2;
+
+    const T* __restrict__ src = reinterpret_cast<const T*>(prm.src) + (long)img * HW * prm.C;
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(prm.wgt);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page3);
+
+    const int nslab = prm.C / BK;
+    const int nstep = nslab * 9;
+    int issued = 0;          // DMA instructions this wave has issued so far
+    int b_mark[Cfg::NRING];  // value of `issued` right after the weight tile of ring slot i was issued
+#pragma unroll
+    for (int i = 0; i < Cfg::NRING; ++i) b_mark[i] = 0;
+
+    // halo rows of slab s: row hr <-> pixel p0 - W - 1 + hr of this image (zero outside)
+    auto fetch_A = [&](int s, int buf) {
+        char* Ab = As + buf * Cfg::A_BYTES;
+        for (int g = wave; g * 16 < halo_rows; g += NW) {
+            const int hr = g * 16 + (lane >> 2);
+            const int p = p0 - W - 1 + hr;
+            const int kc = swz3(hr, lane & 3);
+            const bool ok = hr < halo_rows && p >= 0 && p < HW;
+            const void* gp = ok ? reinterpret_cast<const void*>(src + (long)p * prm.C + s * BK + kc * VEC)
+                                : reinterpret_cast<const void*>(zero);
+            dma16c(gp, Ab + g * 1024);
+            ++issued;
+        }
+    };
+    // weight tile of step j = (slab, tap): forward [n][k] rows of 64 B; dgrad natural [k][n], flipped tap
+    auto fetch_B = [&](int j, int slot) {
+        char* Bb = Bs + slot * Cfg::B_BYTES;
+        const int s = j / 9, t = j - s * 9;
+        if (!DGRAD) {
+            for (int g = wave; g * 16 < BN; g += NW) {
+                const int row = g * 16 + (lane >> 2);
+                const int kc = swz3(row, lane & 3);
+                const int n = n0 + row;
+                const void* gp = n < prm.Nout
+                                     ? reinterpret_cast<const void*>(wgt + ((long)n * 9 + t) * prm.C + s * BK + kc * VEC)
+                                     : reinterpret_cast<const void*>(zero);
+                dma16c(gp, Bb + g * 1024);
+                ++issued;
+            }
+        } else {
+            constexpr int CPRW = ROWB / 16, RPI = 1024 / ROWB;
+            for (int g = wave; g * RPI < BK; g += NW) {
+                const int krow = g * RPI + lane / CPRW;
+                const int cp = lane % CPRW;
+                const int gsw = (ROWB >= 256) ? (krow & 3) : ((krow >> 1) & 1);
+                const int n = n0 + ((((cp >> 2) ^ gsw) << 2) | (cp & 3)) * VEC;
+                const int co = s * BK + krow;  // source channel = forward output channel
+                // dX[p] += dY[p + (1-r)W + (1-s)] * W[co][r][s][ci]: halo offset index t' = 8 - t  <->  tap t
+                const void* gp = n < prm.Nout ? reinterpret_cast<const void*>(wgt + ((long)co * 9 + (8 - t)) * prm.Nout + n)
+                                              : reinterpret_cast<const void*>(zero);
+                dma16c(gp, Bb + g * 1024);
+                ++issued;
+            }
+        }
+        b_mark[slot] = issued;
+    };
+
+    // per-lane horizontal-padding flags of the TM pixels this lane owns as MFMA columns
+    bool edge_l[TM], edge_r[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int p = p0 + (wm * TM + tm) * 32 + l31;
+        const int col = p % W;
+        edge_l[tm] = col == 0;
+        edge_r[tm] = col == W - 1;
+    }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+    auto compute = [&](int abuf, int slot, int t) {
+        const char* Ab = As + abuf * Cfg::A_BYTES;
+        const char* Bb = Bs + slot * Cfg::B_BYTES;
+        const int r = t / 3, s = t - r * 3;
+        const int roff = r * W + s;  // halo row of output row 0 for this tap
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag_t xf[TM], wf[TN];
+            const int cidx = ks * 2 + lh;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = (wm * TM + tm) * 32 + l31 + roff;
+                xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * 64 + swz3(row, cidx) * 16);
+                const bool kill = (s == 0 && edge_l[tm]) || (s == 2 && edge_r[tm]);
+                if (kill) xf[tm] = frag_t{};
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int ncol = (wn * TN + tn) * 32;
+                if (!DGRAD) {
+                    const int row = ncol + l31;
+                    wf[tn] = *reinterpret_cast<const frag_t*>(Bb + row * 64 + swz3(row, cidx) * 16);
+                } else if constexpr (sizeof(T) == 2) {
+                    const int li = lane & 15, G = lane >> 4;
+                    const int q = li >> 2, p = li & 3;
+                    const int kbase = ks * 16 + (G >> 1) * 8 + q;
+                    const int cb = (ncol + (G & 1) * 16 + p * 4) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Bb + nat_off3<ROWB>(kbase, cb)));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Bb + nat_off3<ROWB>(kbase + 4, cb)));
+                    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    wf[tn] = __builtin_bit_cast(frag_t, both);
+                } else {
+                    frag_t tt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        tt[e] = *reinterpret_cast<const float*>(Bb + nat_off3<ROWB>(ks * 8 + lh * 4 + e, (ncol + l31) * 4));
+                    wf[tn] = tt;
+                }
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[tn][e], xf[tm][e], acc[tn][tm], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    // ---------------- pipeline: A one slab (nine steps) ahead, weights three steps ahead ----------------
+    fetch_A(0, 0);
+    fetch_B(0, 0);
+    if (nstep > 1) fetch_B(1, 1);
+    if (nstep > 2) fetch_B(2, 2);
+    int slot = 0;
+    for (int j = 0; j < nstep; ++j) {
+        const int s = j / 9, t = j - s * 9;
+        // everything issued up to and including weight tile j must have landed (A(s) was issued before it,
+        // except for slab 0 whose A precedes B(0) as well): allow only the instructions issued after it
+        wait_vmcnt(issued - b_mark[slot]);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 3 < nstep) fetch_B(j + 3, (slot + 3) & 3);
+        if (t == 0 && s + 1 < nslab) fetch_A(s + 1, (s + 1) & 1);
+        compute(s & 1, slot, t);
+        slot = (slot + 1) & 3;
+    }
+    __syncthreads();
+
+    // ---------------- epilogue (as igemm.hip) ----------------
+    const int m_img0 = img * HW;  // global row of this image's pixel 0
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ncol = (wn * TN + tn) * 32 + 8 * g + 4 * lh;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = (wm * TM + tm) * 32 + l31;
+                T* dst = Cs + row * LDC + ncol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) store_elem<T>(dst, e, acc[tn][tm][g * 4 + e]);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / VEC;
+    constexpr int RPP = NT / CPR;
+    const int cc = tid % CPR;
+    const int rr = tid / CPR;
+    const int ncol = n0 + cc * VEC;
+    const bool col_ok = ncol < prm.Nout;
+    T* __restrict__ out = reinterpret_cast<T*>(prm.out);
+    const T* __restrict__ resid = reinterpret_cast<const T*>(prm.resid);
+    const T* __restrict__ mask_c = reinterpret_cast<const T*>(prm.mask_c);
+    float ssum[VEC], ssq[VEC], msc[VEC], msh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
+    if (mask_c != nullptr && col_ok) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            msc[e] = prm.mask_scale[ncol + e];
+            msh[e] = prm.mask_shift[ncol + e];
+        }
+    }
+#pragma unroll 2
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int row = rr + pass * RPP;
+        const int p = p0 + row;
+        if (p < HW && col_ok) {
+            uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
+            const long off = (long)(m_img0 + p) * prm.Nout + ncol;
+            if (resid != nullptr) {
+                float f[VEC], g[VEC];
+                unpack16<T>(v, f);
+                unpack16<T>(*reinterpret_cast<const uint4*>(resid + off), g);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] += g[e];
+                v = pack16<T>(f);
+            }
+            if (mask_c != nullptr) {
+                float f[VEC], cv[VEC];
+                unpack16<T>(v, f);
+                unpack16<T>(*reinterpret_cast<const uint4*>(mask_c + off), cv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (!(fmaf(cv[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
+                    ssum[e] += f[e];
+                    ssq[e] = fmaf(f[e], cv[e], ssq[e]);
+                }
+                v = pack16<T>(f);
+                *reinterpret_cast<uint4*>(out + off) = v;
+            } else {
+                *reinterpret_cast<uint4*>(out + off) = v;
+                if (prm.stats != nullptr) {
+                    float f[VEC];
+                    unpack16<T>(v, f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        ssum[e] += f[e];
+                        ssq[e] = fmaf(f[e], f[e], ssq[e]);
+                    }
+                }
+            }
+        }
+    }
+    if (prm.stats != nullptr) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+            for (int off = CPR; off < 64; off <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], off, 64);
+                ssq[e] += __shfl_xor(ssq[e], off, 64);
+            }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                red[(wave * BN + lane * VEC + e) * 2 + 0] = ssum[e];
+                red[(wave * BN + lane * VEC + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += NT) {
+            const int col = i % BN, which = i / BN;
+            if (n0 + col < prm.Nout) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += red[(w * BN + col) * 2 + which];
+                double* dst = prm.stats + ((long)(tile_mi % prm.nshard) * 2 + which) * prm.Nout + n0 + col;
+                atomicAdd(dst, (double)t);
+            }
+        }
+    }
+}
+
+template <typename T, int BN, bool DGRAD>
+int launch_c3(C3Params& prm, hipStream_t stream) {
+    typedef C3Cfg<T, BN, DGRAD> Cfg;
+    const int HW = prm.H * prm.W;
+    prm.tiles_per_img = (HW + Cfg::BM - 1) / Cfg::BM;
+    prm.ntile_n = (prm.Nout + BN - 1) / BN;
+    const long nblk = (long)prm.N * prm.tiles_per_img * prm.ntile_n;
+    if (nblk <= 0 || nblk > 0x7fffffffL) return MSFWSI_EINVAL;
+    auto kern = conv3x3_kernel<T, BN, DGRAD>;
+    static bool attr_done = false;  // one attribute per instantiation
+    if (!attr_done && Cfg::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), Cfg::LDS_BYTES, stream, prm);
+    return msfwsi_launch_status();
+}
+
+}  // namespace
+
+// 1 if the halo kernel handles this geometry (3x3, stride 1, pad 1, 14 <= W <= 56, channel slabs of 64 bytes)
+extern "C" int msfwsi_conv3x3_supported(const msfwsi_conv_desc* d) {
+    if (d == nullptr) return 0;
+    const int bk = d->dtype == MSFWSI_DT_BF16 ? 32 : 16;
+    if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1) return 0;
+    if (d->W > 56 || d->H * d->W < 128) return 0;
+    if (d->C % bk != 0 || d->K % bk != 0) return 0;
+    return 1;
+}
+
+extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, double* stats,
+                                  int nshard, void* stream) {
+    if (!msfwsi_conv3x3_supported(d)) return MSFWSI_EUNSUPPORTED;
+    MSFWSI_CHECK_ARG(x != nullptr && w != nullptr && y != nullptr && (stats == nullptr || nshard >= 1));
+    MSFWSI_CHECK_ARG((long)d->N * d->H * d->W <= 0x7fffffffL);
+    C3Params prm{};
+    prm.src = x; prm.wgt = w; prm.out = y; prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C; prm.Nout = d->K;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MSFWSI_DT_BF16)
+        return d->K <= 64 ? launch_c3<__bf16, 64, false>(prm, st) : launch_c3<__bf16, 128, false>(prm, st);
+    return d->K <= 64 ? launch_c3<float, 64, false>(prm, st) : launch_c3<float, 128, false>(prm, st);
+}
+
+extern "C" int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
+                                    const void* resid, const void* mask_c, const float* mask_scale,
+                                    const float* mask_shift, double* sums, int nshard, void* stream) {
+    if (!msfwsi_conv3x3_supported(d)) return MSFWSI_EUNSUPPORTED;
+    MSFWSI_CHECK_ARG(dy != nullptr && w != nullptr && dx != nullptr);
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
+    MSFWSI_CHECK_ARG((long)d->N * d->H * d->W <= 0x7fffffffL);
+    C3Params prm{};
+    prm.src = dy; prm.wgt = w; prm.out = dx; prm.resid = resid;
+    prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
+    prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->K; prm.Nout = d->C;  // stride 1: same H, W
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MSFWSI_DT_BF16)
+        return d->C <= 64 ? launch_c3<__bf16, 64, true>(prm, st) : launch_c3<__bf16, 128, true>(prm, st);
+    return d->C <= 64 ? launch_c3<float, 64, true>(prm, st) : launch_c3<float, 128, true>(prm, st);
+}

@@ -186,6 +186,10 @@ class Engine:
         self.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")  # off | t1 | targets | auto
         self.materialize_3x3 = os.environ.get("MSFWSI_MATERIALIZE_3X3", "1") != "0"
         self.materialize_wgrad = os.environ.get("MSFWSI_MATERIALIZE_WGRAD", "1") != "0"
+        # halo-in-LDS 3x3 kernel: measured +14..25 % for the input gradient (natural 256-byte weight rows),
+        # -7..+2 % for the forward (64-byte weight rows): on for dgrad, off for fwd
+        self.halo3x3 = os.environ.get("MSFWSI_HALO3X3", "1") != "0"
+        self.halo3x3_fwd = os.environ.get("MSFWSI_HALO3X3_FWD", "0") != "0"
 
     # ---- configuration ---------------------------------------------------------------------
     @staticmethod
@@ -280,7 +284,10 @@ class Engine:
             xin = torch.empty_like(x)
             kn.bn_act(x, pro[0], pro[1], xin, relu=True)
             pro = None
-        kn.conv_fwd(d, xin, w, c, pro=pro, bias=bias.data if bias is not None else None, stats=stats)
+        if self.halo3x3_fwd and pro is None and bias is None and not pad_c and kn.conv3x3_supported(d):
+            kn.conv3x3_fwd(d, xin, w, c, stats=stats)  # input patch staged once per channel slab, 9 taps reuse it
+        else:
+            kn.conv_fwd(d, xin, w, c, pro=pro, bias=bias.data if bias is not None else None, stats=stats)
         u = Unit(op, bn, relu, d, x, x_pro, c)
         if bn is not None:
             u.st = self._bn_finalize(stats, N * d.P * d.Q, bn)
@@ -314,7 +321,10 @@ class Engine:
         d = u.desc
         dx = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dc.device)
         w = self.weights.get(u.op.weight, dtype)
-        kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale, mask=mask, sums=sums)
+        if self.halo3x3 and gapg is None and kn.conv3x3_supported(d):
+            kn.conv3x3_dgrad(d, dc, w, dx, resid=resid, mask=mask, sums=sums)
+        else:
+            kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale, mask=mask, sums=sums)
         return dx
 
     # ---- encoder -------------------------------------------------------------------------------

@@ -439,3 +439,53 @@ def unpad_add(src, dst, rows, Cn, CP):
     _req(src, "src", torch.float32, rows * CP)
     _req(dst, "dst", torch.float32, rows * Cn)
     _lib.check(lib.msfwsi_unpad_add(_p(src), _p(dst), rows, Cn, CP, _stream()), "unpad_add")
+
+
+# ------------------------------------------------------------------------------------------------
+# 3x3 / stride-1 halo kernel (csrc/conv3x3.hip)
+# ------------------------------------------------------------------------------------------------
+def conv3x3_supported(d: ConvDesc) -> bool:
+    return bool(_lib.load().msfwsi_conv3x3_supported(C.byref(d)))
+
+
+def conv3x3_fwd(d: ConvDesc, x, w, y, stats=None):
+    lib = _lib.load()
+    dt = x.dtype
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(w, "w", dt, d.K * 9 * d.C)
+    _req(y, "y", dt, d.N * d.P * d.Q * d.K)
+    nsh = 1
+    if stats is not None:
+        _req(stats, "stats", torch.float64)
+        nsh = stats.shape[0]
+        if stats.numel() != nsh * 2 * d.K:
+            raise ValueError("stats must be [nshard,2,K]")
+    _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
+        lib.msfwsi_conv3x3_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(stats), nsh, _stream()), "conv3x3_fwd"))
+    return y
+
+
+def conv3x3_dgrad(d: ConvDesc, dy, w, dx, resid=None, mask=None, sums=None):
+    lib = _lib.load()
+    dt = dy.dtype
+    _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
+    _req(w, "w", dt, d.K * 9 * d.C)
+    _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
+    _opt(resid, "resid", dt, d.N * d.H * d.W * d.C)
+    mc = msc = msh = None
+    nsh = 1
+    if mask is not None:
+        mc, msc, msh = mask
+        _req(mc, "mask_c", dt, d.N * d.H * d.W * d.C)
+        _req(msc, "mask_scale", torch.float32, d.C)
+        _req(msh, "mask_shift", torch.float32, d.C)
+        _req(sums, "sums", torch.float64)
+        nsh = sums.numel() // (2 * d.C)
+        if nsh * 2 * d.C != sums.numel():
+            raise ValueError("sums must be [nshard,2,C]")
+    elif sums is not None:
+        raise ValueError("sums without mask")
+    _timed("conv_dgrad", d, dy.element_size(), lambda: _lib.check(
+        lib.msfwsi_conv3x3_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(mc), _p(msc), _p(msh), _p(sums),
+                                 nsh, _stream()), "conv3x3_dgrad"))
+    return dx

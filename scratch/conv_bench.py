@@ -14,6 +14,7 @@ _L.load().msfwsi_set_tuning(0, int(os.environ.get("TUNE_BIG", "1024")))
 N = int(os.environ.get("NIMG", "1024"))
 REP = int(os.environ.get("REP", "5"))
 ONLY = os.environ.get("ONLY", "")
+HALO = os.environ.get("HALO", "1") != "0"
 dt = torch.bfloat16
 SHAPES = [  # name, H, C, K, R, stride, pro
     ("l1.conv1 1x1 256->64", 56, 256, 64, 1, 1, False),
@@ -57,8 +58,12 @@ for name, H, C, K, R, st, pro in SHAPES:
     fl = 2.0 * M * K * R * R * C
     by = 2.0 * (x.numel() + y.numel() + w.numel())
     p = (sc, sh) if pro else None
-    t_f = timeit(lambda: kn.conv_fwd(d, x, w, y, pro=p, stats=stats))
-    t_d = timeit(lambda: kn.conv_dgrad(d, dy, w, dx))
+    if HALO and R == 3 and not pro and kn.conv3x3_supported(d):
+        t_f = timeit(lambda: kn.conv3x3_fwd(d, x, w, y, stats=stats))
+        t_d = timeit(lambda: kn.conv3x3_dgrad(d, dy, w, dx))
+    else:
+        t_f = timeit(lambda: kn.conv_fwd(d, x, w, y, pro=p, stats=stats))
+        t_d = timeit(lambda: kn.conv_dgrad(d, dy, w, dx))
     t_w = timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=p))
     print(f"{name:30s} M={M:9d} fwd {t_f:7.3f} ms {fl / t_f / 1e9:7.1f} TF {by / t_f / 1e6:7.1f} GB/s | "
           f"dgrad {t_d:7.3f} ms {fl / t_d / 1e9:7.1f} TF | wgrad {t_w:7.3f} ms {fl / t_w / 1e9:7.1f} TF", flush=True)

@@ -413,3 +413,72 @@ def test_bad_arguments_are_rejected(hip_lib):
         kn.conv_fwd(d, x, w, y)
     with pytest.raises(MsfwsiHipError):
         kn.conv_fwd(kn.conv_desc(torch.float32, 1, 8, 8, 8, 8, 3, 3, 1, 1), x.cpu(), w, y)
+
+
+HALO = [  # N, H, W, C, K     (3x3, stride 1, pad 1)
+    (2, 56, 56, 64, 64),
+    (3, 28, 28, 128, 128),
+    (5, 14, 14, 64, 256),    # one 196-pixel image per 256-row tile
+    (2, 20, 23, 32, 96),     # odd width, HW not a multiple of the tile, K not a tile multiple
+    (1, 16, 8, 96, 32),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", HALO)
+def test_conv3x3_halo_fwd(hip_lib, dt, geom):
+    """halo-in-LDS 3x3 kernel (csrc/conv3x3.hip) against F.conv2d, incl. the BatchNorm sums"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K = geom
+    if dt == torch.float32 and Cc % 16:
+        pytest.skip("fp32 slabs are 16 channels")
+    g = torch.Generator().manual_seed(21)
+    x = rnd((N, Cc, H, W), dt, g)
+    w = rnd((K, Cc, 3, 3), dt, g, 1.0 / math.sqrt(Cc * 9))
+    d = kn.conv_desc(dt, N, H, W, Cc, K, 3, 3, 1, 1)
+    assert kn.conv3x3_supported(d)
+    ref = F.conv2d(x.double(), w.double(), None, stride=1, padding=1)
+    y = torch.empty(N, H, W, K, dtype=dt, device="cuda")
+    stats = kn.new_stats(K)
+    kn.conv3x3_fwd(d, nhwc(x).to(dt).cuda(), nhwc(w).to(dt).cuda(), y, stats=stats)
+    torch.cuda.synchronize()
+    assert rel(y.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt)
+    s = stats.sum(0).cpu()
+    yy = y.double().cpu().reshape(-1, K)
+    assert torch.allclose(s[0], yy.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(s[1], (yy * yy).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", HALO)
+@pytest.mark.parametrize("fused", [False, True])
+def test_conv3x3_halo_dgrad(hip_lib, dt, geom, fused):
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K = geom
+    if dt == torch.float32 and (Cc % 16 or K % 16):
+        pytest.skip("fp32 slabs are 16 channels")
+    g = torch.Generator().manual_seed(22)
+    d = kn.conv_desc(dt, N, H, W, Cc, K, 3, 3, 1, 1)
+    w = rnd((K, Cc, 3, 3), dt, g, 1.0 / math.sqrt(K * 9))
+    dy = rnd((N, K, H, W), dt, g)
+    resid = rnd((N, Cc, H, W), dt, g)
+    c = rnd((N, Cc, H, W), dt, g)
+    sc, sh = torch.rand(Cc, generator=g) - 0.3, torch.randn(Cc, generator=g) * 0.3
+    ref = torch.nn.grad.conv2d_input((N, Cc, H, W), w.double(), dy.double(), stride=1, padding=1) + resid.double()
+    dx = torch.empty(N, H, W, Cc, dtype=dt, device="cuda")
+    kw = {}
+    if fused:
+        ref = ref * ((c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0)
+        sums = kn.new_stats(Cc)
+        cd = nhwc(c).to(dt).cuda()
+        kw = dict(mask=(cd, sc.cuda(), sh.cuda()), sums=sums)
+    kn.conv3x3_dgrad(d, nhwc(dy).to(dt).cuda(), nhwc(w).to(dt).cuda(), dx, resid=nhwc(resid).to(dt).cuda(), **kw)
+    torch.cuda.synchronize()
+    assert rel(dx.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt) * (2 if dt == torch.bfloat16 else 1)
+    if fused:
+        s = sums.sum(0).cpu()
+        gd = dx.double().cpu().reshape(-1, Cc)
+        assert torch.allclose(s[0], gd.sum(0), rtol=1e-5, atol=1e-4)
+        assert torch.allclose(s[1], (gd * cd.double().cpu().reshape(-1, Cc)).sum(0), rtol=1e-5, atol=1e-4)
