@@ -186,6 +186,7 @@ class Engine:
         self.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")  # off | t1 | targets | auto
         self.materialize_3x3 = os.environ.get("MSFWSI_MATERIALIZE_3X3", "1") != "0"
         self.materialize_wgrad = os.environ.get("MSFWSI_MATERIALIZE_WGRAD", "1") != "0"
+        self.materialize_1x1 = os.environ.get("MSFWSI_MATERIALIZE_1X1", "1") != "0"
         # halo-in-LDS 3x3 kernel: measured +14..25 % for the input gradient (natural 256-byte weight rows),
         # -7..+2 % for the forward (64-byte weight rows): on for dgrad, off for fwd
         self.halo3x3 = os.environ.get("MSFWSI_HALO3X3", "1") != "0"
@@ -278,7 +279,7 @@ class Engine:
         stats = kn.new_stats(K, 2, x.device) if bn is not None else None
         bias = getattr(op, "bias", None)
         xin, pro = x, (x_pro.scale, x_pro.shift) if x_pro is not None else None
-        if pro is not None and R * S > 1 and self.materialize_3x3:
+        if pro is not None and self.materialize_3x3 and (R * S > 1 or (self.materialize_1x1 and N * H * W >= 8192)):
             # a 3x3 gather reads every input element 9 times: normalising it once into a transient tensor and
             # letting the conv stage by pure LDS-DMA is cheaper than re-applying BatchNorm+ReLU per tap
             xin = torch.empty_like(x)
@@ -293,10 +294,18 @@ class Engine:
             u.st = self._bn_finalize(stats, N * d.P * d.Q, bn)
         return u
 
-    def _unit_wgrad(self, u: Unit, dc: torch.Tensor, grads: GradStore, dtype: torch.dtype):
+    def _normalised_operand(self, u: Unit) -> torch.Tensor:
+        """relu(bn(x)) of a unit's operand as a transient tensor (one streaming pass)"""
+        xm = torch.empty_like(u.x)
+        kn.bn_act(u.x, u.x_pro.scale, u.x_pro.shift, xm, relu=True)
+        return xm
+
+    def _unit_wgrad(self, u: Unit, dc: torch.Tensor, grads: GradStore, dtype: torch.dtype, x_mat=None):
         pro = (u.x_pro.scale, u.x_pro.shift) if u.x_pro is not None else None
         x = u.x
-        if pro is not None and self.materialize_wgrad and u.desc.N * u.desc.H * u.desc.W >= 8192:
+        if x_mat is not None:
+            x, pro = x_mat, None
+        elif pro is not None and self.materialize_wgrad and u.desc.N * u.desc.H * u.desc.W >= 8192:
             # normalise the operand once into a transient tensor: the weight-gradient kernel then stages both
             # tiles by LDS-DMA (3-stage pipeline) instead of register-staging with the BatchNorm prologue
             x = torch.empty_like(u.x)
@@ -456,11 +465,17 @@ class Engine:
 
     def _block_bwd(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype) -> torch.Tensor:
         last = rec.units[-1]
-        if last.c is None:  # dropped bottleneck conv3 output: same kernel, same operands -> same bits
+        last_xmat = None
+        if last.c is None:  # dropped bottleneck conv3 output: re-run the 1x1 conv from the kept c2 + statistics
             d = last.desc
             last.c = torch.empty(d.N, d.P, d.Q, d.K, dtype=dtype, device=rec.y_out.device)
-            kn.conv_fwd(d, last.x, self.weights.get(last.op.weight, dtype), last.c,
-                        pro=(last.x_pro.scale, last.x_pro.shift) if last.x_pro is not None else None)
+            pro = (last.x_pro.scale, last.x_pro.shift) if last.x_pro is not None else None
+            xin = last.x
+            if pro is not None and self.materialize_3x3 and self.materialize_1x1:
+                # the same normalised operand the forward used; shared with this conv's weight gradient below
+                last_xmat = self._normalised_operand(last)
+                xin, pro = last_xmat, None
+            kn.conv_fwd(d, xin, self.weights.get(last.op.weight, dtype), last.c, pro=pro)
         Cn = last.c.shape[-1]
         dev = last.c.device
         g = torch.empty_like(rec.y_out)
@@ -479,7 +494,8 @@ class Engine:
         cur = dc
         for i in range(len(rec.units) - 1, 0, -1):
             u, prev = rec.units[i], rec.units[i - 1]
-            self._unit_wgrad(u, cur, grads, dtype)
+            self._unit_wgrad(u, cur, grads, dtype, x_mat=last_xmat if u is last else None)
+            last_xmat = None
             s2 = kn.new_stats(prev.c.shape[-1], 2, dev)
             # ReLU gate of prev and its BatchNorm-backward sums are fused into the dgrad epilogue
             da = self._unit_dgrad(u, cur, dtype, mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2)
