@@ -26,6 +26,17 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = {"resnet18": 363.37e9, "resnet50": 848.8e9}  # SURVEY.md 8(d), fwd+bwd per tile pair
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of `family` from the committed PMC summary (separate rocprofv3 --pmc passes)"""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            fam = json.load(f)["families"].get(family)
+        return None if fam is None else round(fam["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def hub_stub():
     """random-init 'pretrained' weights: the GPU box has no network (data/weights are synthetic)"""
     from msf_wsi_amd.models import resnet as R
@@ -168,7 +179,7 @@ def main():
                 "achieved": round(tf if bound == "mfma" else gbs, 2),
                 "peak": PEAK_TFLOPS[args.dtype] if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                "frac": round(max(frac_m, frac_h), 4), "traffic": None,
+                "frac": round(max(frac_m, frac_h), 4), "traffic": pmc_traffic(dom),
                 "launches": s["launches"], "avg_launch_ms": round(1e3 * s["seconds"] / s["launches"], 4),
                 "alt": {"TFLOP/s": round(tf, 2), "frac_mfma": round(frac_m, 4), "GB/s": round(gbs, 1),
                         "frac_hbm": round(frac_h, 4)},

@@ -77,7 +77,14 @@ class PretrainStep:
             for gi in range(3):
                 kn.cast_bf16(self.flats.w[gi], self.flats.w16[gi])
         self.grads = _FlatGradStore(self.flats)
-        self.reducer = GradReducer(self.flats, process_group)
+        # gradients travel on their OWN communicator: the multi-GB all-reduce of the head group must not sit in
+        # front of the latency-bound SyncBN exchanges of the encoder backward that is still running
+        grad_group = process_group
+        if world_size(process_group) > 1 and process_group is None:
+            import torch.distributed as dist
+
+            grad_group = dist.new_group(backend=dist.get_backend())
+        self.reducer = GradReducer(self.flats, grad_group)
         # GradScaler state, resident on the device (the reference enables it whenever --amp, also for bf16)
         self.use_scaler = (dtype != torch.float32) if use_scaler is None else bool(use_scaler)
         self.scale = torch.full((1,), init_scale if self.use_scaler else 1.0, dtype=torch.float32, device=dev)
