@@ -134,3 +134,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// XCD-aware workgroup renumbering (MI355X: 8 XCDs, each with a private L2; consecutive workgroup ids are dealt
+// round-robin over the XCDs).  Maps the hardware id to a logical id such that each XCD works on one CONTIGUOUS
+// range of logical ids, so that workgroups sharing operand rows (the n-tiles of one m-tile, the tiles of one pixel
+// split) fill the same L2 instead of eight.  Bijective for every grid size; affects speed only.
+__device__ __forceinline__ unsigned xcd_remap(unsigned hw_id, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u;
+    const unsigned xcd = hw_id & 7u, idx = hw_id >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const C3Params prm) {
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int tile_n = blockIdx.x % prm.ntile_n;
-    const int tile_mi = blockIdx.x / prm.ntile_n;
+    const unsigned wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wgid % prm.ntile_n;
+    const int tile_mi = wgid / prm.ntile_n;
     const int img = tile_mi / prm.tiles_per_img;
     const int p0 = (tile_mi - img * prm.tiles_per_img) * BM;  // first output pixel (raster index in the image)
     const int n0 = tile_n * BN;

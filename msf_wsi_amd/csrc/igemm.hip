@@ -146,8 +146,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int tile_n = blockIdx.x % prm.ntile_n;
-    const int tile_m = blockIdx.x / prm.ntile_n;
+    const unsigned wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wgid % prm.ntile_n;
+    const int tile_m = wgid / prm.ntile_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 

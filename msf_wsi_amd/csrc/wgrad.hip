@@ -125,10 +125,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
     const int wi = wave % WI, wj = wave / WI;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int tile_i = blockIdx.x % prm.ntile_i;
-    const int tile_j = blockIdx.x / prm.ntile_i;
+    // tiles of one pixel split share their dY / activation rows: keep them on one XCD
+    const unsigned wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const unsigned tile_lin = wgid % gridDim.x, split = wgid / gridDim.x;
+    const int tile_i = tile_lin % prm.ntile_i;
+    const int tile_j = tile_lin / prm.ntile_i;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
-    const int mbeg = blockIdx.y * prm.rows_per_split;
+    const int mbeg = split * prm.rows_per_split;
     const int mend = min(prm.M, mbeg + prm.rows_per_split);
 
     const T* __restrict__ x = reinterpret_cast<const T*>(prm.x);
