@@ -1,0 +1,113 @@
+"""GPU: the reference's own wrapping and loop statements around the drop-in module
+(tools/ssl_train.py:160-170 SyncBatchNorm + DDP, :441-474 autocast + GradScaler + backward + step)."""
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from helpers import LR, build_product, reference_loop_loss
+
+pytestmark = pytest.mark.gpu
+B, SIZE, K = 4, 64, 16
+
+
+def _batch(seed=7):
+    from oracle import msfwsi_oracle as orc
+
+    return orc.synthetic_batch(B, SIZE, K, seed)
+
+
+def test_reference_amp_loop_bf16(hip_lib):
+    """`--amp --bf16` path: autocast(bf16) + GradScaler around the module, three iterations"""
+    model = build_product("resnet18").cuda().train()
+    named = list(model.named_parameters())
+    groups = [[p for n, p in named if n.startswith(pre)] for pre in ("context_", "target_", "inter_")]
+    opt = torch.optim.Adam([{"params": g, "lr": 5e-4} for g in groups], lr=5e-4)
+    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    (c1, c2), (t1, t2), idx = _batch()
+    c1, c2, t1, t2 = c1.cuda(), c2.cuda(), t1.cuda(), t2.cuda()
+    losses = []
+    for _ in range(3):
+        with torch.autocast("cuda", enabled=True, dtype=torch.bfloat16):
+            outputs = model((c1, t1), (c2, t2), idx)
+            loss, _ = reference_loop_loss(outputs)
+        assert outputs[0][0][0].dtype == torch.bfloat16
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.item())
+    assert all(torch.isfinite(torch.tensor(losses))) and scaler.get_scale() == 65536.0
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for _, p in named)
+    assert losses[2] < losses[0]  # three Adam steps on a fixed batch reduce the loss
+
+
+def _ddp_worker(rank, world, port, ret):
+    from msf_wsi_amd.dist import shard_range
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        model = build_product("resnet18")
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)  # ssl_train.py:160
+        model.cuda(0)
+        ddp = nn.parallel.DistributedDataParallel(model, device_ids=[0])  # ssl_train.py:170
+        named = list(ddp.module.named_parameters())
+        groups = [[p for n, p in named if n.startswith(pre)] for pre in ("context_", "target_", "inter_")]
+        lr = LR * (B ** 0.5) / (32 ** 0.5)
+        opt = torch.optim.Adam([{"params": g, "lr": lr} for g in groups], lr=lr)
+        (c1, c2), (t1, t2), idx = _batch()
+        lo, hi = shard_range(B, world, rank)
+        ddp.train()
+        outputs = ddp((c1[lo:hi].cuda(), t1[lo * K:hi * K].cuda()), (c2[lo:hi].cuda(), t2[lo * K:hi * K].cuda()),
+                      [idx[0][lo:hi], idx[1][lo:hi]])
+        loss, _ = reference_loop_loss(outputs)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        lsum = torch.tensor([loss.item()], dtype=torch.float64)
+        dist.all_reduce(lsum)
+        if rank == 0:
+            ret["loss"] = float(lsum) / world
+            ret["sd"] = {k: v.detach().cpu() for k, v in ddp.state_dict().items()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_ddp_wrapping_matches_single_process(hip_lib):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, port, ret), nprocs=2, join=True)
+
+    model = build_product("resnet18").cuda().train()
+    named = list(model.named_parameters())
+    groups = [[p for n, p in named if n.startswith(pre)] for pre in ("context_", "target_", "inter_")]
+    lr = LR * (B ** 0.5) / (32 ** 0.5)
+    opt = torch.optim.Adam([{"params": g, "lr": lr} for g in groups], lr=lr)
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    (c1, c2), (t1, t2), idx = _batch()
+    outputs = model((c1.cuda(), t1.cuda()), (c2.cuda(), t2.cuda()), idx)
+    loss, _ = reference_loop_loss(outputs)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert abs(ret["loss"] - loss.item()) <= 1e-4 * max(1.0, abs(loss.item()))
+    sd2 = ret["sd"]
+    assert all(k.startswith("module.") for k in sd2)  # DDP prefix, as saved by the reference (ssl_train.py:380)
+    for k, v in model.state_dict().items():
+        a, b = sd2["module." + k].double(), v.detach().cpu().double()
+        if k.endswith("num_batches_tracked"):
+            assert int(a) == int(b) == 2
+        elif "running_" in k:
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-5), k
+        else:
+            d = (a - b).abs()
+            assert float((d > 0.5 * lr).double().mean()) <= 0.02 or int((d > 0.5 * lr).sum()) <= 2, k
