@@ -12,8 +12,8 @@
  *   - return value: 0 ok; <0 invalid argument (-1) / unsupported configuration (-2); >0 a hipError_t.
  *   - re-entrant and stateless: safe to call from the forward thread and autograd's backward thread.
  *   - activations are NHWC ("channels last"), viewed as [M = N*H*W][C]; dtype selects the storage type
- *     of activations AND weights (MSFWSI_DT_F32 exact-fp32 MFMA path, MSFWSI_DT_BF16 bf16 MFMA with fp32
- *     accumulation); per-channel vectors, statistics and weight gradients are always fp32 / fp64.
+ *     of activations AND weights (MSFWSI_DT_F32 exact-fp32 MFMA path, MSFWSI_DT_BF16 / MSFWSI_DT_F16 16-bit
+ *     MFMA with fp32 accumulation); per-channel vectors, statistics and weight gradients are always fp32 / fp64.
  *   - channel counts must be multiples of one 16-byte chunk (4 fp32 / 8 bf16 elements).
  */
 #ifndef MSFWSI_HIP_H
@@ -25,6 +25,7 @@ extern "C" {
 
 #define MSFWSI_DT_F32 0
 #define MSFWSI_DT_BF16 1
+#define MSFWSI_DT_F16 2
 
 /* Geometry of one convolution (a Linear layer is R=S=1, H=W=1, N=rows). */
 typedef struct msfwsi_conv_desc {
@@ -165,12 +166,14 @@ int msfwsi_scaler_update(float* scale, int* growth_tracker, const float* found, 
                          float backoff_factor, int growth_interval, void* stream);
 
 /* One Adam step over a flat fp32 parameter group (torch.optim.Adam defaults, tools/ssl_train.py:309,473);
- * grads are divided by *loss_scale, the step is skipped when *found > 0; p_bf16 != NULL also refreshes
- * the bf16 compute copy. */
+ * grads are divided by *loss_scale, the step is skipped when *found > 0; p_lowp != NULL also refreshes
+ * the 16-bit compute copy (lowp_dtype = MSFWSI_DT_BF16 or MSFWSI_DT_F16). */
 int msfwsi_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                float eps, long step, const float* loss_scale, const float* found, void* p_bf16, void* stream);
+                float eps, long step, const float* loss_scale, const float* found, void* p_lowp, int lowp_dtype,
+                void* stream);
 
-int msfwsi_cast_bf16(const float* src, void* dst, long n, void* stream);
+/* fp32 -> bf16 / fp16 compute copy of a flat weight buffer (dtype = MSFWSI_DT_BF16 or MSFWSI_DT_F16) */
+int msfwsi_cast_lowp(int dtype, const float* src, void* dst, long n, void* stream);
 int msfwsi_pad_cast(int dtype, const float* src, void* dst, long rows, int C, int CP, void* stream);
 int msfwsi_unpad_add(const float* src, float* dst, long rows, int C, int CP, void* stream);
 

@@ -15,6 +15,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DT_F32 = 0
 DT_BF16 = 1
+DT_F16 = 2
 
 
 class ConvDesc(C.Structure):
@@ -53,8 +54,8 @@ SIGNATURES = {
     "msfwsi_cosine_loss": [_i, _vp, _vp, _l, _i, _f, _vp, _f, _vp, _vp, _vp],
     "msfwsi_nonfinite_check": [_vp, _l, _vp, _vp],
     "msfwsi_scaler_update": [_vp, _vp, _vp, _f, _f, _i, _vp],
-    "msfwsi_adam": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _l, _vp, _vp, _vp, _vp],
-    "msfwsi_cast_bf16": [_vp, _vp, _l, _vp],
+    "msfwsi_adam": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _l, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_cast_lowp": [_i, _vp, _vp, _l, _vp],
     "msfwsi_pad_cast": [_i, _vp, _vp, _l, _i, _i, _vp],
     "msfwsi_unpad_add": [_vp, _vp, _l, _i, _i, _vp],
     "msfwsi_set_tuning": [_i, _l],

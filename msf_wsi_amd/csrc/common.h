@@ -6,6 +6,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -13,6 +14,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define MSFWSI_DT_F32 0
 #define MSFWSI_DT_BF16 1
+#define MSFWSI_DT_F16 2
 
 // return codes of the C ABI: 0 ok, <0 invalid argument class, >0 hipError_t
 #define MSFWSI_OK 0
@@ -44,6 +46,29 @@ struct ElemTraits<__bf16> {
     static constexpr int VEC = 8;
     static constexpr int BK = 32;
 };
+template <>
+struct ElemTraits<_Float16> {
+    static constexpr int VEC = 8;
+    static constexpr int BK = 32;
+};
+
+static inline bool msfwsi_dtype_ok(int dt) { return dt == MSFWSI_DT_F32 || dt == MSFWSI_DT_BF16 || dt == MSFWSI_DT_F16; }
+static inline int msfwsi_vec_of(int dt) { return dt == MSFWSI_DT_F32 ? 4 : 8; }
+
+// run `...` with T bound to the storage type selected by `dtype` (the statement may contain commas)
+#define MSFWSI_WITH_T(dtype, ...)                \
+    do {                                         \
+        if ((dtype) == MSFWSI_DT_BF16) {         \
+            typedef __bf16 T;                    \
+            __VA_ARGS__;                         \
+        } else if ((dtype) == MSFWSI_DT_F16) {   \
+            typedef _Float16 T;                  \
+            __VA_ARGS__;                         \
+        } else {                                 \
+            typedef float T;                     \
+            __VA_ARGS__;                         \
+        }                                        \
+    } while (0)
 
 __device__ __forceinline__ float bf16_bits_to_float(unsigned short b) {
     return __uint_as_float(((unsigned)b) << 16);
@@ -74,8 +99,22 @@ __device__ __forceinline__ void unpack16<__bf16>(const uint4& v, float* f) {
     f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
+template <>
+__device__ __forceinline__ void unpack16<_Float16>(const uint4& v, float* f) {
+    const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+}
+
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     return (unsigned)float_to_bf16_bits(lo) | ((unsigned)float_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ unsigned short float_to_f16_bits(float f) {
+    return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+__device__ __forceinline__ unsigned pack2_f16(float lo, float hi) {
+    return (unsigned)float_to_f16_bits(lo) | ((unsigned)float_to_f16_bits(hi) << 16);
 }
 
 template <typename T>
@@ -91,6 +130,14 @@ __device__ __forceinline__ uint4 pack16<__bf16>(const float* f) {
                       pack2_bf16(f[6], f[7]));
 }
 
+template <>
+__device__ __forceinline__ uint4 pack16<_Float16>(const float* f) {
+    f16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (_Float16)f[e];
+    return __builtin_bit_cast(uint4, h);
+}
+
 // value of one element after a round trip through the storage type T
 template <typename T>
 __device__ __forceinline__ float round_to(float f);
@@ -103,6 +150,11 @@ __device__ __forceinline__ float round_to<__bf16>(float f) {
     return bf16_bits_to_float(float_to_bf16_bits(f));
 }
 
+template <>
+__device__ __forceinline__ float round_to<_Float16>(float f) {
+    return (float)(_Float16)f;
+}
+
 template <typename T>
 __device__ __forceinline__ float load_elem(const T* p, size_t i);
 template <>
@@ -113,6 +165,10 @@ template <>
 __device__ __forceinline__ float load_elem<__bf16>(const __bf16* p, size_t i) {
     return bf16_bits_to_float(reinterpret_cast<const unsigned short*>(p)[i]);
 }
+template <>
+__device__ __forceinline__ float load_elem<_Float16>(const _Float16* p, size_t i) {
+    return (float)p[i];
+}
 template <typename T>
 __device__ __forceinline__ void store_elem(T* p, size_t i, float v);
 template <>
@@ -122,6 +178,43 @@ __device__ __forceinline__ void store_elem<float>(float* p, size_t i, float v) {
 template <>
 __device__ __forceinline__ void store_elem<__bf16>(__bf16* p, size_t i, float v) {
     reinterpret_cast<unsigned short*>(p)[i] = float_to_bf16_bits(v);
+}
+
+template <>
+__device__ __forceinline__ void store_elem<_Float16>(_Float16* p, size_t i, float v) {
+    p[i] = (_Float16)v;
+}
+
+// MFMA fragment types and the 32x32 step per storage type (16-bit: 32x32x16, fp32: 4 x 32x32x2 exact fp32)
+template <typename T>
+struct MmaFrag;
+template <>
+struct MmaFrag<float> {
+    typedef f32x4 type;
+};
+template <>
+struct MmaFrag<__bf16> {
+    typedef bf16x8 type;
+};
+template <>
+struct MmaFrag<_Float16> {
+    typedef f16x8 type;
+};
+template <typename T>
+__device__ __forceinline__ void mma32(f32x16& acc, const typename MmaFrag<T>::type& a, const typename MmaFrag<T>::type& b);
+template <>
+__device__ __forceinline__ void mma32<__bf16>(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma32<_Float16>(f32x16& acc, const f16x8& a, const f16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma32<float>(f32x16& acc, const f32x4& a, const f32x4& b) {
+    // lane half h supplies k = 4h+e to step e on BOTH operands: a consistent k permutation
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -36,15 +36,7 @@ struct C3Params {
 };
 
 template <typename T>
-struct Frag3;
-template <>
-struct Frag3<float> {
-    typedef f32x4 type;
-};
-template <>
-struct Frag3<__bf16> {
-    typedef bf16x8 type;
-};
+using Frag3 = MmaFrag<T>;
 
 __device__ __forceinline__ void dma16c(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -238,13 +230,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const C3Params prm) {
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
-                    if constexpr (sizeof(T) == 2) {
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[tn][e], xf[tm][e], acc[tn][tm], 0, 0, 0);
-                    }
+                    mma32<T>(acc[tn][tm], wf[tn], xf[tm]);
                 }
         }
     };
@@ -401,7 +387,8 @@ int launch_c3(C3Params& prm, hipStream_t stream) {
 // 1 if the halo kernel handles this geometry (3x3, stride 1, pad 1, 14 <= W <= 56, channel slabs of 64 bytes)
 extern "C" int msfwsi_conv3x3_supported(const msfwsi_conv_desc* d) {
     if (d == nullptr) return 0;
-    const int bk = d->dtype == MSFWSI_DT_BF16 ? 32 : 16;
+    if (!msfwsi_dtype_ok(d->dtype)) return 0;
+    const int bk = d->dtype == MSFWSI_DT_F32 ? 16 : 32;
     if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1) return 0;
     if (d->W > 56 || d->H * d->W < 128) return 0;
     if (d->C % bk != 0 || d->K % bk != 0) return 0;
@@ -417,9 +404,8 @@ extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, cons
     prm.src = x; prm.wgt = w; prm.out = y; prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C; prm.Nout = d->K;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->dtype == MSFWSI_DT_BF16)
-        return d->K <= 64 ? launch_c3<__bf16, 64, false>(prm, st) : launch_c3<__bf16, 128, false>(prm, st);
-    return d->K <= 64 ? launch_c3<float, 64, false>(prm, st) : launch_c3<float, 128, false>(prm, st);
+    MSFWSI_WITH_T(d->dtype, return d->K <= 64 ? launch_c3<T, 64, false>(prm, st) : launch_c3<T, 128, false>(prm, st));
+    return MSFWSI_EINVAL;
 }
 
 extern "C" int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
@@ -436,7 +422,6 @@ extern "C" int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, c
     prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->K; prm.Nout = d->C;  // stride 1: same H, W
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->dtype == MSFWSI_DT_BF16)
-        return d->C <= 64 ? launch_c3<__bf16, 64, true>(prm, st) : launch_c3<__bf16, 128, true>(prm, st);
-    return d->C <= 64 ? launch_c3<float, 64, true>(prm, st) : launch_c3<float, 128, true>(prm, st);
+    MSFWSI_WITH_T(d->dtype, return d->C <= 64 ? launch_c3<T, 64, true>(prm, st) : launch_c3<T, 128, true>(prm, st));
+    return MSFWSI_EINVAL;
 }

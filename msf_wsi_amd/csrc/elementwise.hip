@@ -587,8 +587,8 @@ inline unsigned stream_grid(long total) {
     return (unsigned)b;
 }
 
-inline bool dtype_ok(int dt) { return dt == MSFWSI_DT_F32 || dt == MSFWSI_DT_BF16; }
-inline int vec_of(int dt) { return dt == MSFWSI_DT_BF16 ? 8 : 4; }
+inline bool dtype_ok(int dt) { return msfwsi_dtype_ok(dt); }
+inline int vec_of(int dt) { return msfwsi_vec_of(dt); }
 
 }  // namespace
 
@@ -599,12 +599,8 @@ extern "C" int msfwsi_nchw_to_nhwc(int dtype, const float* x, void* y, int N, in
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && x && y && N > 0 && C > 0 && H > 0 && W > 0 && CP >= C);
     MSFWSI_CHECK_ARG(CP % vec_of(dtype) == 0);
     const long total = (long)N * H * W * (CP / vec_of(dtype));
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream), x,
-                           (__bf16*)y, N, C, H * W, CP);
-    else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream), x,
-                           (float*)y, N, C, H * W, CP);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream), x,
+                           (T*)y, N, C, H * W, CP));
     return msfwsi_launch_status();
 }
 
@@ -632,14 +628,9 @@ extern "C" int msfwsi_bn_act(int dtype, const void* c, const float* scale, const
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && c && scale && shift && out && M > 0 && C > 0 && C % vec_of(dtype) == 0);
     MSFWSI_CHECK_ARG((id_scale == nullptr) == (id_shift == nullptr));
     const long total = M * (C / vec_of(dtype));
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(bn_act_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const __bf16*)c, scale, shift, (const __bf16*)ident, id_scale, id_shift, relu, (__bf16*)out,
-                           M, C);
-    else
-        hipLaunchKernelGGL(bn_act_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const float*)c, scale, shift, (const float*)ident, id_scale, id_shift, relu, (float*)out, M,
-                           C);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(bn_act_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const T*)c, scale, shift, (const T*)ident, id_scale, id_shift, relu, (T*)out,
+                           M, C));
     return msfwsi_launch_status();
 }
 
@@ -649,12 +640,8 @@ extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scal
     MSFWSI_CHECK_ARG(C % vec_of(dtype) == 0);
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     const long total = (long)N * P * Q * (C / vec_of(dtype));
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(stem_pool_fwd_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const __bf16*)c0, scale, shift, (__bf16*)out, argmax, N, H, W, C, P, Q);
-    else
-        hipLaunchKernelGGL(stem_pool_fwd_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const float*)c0, scale, shift, (float*)out, argmax, N, H, W, C, P, Q);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_fwd_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const T*)c0, scale, shift, (T*)out, argmax, N, H, W, C, P, Q));
     return msfwsi_launch_status();
 }
 
@@ -667,14 +654,9 @@ extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned ch
     const int vec = vec_of(dtype);
     ColGrid g = make_col_grid((long)N * H * W, C, vec, 2048);
     const size_t lds = (size_t)kThreads * 2 * vec * sizeof(float);
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(stem_pool_bwd_kernel<__bf16>, g.grid, dim3(kThreads), lds, ST(stream), (const __bf16*)dp,
-                           argmax, (const __bf16*)c0, scale, shift, (__bf16*)g0, sums, nshard, N, H, W, C, P, Q, g.cw,
-                           g.nrl, g.rows_per_block);
-    else
-        hipLaunchKernelGGL(stem_pool_bwd_kernel<float>, g.grid, dim3(kThreads), lds, ST(stream), (const float*)dp,
-                           argmax, (const float*)c0, scale, shift, (float*)g0, sums, nshard, N, H, W, C, P, Q, g.cw,
-                           g.nrl, g.rows_per_block);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_kernel<T>, g.grid, dim3(kThreads), lds, ST(stream), (const T*)dp,
+                           argmax, (const T*)c0, scale, shift, (T*)g0, sums, nshard, N, H, W, C, P, Q, g.cw,
+                           g.nrl, g.rows_per_block));
     return msfwsi_launch_status();
 }
 
@@ -688,12 +670,8 @@ extern "C" int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW
     if (nrl > HW) nrl = HW;
     const dim3 grid((unsigned)((cpr + cw - 1) / cw), (unsigned)N);
     const size_t lds = (size_t)kThreads * vec * sizeof(float);
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(gap_fwd_kernel<__bf16>, grid, dim3(kThreads), lds, ST(stream), (const __bf16*)y,
-                           (__bf16*)out, N, HW, C, cw, nrl);
-    else
-        hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(kThreads), lds, ST(stream), (const float*)y,
-                           (float*)out, N, HW, C, cw, nrl);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(gap_fwd_kernel<T>, grid, dim3(kThreads), lds, ST(stream), (const T*)y,
+                           (T*)out, N, HW, C, cw, nrl));
     return msfwsi_launch_status();
 }
 
@@ -705,14 +683,9 @@ extern "C" int msfwsi_block_end_bwd(int dtype, const void* dy, const void* y, co
     const int vec = vec_of(dtype);
     ColGrid cg = make_col_grid(M, C, vec, 2048);
     const size_t lds = (size_t)kThreads * 3 * vec * sizeof(float);
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(block_end_bwd_kernel<__bf16>, cg.grid, dim3(kThreads), lds, ST(stream), (const __bf16*)dy,
-                           (const __bf16*)y, (const __bf16*)gapg, gap_scale, (const __bf16*)c_main,
-                           (const __bf16*)c_ds, (__bf16*)g, sums, nshard, M, HW, C, cg.cw, cg.nrl, cg.rows_per_block);
-    else
-        hipLaunchKernelGGL(block_end_bwd_kernel<float>, cg.grid, dim3(kThreads), lds, ST(stream), (const float*)dy,
-                           (const float*)y, (const float*)gapg, gap_scale, (const float*)c_main, (const float*)c_ds,
-                           (float*)g, sums, nshard, M, HW, C, cg.cw, cg.nrl, cg.rows_per_block);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(block_end_bwd_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)dy,
+                           (const T*)y, (const T*)gapg, gap_scale, (const T*)c_main,
+                           (const T*)c_ds, (T*)g, sums, nshard, M, HW, C, cg.cw, cg.nrl, cg.rows_per_block));
     return msfwsi_launch_status();
 }
 
@@ -725,14 +698,9 @@ extern "C" int msfwsi_act_bwd_reduce(int dtype, const void* da, const void* c, c
     const int vec = vec_of(dtype);
     ColGrid cg = make_col_grid(M, C, vec, 2048);
     const size_t lds = (size_t)kThreads * 2 * vec * sizeof(float);
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(act_bwd_reduce_kernel<__bf16>, cg.grid, dim3(kThreads), lds, ST(stream), (const __bf16*)da,
-                           (const __bf16*)c, scale, shift, (__bf16*)g, sums, nshard, M, C, cg.cw, cg.nrl,
-                           cg.rows_per_block);
-    else
-        hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, cg.grid, dim3(kThreads), lds, ST(stream), (const float*)da,
-                           (const float*)c, scale, shift, (float*)g, sums, nshard, M, C, cg.cw, cg.nrl,
-                           cg.rows_per_block);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(act_bwd_reduce_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)da,
+                           (const T*)c, scale, shift, (T*)g, sums, nshard, M, C, cg.cw, cg.nrl,
+                           cg.rows_per_block));
     return msfwsi_launch_status();
 }
 
@@ -750,12 +718,8 @@ extern "C" int msfwsi_bn_bwd_apply(int dtype, const void* g, const void* c, cons
                                    const float* k3, void* dc, long M, int C, void* stream) {
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && g && c && k1 && k2 && k3 && dc && M > 0 && C % vec_of(dtype) == 0);
     const long total = M * (C / vec_of(dtype));
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const __bf16*)g, (const __bf16*)c, k1, k2, k3, (__bf16*)dc, M, C);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const float*)g, (const float*)c, k1, k2, k3, (float*)dc, M, C);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const T*)g, (const T*)c, k1, k2, k3, (T*)dc, M, C));
     return msfwsi_launch_status();
 }
 
@@ -764,12 +728,8 @@ extern "C" int msfwsi_colsum(int dtype, const void* x, double* sums, long M, int
     const int vec = vec_of(dtype);
     ColGrid cg = make_col_grid(M, C, vec, 1024);
     const size_t lds = (size_t)kThreads * vec * sizeof(float);
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(colsum_kernel<__bf16>, cg.grid, dim3(kThreads), lds, ST(stream), (const __bf16*)x, sums, M,
-                           C, cg.cw, cg.nrl, cg.rows_per_block);
-    else
-        hipLaunchKernelGGL(colsum_kernel<float>, cg.grid, dim3(kThreads), lds, ST(stream), (const float*)x, sums, M, C,
-                           cg.cw, cg.nrl, cg.rows_per_block);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)x, sums, M,
+                           C, cg.cw, cg.nrl, cg.rows_per_block));
     return msfwsi_launch_status();
 }
 
@@ -783,12 +743,8 @@ extern "C" int msfwsi_rows_permute(int dtype, const void* in, const long* idx, v
                                    int scatter, int accumulate, void* stream) {
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && in && idx && out && B > 0 && K > 0 && C % vec_of(dtype) == 0);
     const long total = (long)B * K * (C / vec_of(dtype));
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(rows_permute_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const __bf16*)in, idx, (__bf16*)out, B, K, C, scatter, accumulate);
-    else
-        hipLaunchKernelGGL(rows_permute_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const float*)in, idx, (float*)out, B, K, C, scatter, accumulate);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(rows_permute_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const T*)in, idx, (T*)out, B, K, C, scatter, accumulate));
     return msfwsi_launch_status();
 }
 
@@ -798,11 +754,7 @@ extern "C" int msfwsi_copy2d(int dtype, const void* src, long src_ld, void* dst,
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && src && dst && rows > 0 && cols > 0 && cols % vec == 0);
     MSFWSI_CHECK_ARG(src_ld % vec == 0 && dst_ld % vec == 0);
     const long total = rows * (cols / vec);
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(copy2d_kernel<__bf16>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const __bf16*)src, src_ld, (__bf16*)dst, dst_ld, rows, cols, accumulate);
-    else
-        hipLaunchKernelGGL(copy2d_kernel<float>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
-                           (const float*)src, src_ld, (float*)dst, dst_ld, rows, cols, accumulate);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(copy2d_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
+                           (const T*)src, src_ld, (T*)dst, dst_ld, rows, cols, accumulate));
     return msfwsi_launch_status();
 }

@@ -55,28 +55,12 @@ struct IgemmParams {
 };
 
 template <typename T>
-struct Frag;
-template <>
-struct Frag<float> {
-    typedef f32x4 type;
-};
-template <>
-struct Frag<__bf16> {
-    typedef bf16x8 type;
-};
+using Frag = MmaFrag<T>;
 
 template <typename T>
-__device__ __forceinline__ void mma_step(f32x16& acc, const typename Frag<T>::type& w,
-                                         const typename Frag<T>::type& x);
-template <>
-__device__ __forceinline__ void mma_step<__bf16>(f32x16& acc, const bf16x8& w, const bf16x8& x) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma_step<float>(f32x16& acc, const f32x4& w, const f32x4& x) {
-    // lane half h supplies k = 4h+e to step e on BOTH operands: a consistent k permutation
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+__device__ __forceinline__ void mma_step(f32x16& acc, const typename MmaFrag<T>::type& w,
+                                         const typename MmaFrag<T>::type& x) {
+    mma32<T>(acc, w, x);
 }
 
 // 16 bytes global -> LDS without touching VGPRs; lds_wave_base is wave-uniform, lane l lands at base + 16*l
@@ -675,8 +659,8 @@ int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
 
 int check_desc(const msfwsi_conv_desc* d) {
     if (d == nullptr) return MSFWSI_EINVAL;
-    if (d->dtype != MSFWSI_DT_F32 && d->dtype != MSFWSI_DT_BF16) return MSFWSI_EUNSUPPORTED;
-    const int vec = d->dtype == MSFWSI_DT_BF16 ? 8 : 4;
+    if (!msfwsi_dtype_ok(d->dtype)) return MSFWSI_EUNSUPPORTED;
+    const int vec = msfwsi_vec_of(d->dtype);
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->P <= 0 || d->Q <= 0) return MSFWSI_EINVAL;
     if (d->R <= 0 || d->S <= 0 || d->pad < 0) return MSFWSI_EINVAL;
     if (d->stride != 1 && d->stride != 2) return MSFWSI_EUNSUPPORTED;
@@ -721,9 +705,8 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
     prm.Ktot = d->R * d->S * d->C;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool pro = pro_scale != nullptr;
-    if (d->dtype == MSFWSI_DT_BF16)
-        return pro ? dispatch_tile<__bf16, false, true>(prm, st) : dispatch_tile<__bf16, false, false>(prm, st);
-    return pro ? dispatch_tile<float, false, true>(prm, st) : dispatch_tile<float, false, false>(prm, st);
+    MSFWSI_WITH_T(d->dtype, return pro ? dispatch_tile<T, false, true>(prm, st) : dispatch_tile<T, false, false>(prm, st));
+    return MSFWSI_EINVAL;
 }
 
 extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
@@ -747,6 +730,6 @@ extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, cons
     prm.M = d->N * d->H * d->W;
     prm.Ktot = d->R * d->S * d->K;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d->dtype == MSFWSI_DT_BF16) return dispatch_tile<__bf16, true, false>(prm, st);
-    return dispatch_tile<float, true, false>(prm, st);
+    MSFWSI_WITH_T(d->dtype, return dispatch_tile<T, true, false>(prm, st));
+    return MSFWSI_EINVAL;
 }

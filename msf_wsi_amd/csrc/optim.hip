@@ -93,7 +93,7 @@ __global__ void scaler_update_kernel(float* scale, int* growth_tracker, const fl
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float beta1, float beta2, float eps, float step_size,
                             float bc2_sqrt, const float* __restrict__ loss_scale, const float* __restrict__ found,
-                            unsigned short* __restrict__ p_bf16) {
+                            unsigned short* __restrict__ p_bf16, int lowp_f16) {
     if (found != nullptr && *found > 0.f) return;  // GradScaler.step skips the update
     const float inv_scale = loss_scale != nullptr ? 1.f / *loss_scale : 1.f;
     const long n4 = n >> 2;
@@ -119,8 +119,13 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         reinterpret_cast<float4*>(v)[i] = vv;
         if (p_bf16 != nullptr) {
             uint2 o;
-            o.x = pack2_bf16(pp[0], pp[1]);
-            o.y = pack2_bf16(pp[2], pp[3]);
+            if (lowp_f16) {
+                o.x = pack2_f16(pp[0], pp[1]);
+                o.y = pack2_f16(pp[2], pp[3]);
+            } else {
+                o.x = pack2_bf16(pp[0], pp[1]);
+                o.y = pack2_bf16(pp[2], pp[3]);
+            }
             reinterpret_cast<uint2*>(p_bf16)[i] = o;
         }
     }
@@ -131,20 +136,28 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         v[i] = v[i] * beta2 + (1.f - beta2) * gr * gr;
         const float denom = sqrtf(v[i]) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (m[i] / denom);
-        if (p_bf16 != nullptr) p_bf16[i] = float_to_bf16_bits(p[i]);
+        if (p_bf16 != nullptr) p_bf16[i] = lowp_f16 ? float_to_f16_bits(p[i]) : float_to_bf16_bits(p[i]);
     }
 }
 
-__global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n) {
+__global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n, int f16) {
     const long n4 = n >> 2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(src)[i];
         uint2 o;
-        o.x = pack2_bf16(v.x, v.y);
-        o.y = pack2_bf16(v.z, v.w);
+        if (f16) {
+            o.x = pack2_f16(v.x, v.y);
+            o.y = pack2_f16(v.z, v.w);
+        } else {
+            o.x = pack2_bf16(v.x, v.y);
+            o.y = pack2_bf16(v.z, v.w);
+        }
         reinterpret_cast<uint2*>(dst)[i] = o;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[n4 * 4 + threadIdx.x] = float_to_bf16_bits(src[n4 * 4 + threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float x = src[n4 * 4 + threadIdx.x];
+        dst[n4 * 4 + threadIdx.x] = f16 ? float_to_f16_bits(x) : float_to_bf16_bits(x);
+    }
 }
 
 // [rows][C] fp32 -> [rows][CP] storage type, zero padded (stem weights: C=3 -> CP=8 / 4)
@@ -180,15 +193,11 @@ inline unsigned sgrid(long total, int threads) {
 
 extern "C" int msfwsi_cosine_loss(int dtype, const void* p, const void* z, long rows, int d, float coef,
                                   const float* loss_scale, float eps, double* loss_accum, void* dp, void* stream) {
-    MSFWSI_CHECK_ARG((dtype == MSFWSI_DT_F32 || dtype == MSFWSI_DT_BF16) && p && z && rows > 0 && d > 0);
-    MSFWSI_CHECK_ARG(d % (dtype == MSFWSI_DT_BF16 ? 8 : 4) == 0);
+    MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && p && z && rows > 0 && d > 0);
+    MSFWSI_CHECK_ARG(d % msfwsi_vec_of(dtype) == 0);
     const long blocks = (rows + 3) / 4;
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(cosine_loss_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, ST(stream),
-                           (const __bf16*)p, (const __bf16*)z, rows, d, coef, loss_scale, eps, loss_accum, (__bf16*)dp);
-    else
-        hipLaunchKernelGGL(cosine_loss_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ST(stream), (const float*)p,
-                           (const float*)z, rows, d, coef, loss_scale, eps, loss_accum, (float*)dp);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(cosine_loss_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, ST(stream),
+                           (const T*)p, (const T*)z, rows, d, coef, loss_scale, eps, loss_accum, (T*)dp));
     return msfwsi_launch_status();
 }
 
@@ -207,33 +216,32 @@ extern "C" int msfwsi_scaler_update(float* scale, int* growth_tracker, const flo
 }
 
 extern "C" int msfwsi_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                           float eps, long step, const float* loss_scale, const float* found, void* p_bf16,
-                           void* stream) {
+                           float eps, long step, const float* loss_scale, const float* found, void* p_lowp,
+                           int lowp_dtype, void* stream) {
     MSFWSI_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+    MSFWSI_CHECK_ARG(p_lowp == nullptr || lowp_dtype == MSFWSI_DT_BF16 || lowp_dtype == MSFWSI_DT_F16);
+    void* p_bf16 = p_lowp;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_kernel, dim3(sgrid(n / 4 + 1, 256)), dim3(256), 0, ST(stream), p, g, m, v, n, beta1, beta2,
-                       eps, step_size, bc2_sqrt, loss_scale, found, (unsigned short*)p_bf16);
+                       eps, step_size, bc2_sqrt, loss_scale, found, (unsigned short*)p_bf16,
+                       lowp_dtype == MSFWSI_DT_F16 ? 1 : 0);
     return msfwsi_launch_status();
 }
 
-extern "C" int msfwsi_cast_bf16(const float* src, void* dst, long n, void* stream) {
-    MSFWSI_CHECK_ARG(src && dst && n > 0);
+extern "C" int msfwsi_cast_lowp(int dtype, const float* src, void* dst, long n, void* stream) {
+    MSFWSI_CHECK_ARG(src && dst && n > 0 && (dtype == MSFWSI_DT_BF16 || dtype == MSFWSI_DT_F16));
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(sgrid(n / 4 + 1, 256)), dim3(256), 0, ST(stream), src,
-                       (unsigned short*)dst, n);
+                       (unsigned short*)dst, n, dtype == MSFWSI_DT_F16 ? 1 : 0);
     return msfwsi_launch_status();
 }
 
 extern "C" int msfwsi_pad_cast(int dtype, const float* src, void* dst, long rows, int C, int CP, void* stream) {
-    MSFWSI_CHECK_ARG((dtype == MSFWSI_DT_F32 || dtype == MSFWSI_DT_BF16) && src && dst && rows > 0 && C > 0 && CP >= C);
-    if (dtype == MSFWSI_DT_BF16)
-        hipLaunchKernelGGL(pad_cast_kernel<__bf16>, dim3(sgrid(rows * CP, 256)), dim3(256), 0, ST(stream), src,
-                           (__bf16*)dst, rows, C, CP);
-    else
-        hipLaunchKernelGGL(pad_cast_kernel<float>, dim3(sgrid(rows * CP, 256)), dim3(256), 0, ST(stream), src,
-                           (float*)dst, rows, C, CP);
+    MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && src && dst && rows > 0 && C > 0 && CP >= C);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(pad_cast_kernel<T>, dim3(sgrid(rows * CP, 256)), dim3(256), 0, ST(stream), src,
+                           (T*)dst, rows, C, CP));
     return msfwsi_launch_status();
 }
 

@@ -56,15 +56,7 @@ struct WgradCfg {
 };
 
 template <typename T>
-struct WFrag;
-template <>
-struct WFrag<float> {
-    typedef f32x4 type;
-};
-template <>
-struct WFrag<__bf16> {
-    typedef bf16x8 type;
-};
+using WFrag = MmaFrag<T>;
 
 __device__ __forceinline__ void wdma16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -255,13 +247,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < TJ; ++tj) {
-                    if constexpr (sizeof(T) == 2) {
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ti][e], bf[tj][e], acc[ti][tj], 0, 0, 0);
-                    }
+                    mma32<T>(acc[ti][tj], af[ti], bf[tj]);
                 }
         }
     };
@@ -349,8 +335,8 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
                                  const float* pro_scale, const float* pro_shift, int target_blocks,
                                  void* stream) {
     if (d == nullptr || x == nullptr || dy == nullptr || dw == nullptr) return MSFWSI_EINVAL;
-    if (d->dtype != MSFWSI_DT_F32 && d->dtype != MSFWSI_DT_BF16) return MSFWSI_EUNSUPPORTED;
-    const int vec = d->dtype == MSFWSI_DT_BF16 ? 8 : 4;
+    if (!msfwsi_dtype_ok(d->dtype)) return MSFWSI_EUNSUPPORTED;
+    const int vec = msfwsi_vec_of(d->dtype);
     if (d->C % vec != 0 || d->K % vec != 0) return MSFWSI_EUNSUPPORTED;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->P <= 0 || d->Q <= 0 || d->R <= 0 || d->S <= 0) return MSFWSI_EINVAL;
     if ((pro_scale == nullptr) != (pro_shift == nullptr)) return MSFWSI_EINVAL;
@@ -367,14 +353,11 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool small_i = d->K <= 64;
     const bool small_j = prm.Jtot <= 64;
-    if (d->dtype == MSFWSI_DT_BF16) {
-        if (small_i && small_j) return launch_wgrad<__bf16, 64, 64>(prm, target_blocks, st);
-        if (small_i) return launch_wgrad<__bf16, 64, 128>(prm, target_blocks, st);
-        if (small_j) return launch_wgrad<__bf16, 128, 64>(prm, target_blocks, st);
-        return launch_wgrad<__bf16, 128, 128>(prm, target_blocks, st);
-    }
-    if (small_i && small_j) return launch_wgrad<float, 64, 64>(prm, target_blocks, st);
-    if (small_i) return launch_wgrad<float, 64, 128>(prm, target_blocks, st);
-    if (small_j) return launch_wgrad<float, 128, 64>(prm, target_blocks, st);
-    return launch_wgrad<float, 128, 128>(prm, target_blocks, st);
+    MSFWSI_WITH_T(d->dtype, {
+        if (small_i && small_j) return launch_wgrad<T, 64, 64>(prm, target_blocks, st);
+        if (small_i) return launch_wgrad<T, 64, 128>(prm, target_blocks, st);
+        if (small_j) return launch_wgrad<T, 128, 64>(prm, target_blocks, st);
+        return launch_wgrad<T, 128, 128>(prm, target_blocks, st);
+    });
+    return MSFWSI_EINVAL;
 }

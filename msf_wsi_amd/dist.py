@@ -52,7 +52,10 @@ def sync_sums(packed: torch.Tensor, group=None) -> torch.Tensor:
 class FlatGroups:
     """Flat storage of the model parameters by optimizer group."""
 
-    def __init__(self, model: nn.Module, with_bf16: bool, device=None):
+    def __init__(self, model: nn.Module, with_bf16: bool = False, device=None, lowp_dtype=None):
+        if with_bf16 and lowp_dtype is None:
+            lowp_dtype = torch.bfloat16
+        with_bf16 = lowp_dtype is not None
         named = list(model.named_parameters())
         self.names: List[List[str]] = [[n for n, _ in named if n.startswith(p)] for p in GROUP_PREFIXES]
         self.params: List[List[nn.Parameter]] = [[p for n, p in named if n.startswith(pre)] for pre in GROUP_PREFIXES]
@@ -78,7 +81,7 @@ class FlatGroups:
             self.g.append(torch.zeros(total, dtype=torch.float32, device=dev))
             self.m.append(torch.zeros(total, dtype=torch.float32, device=dev))
             self.v.append(torch.zeros(total, dtype=torch.float32, device=dev))
-            self.w16.append(torch.zeros(total, dtype=torch.bfloat16, device=dev) if with_bf16 else None)
+            self.w16.append(torch.zeros(total, dtype=lowp_dtype, device=dev) if with_bf16 else None)
         self._grad_views: Dict[int, torch.Tensor] = {}
         self._w16_views: Dict[int, torch.Tensor] = {}
         for gi, plist in enumerate(self.params):

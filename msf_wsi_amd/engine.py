@@ -97,7 +97,7 @@ class StepRec:
 
 def chan_pad(dtype: torch.dtype) -> int:
     """stem input channels are zero-padded to one 16-byte chunk"""
-    return 8 if dtype == torch.bfloat16 else 4
+    return 4 if dtype == torch.float32 else 8
 
 
 # ------------------------------------------------------------------------------------------------
@@ -147,7 +147,7 @@ class WeightStore:
             kn.pad_cast(phys, out, rows, phys.shape[-1], pad_to)
         else:
             out = torch.empty(phys.shape, dtype=dtype, device=phys.device)
-            kn.cast_bf16(phys, out)
+            kn.cast_lowp(phys, out)
         self._cache[key] = (ver, out)
         return out
 
@@ -198,13 +198,12 @@ class Engine:
         env = os.environ.get("MSFWSI_DTYPE")
         if env:
             return {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
-                    "bfloat16": torch.bfloat16}[env.lower()]
+                    "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16}[env.lower()]
         if torch.is_autocast_enabled():
-            dt = torch.get_autocast_gpu_dtype()
-            if dt == torch.bfloat16:
+            dt = torch.get_autocast_dtype("cuda")  # --amp: fp16 (reference default) or bf16 (--bf16)
+            if dt in (torch.bfloat16, torch.float16):
                 return dt
-            raise _lib.MsfwsiHipError(
-                f"autocast dtype {dt} is not implemented by the gfx950 kernels; use bf16 (--amp --bf16) or fp32")
+            raise _lib.MsfwsiHipError(f"autocast dtype {dt} is not implemented by the gfx950 kernels")
         return torch.float32
 
     def _world(self) -> int:

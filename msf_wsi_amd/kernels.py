@@ -12,7 +12,9 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, DT_BF16, DT_F32
+from ._lib import ConvDesc, DT_BF16, DT_F16, DT_F32
+
+LOWP = {torch.bfloat16: DT_BF16, torch.float16: DT_F16}
 
 NSHARD = 32  # replicas of every fp64 statistics accumulator (spreads memory-side atomics)
 
@@ -22,11 +24,13 @@ def dt_of(t: torch.Tensor) -> int:
         return DT_F32
     if t.dtype == torch.bfloat16:
         return DT_BF16
+    if t.dtype == torch.float16:
+        return DT_F16
     raise TypeError(f"unsupported storage dtype {t.dtype}")
 
 
 def vec_of(dtype: torch.dtype) -> int:
-    return 8 if dtype == torch.bfloat16 else 4
+    return 4 if dtype == torch.float32 else 8
 
 
 def _stream() -> int:
@@ -60,7 +64,8 @@ def _opt(t, name, dtype=None, numel=None):
 def conv_desc(dtype: torch.dtype, N, H, W, Cin, K, R, S, stride, pad) -> ConvDesc:
     P = (H + 2 * pad - R) // stride + 1
     Q = (W + 2 * pad - S) // stride + 1
-    return ConvDesc(DT_BF16 if dtype == torch.bfloat16 else DT_F32, N, H, W, Cin, P, Q, K, R, S, stride, pad)
+    code = DT_F32 if dtype == torch.float32 else LOWP[dtype]
+    return ConvDesc(code, N, H, W, Cin, P, Q, K, R, S, stride, pad)
 
 
 def new_stats(C_: int, slots: int = 2, device=None) -> torch.Tensor:
@@ -406,23 +411,28 @@ def scaler_update(scale, tracker, found, growth_factor, backoff_factor, growth_i
                                         float(backoff_factor), int(growth_interval), _stream()), "scaler_update")
 
 
-def adam(p, g, m, v, lr, beta1, beta2, eps, step, loss_scale=None, found=None, p_bf16=None):
+def adam(p, g, m, v, lr, beta1, beta2, eps, step, loss_scale=None, found=None, p_lowp=None):
+    """p_lowp: bf16 / fp16 compute copy of p refreshed in the same pass"""
     lib = _lib.load()
     n = p.numel()
     for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):
         _req(t, nm, torch.float32, n)
     _opt(loss_scale, "loss_scale", torch.float32, 1)
     _opt(found, "found", torch.float32, 1)
-    _opt(p_bf16, "p_bf16", torch.bfloat16, n)
+    code = 0
+    if p_lowp is not None:
+        _req(p_lowp, "p_lowp", None, n)
+        code = LOWP[p_lowp.dtype]
     _lib.check(lib.msfwsi_adam(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps),
-                               int(step), _p(loss_scale), _p(found), _p(p_bf16), _stream()), "adam")
+                               int(step), _p(loss_scale), _p(found), _p(p_lowp), code, _stream()), "adam")
 
 
-def cast_bf16(src, dst):
+def cast_lowp(src, dst):
+    """fp32 -> bf16 / fp16 (dst.dtype)"""
     lib = _lib.load()
     _req(src, "src", torch.float32)
-    _req(dst, "dst", torch.bfloat16, src.numel())
-    _lib.check(lib.msfwsi_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "cast_bf16")
+    _req(dst, "dst", None, src.numel())
+    _lib.check(lib.msfwsi_cast_lowp(LOWP[dst.dtype], _p(src), _p(dst), src.numel(), _stream()), "cast_lowp")
     return dst
 
 

@@ -53,7 +53,7 @@ class PretrainStep:
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.MsfwsiHipError("PretrainStep needs the model on a HIP device (model.cuda()); no CPU path")
-        if dtype not in (torch.float32, torch.bfloat16):
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise _lib.MsfwsiHipError(f"unsupported compute dtype {dtype}")
         self.model = model
         self.arch = arch
@@ -66,16 +66,16 @@ class PretrainStep:
         self.betas = (0.9, 0.999)
         self.eps = [1e-8, 1e-8, 1e-8]
         self.t = 0
-        self.flats = FlatGroups(model, with_bf16=(dtype == torch.bfloat16))
+        self.flats = FlatGroups(model, lowp_dtype=None if dtype == torch.float32 else dtype)
         self.engine = Engine(process_group=process_group, sync_bn=sync_bn)
         model._engine = self.engine
-        if dtype == torch.bfloat16:
+        if dtype != torch.float32:
             for plist in self.flats.params:
                 for p in plist:
                     if p.dim() >= 2 and not (p.dim() == 4 and p.shape[1] == 3):  # stem: padded copy, cached
-                        self.engine.weights.register(p, torch.bfloat16, self.flats.w16_view(p))
+                        self.engine.weights.register(p, dtype, self.flats.w16_view(p))
             for gi in range(3):
-                kn.cast_bf16(self.flats.w[gi], self.flats.w16[gi])
+                kn.cast_lowp(self.flats.w[gi], self.flats.w16[gi])
         self.grads = _FlatGradStore(self.flats)
         # gradients travel on their OWN communicator: the multi-GB all-reduce of the head group must not sit in
         # front of the latency-bound SyncBN exchanges of the encoder backward that is still running
@@ -141,7 +141,7 @@ class PretrainStep:
         for gi in range(3):
             kn.adam(self.flats.w[gi], self.flats.g[gi], self.flats.m[gi], self.flats.v[gi], self.lrs[gi],
                     self.betas[0], self.betas[1], self.eps[gi], self.t, loss_scale=ls, found=found,
-                    p_bf16=self.flats.w16[gi])
+                    p_lowp=self.flats.w16[gi])
         if self.use_scaler:
             kn.scaler_update(self.scale, self.growth_tracker, self.found_inf, self.growth_factor,
                              self.backoff_factor, self.growth_interval)
@@ -224,9 +224,9 @@ class PretrainStep:
         self.load_optimizer_state_dict(ckpt["optimizer"])
         self.eps = [0.1, 0.1, 0.1]
         self.load_scaler_state_dict(ckpt.get("scaler", {}))
-        if self.dtype == torch.bfloat16:
+        if self.dtype != torch.float32:
             for gi in range(3):
-                kn.cast_bf16(self.flats.w[gi], self.flats.w16[gi])
+                kn.cast_lowp(self.flats.w[gi], self.flats.w16[gi])
         self.engine.weights._cache.clear()
         return int(ckpt["epoch"])
 

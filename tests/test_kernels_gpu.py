@@ -1,6 +1,7 @@
 """Per-kernel numerics on a real MI355X: every C-ABI entry point against a plain PyTorch fp32/fp64 CPU
 reference of the same operator on the same seeded inputs (fp32: rel-L2 <= 2e-5; bf16 storage: <= 1.5e-2,
-inputs pre-rounded to bf16 so only the kernel's own rounding is measured)."""
+fp16 storage: <= 2e-3;
+inputs pre-rounded to the storage type so only the kernel's own rounding is measured)."""
 import math
 
 import pytest
@@ -9,11 +10,11 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def tol(dt):
-    return 2e-5 if dt == torch.float32 else 1.5e-2
+    return {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dt]
 
 
 def rel(a, b):
@@ -320,7 +321,7 @@ def test_nchw_to_nhwc_and_pad(hip_lib):
 
     g = torch.Generator().manual_seed(8)
     x = torch.randn(3, 3, 10, 12, generator=g)
-    for dt, CP in ((torch.float32, 4), (torch.bfloat16, 8)):
+    for dt, CP in ((torch.float32, 4), (torch.bfloat16, 8), (torch.float16, 8)):
         y = torch.empty(3, 10, 12, CP, dtype=dt, device="cuda")
         kn.nchw_to_nhwc(x.cuda(), y, CP)
         ref = torch.zeros(3, 10, 12, CP)
@@ -370,6 +371,7 @@ def test_adam_and_scaler(hip_lib):
     p = p0.clone().cuda()
     m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     pb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    ph = torch.empty(n, dtype=torch.float16, device="cuda")
     scale = torch.full((1,), 1024.0, device="cuda")
     found = torch.zeros(1, device="cuda")
     for step in range(1, 4):
@@ -378,10 +380,14 @@ def test_adam_and_scaler(hip_lib):
         opt.step()
         gd = (gr * 1024.0).cuda()
         kn.nonfinite_check(gd, found)
-        kn.adam(p, gd, m, v, 3e-3, 0.9, 0.999, 1e-8, step, loss_scale=scale, found=found, p_bf16=pb)
+        kn.adam(p, gd, m, v, 3e-3, 0.9, 0.999, 1e-8, step, loss_scale=scale, found=found, p_lowp=pb)
     torch.cuda.synchronize()
     assert found.item() == 0
     assert torch.allclose(p.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(pb.float().cpu(), p.cpu().bfloat16().float())
+    kn.cast_lowp(p, ph)
+    assert torch.equal(ph.float().cpu(), p.cpu().half().float())
+    kn.cast_lowp(p, pb)
     assert torch.equal(pb.float().cpu(), p.cpu().bfloat16().float())
     # a non-finite gradient: flagged, step skipped, scale backs off
     gd = torch.randn(n, generator=g).cuda()
@@ -476,7 +482,7 @@ def test_conv3x3_halo_dgrad(hip_lib, dt, geom, fused):
         kw = dict(mask=(cd, sc.cuda(), sh.cuda()), sums=sums)
     kn.conv3x3_dgrad(d, nhwc(dy).to(dt).cuda(), nhwc(w).to(dt).cuda(), dx, resid=nhwc(resid).to(dt).cuda(), **kw)
     torch.cuda.synchronize()
-    assert rel(dx.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt) * (2 if dt == torch.bfloat16 else 1)
+    assert rel(dx.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt) * (1 if dt == torch.float32 else 2)
     if fused:
         s = sums.sum(0).cpu()
         gd = dx.double().cpu().reshape(-1, Cc)

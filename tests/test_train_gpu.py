@@ -101,6 +101,33 @@ def test_fused_step_bf16_tracks_fp32(hip_lib):
         assert torch.equal(ts.flats.w16[gi].float(), ts.flats.w[gi].bfloat16().float())
 
 
+def test_fused_step_fp16_with_loss_scaling(hip_lib):
+    """fp16 storage / fp16 MFMA (the reference's default --amp dtype): the GradScaler protocol keeps the step
+    finite -- a step is either applied, or skipped with the scale halved (tools/ssl_train.py:472-474)"""
+    from msf_wsi_amd.train import PretrainStep
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden("r18_b8_s64")
+    B, size = man["B"], man["size"]
+    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
+    model = build_product("resnet18").cuda().train()
+    ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float16)
+    w0 = [w.clone() for w in ts.flats.w]
+    losses, scales = [], []
+    for _ in range(4):
+        losses.append(float(ts.step(_gpu_batch(batch))))
+        scales.append(ts.scale.item())
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses))
+    assert abs(losses[0] - float(vec["loss"][0])) < 5e-3
+    assert all(s in (65536.0, 32768.0, 16384.0, 8192.0, 4096.0) for s in scales)
+    assert scales[-1] == scales[-2], "the scale must settle within 3 steps at this size"
+    assert any(not torch.equal(a, b) for a, b in zip(w0, ts.flats.w)), "at least one step was applied"
+    for gi in range(3):
+        assert torch.isfinite(ts.flats.w[gi]).all()
+        assert torch.equal(ts.flats.w16[gi].float(), ts.flats.w[gi].half().float())
+
+
 def test_checkpoint_layout_and_resume(hip_lib):
     from msf_wsi_amd.train import PretrainStep
     from oracle import msfwsi_oracle as orc
