@@ -99,7 +99,8 @@ int msfwsi_bn_act(int dtype, const void* c, const float* scale, const float* shi
 
 /* Backward at a residual-block output y = relu(bn(c_main) + identity):
  * g = (dy + gap_scale*gapg[image]) * (y>0); sums[shard][3][C] += {sum g, sum g*c_main, sum g*c_ds}.
- * dy or gapg may be NULL (not both), c_ds may be NULL. */
+ * dy or gapg may be NULL (not both), c_ds may be NULL; c_main may be NULL (slot 1 untouched: the main-branch
+ * sum then comes from msfwsi_fold_dots). */
 int msfwsi_block_end_bwd(int dtype, const void* dy, const void* y, const void* gapg, float gap_scale,
                          const void* c_main, const void* c_ds, void* g, double* sums, int nshard, long M, int HW,
                          int C, void* stream);
@@ -138,6 +139,16 @@ int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax,
 /* out[n][c] = mean over HW of y[n][hw][c].  Replaces: AdaptiveAvgPool2d((1,1)) + flatten on the four
  * stage outputs, src/models/resnet.py:244-250. */
 int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW, int C, void* stream);
+
+/* BatchNorm backward folded into the weights of the 1x1 conv W[K][C] that produced the BatchNorm input
+ * (Bottleneck conv3 -> bn3, src/models/resnet.py:115-117, backward by autograd in the reference): with c = W a,
+ *   fold_dots:    out[k] = sum_c W[k][c]*M[k][c]  (= sum over pixels of g*c, M = g^T a from msfwsi_conv_wgrad)
+ *   fold_weights: dW += k1 o M + k2 o WA + k3 (x) sa;  Wk1 = k1 o W;  Wk2 = k2 o W;  bvec[c] += sum_k k3[k] W[k][c]
+ * (WA = W (a^T a), sa = column sums of a, k1..k3 from msfwsi_bn_bwd_finalize).  All fp32 / fp64. */
+int msfwsi_fold_dots(const float* W, const float* M, double* out, int K, int C, void* stream);
+int msfwsi_fold_weights(const float* W, const float* M, const float* WA, const float* k1, const float* k2,
+                        const float* k3, const double* sa, float* dW, float* Wk1, float* Wk2, float* bvec, int K, int C,
+                        void* stream);
 
 /* column sums of x[M][C] added into sums[C] (fp64) -- bias gradient of backbone.py:30's Linear. */
 int msfwsi_colsum(int dtype, const void* x, double* sums, long M, int C, void* stream);

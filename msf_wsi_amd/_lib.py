@@ -47,6 +47,8 @@ SIGNATURES = {
     "msfwsi_stem_pool_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "msfwsi_stem_pool_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "msfwsi_gap_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "msfwsi_fold_dots": [_vp, _vp, _vp, _i, _i, _vp],
+    "msfwsi_fold_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_colsum": [_i, _vp, _vp, _l, _i, _vp],
     "msfwsi_add_f64_to_f32": [_vp, _vp, _i, _f, _vp],
     "msfwsi_rows_permute": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -389,12 +389,15 @@ __global__ void block_end_bwd_kernel(const T* __restrict__ dy, const T* __restri
                 for (int e = 0; e < VEC; ++e) g[e] = fmaf(gg[e], gap_scale, g[e]);
             }
             unpack16<T>(*reinterpret_cast<const uint4*>(y + o), yy);
-            unpack16<T>(*reinterpret_cast<const uint4*>(c_main + o), cm);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 g[e] = yy[e] > 0.f ? round_to<T>(g[e]) : 0.f;
                 acc[0][e] += g[e];
-                acc[1][e] = fmaf(g[e], cm[e], acc[1][e]);
+            }
+            if (c_main != nullptr) {  // null: the main-branch sum g*c comes from msfwsi_fold_dots
+                unpack16<T>(*reinterpret_cast<const uint4*>(c_main + o), cm);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[1][e] = fmaf(g[e], cm[e], acc[1][e]);
             }
             if (c_ds != nullptr) {
                 float cd[VEC];
@@ -520,6 +523,49 @@ __global__ void colsum_kernel(const T* __restrict__ x, double* sums, long M, int
         }
     }
     col_commit<1, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward folded into the weights of the 1x1 conv that produced its input (Bottleneck conv3 + bn3,
+// src/models/resnet.py:115-117): with c = W a the terms of  dc = k1*g + k2*c + k3  that depend on c reduce to
+// small [K][C] / [C][C] matrices, so the 4x-wide c never has to be kept, re-made or re-read in backward:
+//   sum_p g*c [k]   = sum_c W[k][c] * M[k][c]                     M = g^T a      (fold_dots)
+//   dW              = k1 o M + k2 o (W A) + k3 (x) sa             A = a^T a, sa = sum_p a   (fold_weights)
+//   W^T dc          = (k1 o W)^T g + (W^T diag(k2) W) a + W^T k3
+// ---------------------------------------------------------------------------------------------
+__global__ void fold_dots_kernel(const float* __restrict__ W, const float* __restrict__ Mm, double* __restrict__ out,
+                                 int K, int C) {
+    // one wave per output channel k
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= K) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int c = lane; c < C; c += 64) acc += (double)W[(long)k * C + c] * (double)Mm[(long)k * C + c];
+    acc = wave_sum_d(acc);
+    if (lane == 0) out[k] = acc;
+}
+
+constexpr int kFoldRows = 16;
+__global__ void fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ Mm,
+                                    const float* __restrict__ WA, const float* __restrict__ k1,
+                                    const float* __restrict__ k2, const float* __restrict__ k3,
+                                    const double* __restrict__ sa, float* __restrict__ dW, float* __restrict__ Wk1,
+                                    float* __restrict__ Wk2, float* bvec, int K, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int kb = blockIdx.y * kFoldRows;
+    const int ke = kb + kFoldRows < K ? kb + kFoldRows : K;
+    const float s = (float)sa[c];
+    float bacc = 0.f;
+    for (int k = kb; k < ke; ++k) {
+        const long o = (long)k * C + c;
+        const float w = W[o], a = k1[k], b = k2[k], d = k3[k];
+        dW[o] += fmaf(a, Mm[o], fmaf(b, WA[o], d * s));
+        Wk1[o] = a * w;
+        Wk2[o] = b * w;
+        bacc = fmaf(d, w, bacc);
+    }
+    atomicAdd(bvec + c, bacc);
 }
 
 __global__ void add_f64_to_f32_kernel(const double* __restrict__ in, float* out, int n, float alpha) {
@@ -678,7 +724,7 @@ extern "C" int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW
 extern "C" int msfwsi_block_end_bwd(int dtype, const void* dy, const void* y, const void* gapg, float gap_scale,
                                     const void* c_main, const void* c_ds, void* g, double* sums, int nshard, long M,
                                     int HW, int C, void* stream) {
-    MSFWSI_CHECK_ARG(dtype_ok(dtype) && y && c_main && g && sums && nshard >= 1 && M > 0 && HW > 0);
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && y && g && sums && nshard >= 1 && M > 0 && HW > 0);
     MSFWSI_CHECK_ARG(C % vec_of(dtype) == 0 && (dy != nullptr || gapg != nullptr));
     const int vec = vec_of(dtype);
     ColGrid cg = make_col_grid(M, C, vec, 2048);
@@ -730,6 +776,21 @@ extern "C" int msfwsi_colsum(int dtype, const void* x, double* sums, long M, int
     const size_t lds = (size_t)kThreads * vec * sizeof(float);
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)x, sums, M,
                            C, cg.cw, cg.nrl, cg.rows_per_block));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_fold_dots(const float* W, const float* M, double* out, int K, int C, void* stream) {
+    MSFWSI_CHECK_ARG(W && M && out && K > 0 && C > 0);
+    hipLaunchKernelGGL(fold_dots_kernel, dim3((K + 3) / 4), dim3(256), 0, ST(stream), W, M, out, K, C);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_fold_weights(const float* W, const float* M, const float* WA, const float* k1, const float* k2,
+                                   const float* k3, const double* sa, float* dW, float* Wk1, float* Wk2, float* bvec,
+                                   int K, int C, void* stream) {
+    MSFWSI_CHECK_ARG(W && M && WA && k1 && k2 && k3 && sa && dW && Wk1 && Wk2 && bvec && K > 0 && C > 0);
+    hipLaunchKernelGGL(fold_weights_kernel, dim3((C + 63) / 64, (K + kFoldRows - 1) / kFoldRows), dim3(64), 0,
+                       ST(stream), W, M, WA, k1, k2, k3, sa, dW, Wk1, Wk2, bvec, K, C);
     return msfwsi_launch_status();
 }
 

@@ -191,6 +191,11 @@ class Engine:
         # -7..+2 % for the forward (64-byte weight rows): on for dgrad, off for fwd
         self.halo3x3 = os.environ.get("MSFWSI_HALO3X3", "1") != "0"
         self.halo3x3_fwd = os.environ.get("MSFWSI_HALO3X3_FWD", "0") != "0"
+        # Bottleneck conv3+bn3 backward folded into weights (no c3 in backward at all); 0 = keep / re-make c3
+        self.fold_bn3 = os.environ.get("MSFWSI_FOLD_BN3", "1") != "0"
+        # ... and the closing ReLU gate of a folded block applied by the producer of its output gradient
+        self.fuse_gate = os.environ.get("MSFWSI_FUSE_GATE", "1") != "0"
+        self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ---- configuration ---------------------------------------------------------------------
     @staticmethod
@@ -381,9 +386,10 @@ class Engine:
                 else:
                     kn.bn_act(last.c, last.st.scale, last.st.shift, y_out, ident=y, relu=True)
                 if save:
-                    if self._drop_c3 and len(units) == 3:
-                        # Bottleneck: the 4x-wide conv3 output is 1/3 of the kept bytes and cheap to redo (1x1):
-                        # drop it, _block_bwd re-runs conv3 from the kept c2 with the kept statistics
+                    if (self._drop_c3 or self.fold_bn3) and len(units) == 3:
+                        # Bottleneck: the 4x-wide conv3 output is 1/3 of the kept bytes.  With the folded bn3
+                        # backward (_block_end_folded) it is never needed again; otherwise _block_bwd re-runs the
+                        # 1x1 conv3 from the kept c2 with the kept statistics
                         last.c = None
                     blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1))
                 y, h, w = y_out, gh, gw
@@ -412,6 +418,9 @@ class Engine:
         (engine.recompute = off | c3 | t1 | targets | auto).  Sets self._drop_c3 for the remaining passes."""
         mode = getattr(self, "recompute", "off")
         self._drop_c3 = False
+        if self.fold_bn3 and c3_fraction > 0:  # conv3 outputs are never kept on the folded path
+            per_image_bytes *= 1.0 - c3_fraction
+            c3_fraction = 0.0
         if mode == "off":
             return set()
         if mode == "c3":
@@ -444,12 +453,20 @@ class Engine:
 
     def encoder_backward(self, ps: EncPass, dfeats: Sequence[Optional[torch.Tensor]], grads: GradStore,
                          dtype: torch.dtype):
-        dy = None
-        for rec in reversed(ps.blocks):
+        dy, pre = None, None
+        for i in range(len(ps.blocks) - 1, -1, -1):
+            rec = ps.blocks[i]
             gapg = dfeats[rec.stage] if rec.stage_end else None
             if dy is None and gapg is None:
                 raise RuntimeError("encoder_backward: no gradient reaches the last block")
-            dy = self._block_bwd(rec, dy, gapg, grads, dtype)
+            gate = None
+            if i > 0 and self.fuse_gate:
+                pr = ps.blocks[i - 1]
+                if self._foldable(pr) and pr.ds is None:
+                    # the producer of pr's output gradient (this block's first conv) applies pr's closing ReLU gate,
+                    # adds pr's pooled-feature gradient and reduces sum(g) in its own epilogue
+                    gate = (pr.y_out, dfeats[pr.stage] if pr.stage_end else None, pr.HW)
+            dy, pre = self._block_bwd(rec, dy, gapg, grads, dtype, pre=pre, gate=gate)
             rec.units = []  # release activations
             rec.ds = None
         # stem: maxpool + relu + bn backward, then the 7x7 weight gradient
@@ -462,7 +479,86 @@ class Engine:
         kn.bn_bwd_apply(g0, u.c, k[0], k[1], k[2], g0)
         self._unit_wgrad(u, g0, grads, dtype)
 
-    def _block_bwd(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype) -> torch.Tensor:
+    def _foldable(self, rec: BlockRec) -> bool:
+        """Bottleneck block whose closing 1x1 conv (conv3) + BatchNorm backward can be folded into weights"""
+        if not self.fold_bn3 or len(rec.units) != 3:
+            return False
+        d = rec.units[-1].desc
+        return d.R == 1 and d.S == 1 and d.stride == 1 and rec.units[-1].x_pro is not None \
+            and getattr(rec.units[-1].op, "bias", None) is None
+
+    def _block_end_folded(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype, pre=None):
+        """Backward through y = relu(bn3(conv3(a2)) + identity) WITHOUT the 4x-wide conv3 output c3 = W a2:
+        every c3-dependent term of the BatchNorm backward dc3 = k1*g + k2*c3 + k3 is folded into [K][C] / [C][C]
+        matrices (msfwsi_fold_dots / msfwsi_fold_weights), so c3 is neither kept, re-made nor re-read:
+            sum g*c3 = rowdot(W, M),  M = g^T a2              (one weight-gradient launch on g)
+            dW      += k1 o M + k2 o (W A) + k3 (x) sum(a2),  A = a2^T a2
+            da2      = [ g (k1 o W) + a2 (W^T diag(k2) W) + W^T k3 ] * relu'(bn2(c2))
+        Returns (g, da2_gated, sums2 of the gated da2 for bn2's backward, the downsample coefficients or None)."""
+        last, prev = rec.units[-1], rec.units[-2]
+        d = last.desc
+        K, Cw = d.K, d.C
+        dev = rec.y_out.device
+        if pre is not None:
+            # dy is already the gated gradient (ReLU gate + pooled-feature gradient applied by its producer);
+            # pre = [nshard][2][K] with slot 0 = sum(g); slot 1 is overwritten by fold_dots below
+            g, sums, ns = dy, pre, 2
+            sums[:, 1].zero_()
+        else:
+            g, ns = torch.empty_like(rec.y_out), 3
+            sums = kn.new_stats(K, 3, dev)
+            kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, None, rec.ds.c if rec.ds is not None else None, g,
+                             sums, rec.HW)
+        a2 = self._normalised_operand(last)
+        W = WeightStore.physical(last.op.weight).view(K, 1, 1, Cw)
+        Mm = torch.zeros(K, 1, 1, Cw, dtype=torch.float32, device=dev)
+        kn.conv_wgrad(d, a2, g, Mm)
+        dsq = kn.conv_desc(dtype, d.N, d.P, d.Q, Cw, Cw, 1, 1, 1, 0)
+        A = torch.zeros(Cw, 1, 1, Cw, dtype=torch.float32, device=dev)
+        kn.conv_wgrad(dsq, a2, a2, A)
+        sa = torch.zeros(Cw, dtype=torch.float64, device=dev)
+        kn.colsum(a2, sa)
+        kn.fold_dots(W, Mm, sums[0, 1])  # slot 1 of shard 0; the other shards of that slot stay zero
+        k = self._bn_bwd_coeffs(sums, ns, 1, last.bn, last.st, grads)
+        kd = self._bn_bwd_coeffs(sums, 3, 2, rec.ds.bn, rec.ds.st, grads) if rec.ds is not None else None
+        # small fp32 matrices on the exact-fp32 MFMA path: WA = W A, G = W^T diag(k2) W
+        dlin = kn.conv_desc(torch.float32, K, 1, 1, Cw, Cw, 1, 1, 1, 0)
+        WA = torch.empty(K, 1, 1, Cw, dtype=torch.float32, device=dev)
+        kn.conv_fwd(dlin, W, A, WA)  # A is symmetric: [out][in] == [in][out]
+        Wk1 = torch.empty_like(WA)
+        Wk2 = torch.empty_like(WA)
+        bvec = torch.zeros(Cw, dtype=torch.float32, device=dev)
+        kn.fold_weights(W, Mm, WA, k[0], k[1], k[2], sa, grads.get(last.op.weight), Wk1, Wk2, bvec)
+        G = torch.zeros(Cw, 1, 1, Cw, dtype=torch.float32, device=dev)
+        kn.conv_wgrad(dlin, W, Wk2, G)  # G[i][j] = sum_k k2[k] W[k][i] W[k][j]
+        if dtype != torch.float32:
+            Gc, Wc = torch.empty_like(G, dtype=dtype), torch.empty_like(Wk1, dtype=dtype)
+            kn.cast_lowp(G, Gc)
+            kn.cast_lowp(Wk1, Wc)
+        else:
+            Gc, Wc = G, Wk1
+        t = torch.empty_like(a2)
+        kn.conv_fwd(dsq, a2, Gc, t, bias=bvec)
+        s2 = kn.new_stats(Cw, 2, dev)
+        da = torch.empty_like(a2)
+        kn.conv_dgrad(d, g, Wc, da, resid=t, mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2)
+        return g, da, s2, kd
+
+    def _block_bwd(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype, pre=None, gate=None):
+        """returns (gradient w.r.t. the block input, its fused-gate sums or None -- see encoder_backward)"""
+        if self._foldable(rec):
+            g, da, s2, kd = self._block_end_folded(rec, dy, gapg, grads, dtype, pre=pre)
+            resid = g
+            if rec.ds is not None:
+                kn.bn_bwd_apply(g, rec.ds.c, kd[0], kd[1], kd[2], g)  # g becomes d(downsample conv output)
+                self._unit_wgrad(rec.ds, g, grads, dtype)
+                resid = self._unit_dgrad(rec.ds, g, dtype)
+            prev = rec.units[1]
+            kp = self._bn_bwd_coeffs(s2, 2, 1, prev.bn, prev.st, grads)
+            kn.bn_bwd_apply(da, prev.c, kp[0], kp[1], kp[2], da)
+            return self._block_bwd_tail(rec, da, 1, resid, grads, dtype, gate=gate)
+        if pre is not None:
+            raise RuntimeError("a pre-gated gradient reached a block that is not on the folded path")
         last = rec.units[-1]
         last_xmat = None
         if last.c is None:  # dropped bottleneck conv3 output: re-run the 1x1 conv from the kept c2 + statistics
@@ -490,10 +586,23 @@ class Engine:
             kn.bn_bwd_apply(g, rec.ds.c, kd[0], kd[1], kd[2], g)  # g becomes d(downsample conv output)
             self._unit_wgrad(rec.ds, g, grads, dtype)
             resid = self._unit_dgrad(rec.ds, g, dtype)
-        cur = dc
-        for i in range(len(rec.units) - 1, 0, -1):
+        return self._block_bwd_tail(rec, dc, len(rec.units) - 1, resid, grads, dtype, last_xmat, gate=gate)
+
+    def _unit_gate(self, Cn: int, dev):
+        key = (Cn, str(dev))
+        if key not in self._gate_vecs:
+            self._gate_vecs[key] = (torch.ones(Cn, dtype=torch.float32, device=dev),
+                                    torch.zeros(Cn, dtype=torch.float32, device=dev))
+        return self._gate_vecs[key]
+
+    def _block_bwd_tail(self, rec: BlockRec, cur, top: int, resid, grads: GradStore, dtype, last_xmat=None,
+                        gate=None):
+        """units[top] .. units[0]: weight gradient, input gradient with the producer's ReLU gate + BatchNorm sums
+        fused into its epilogue, BatchNorm backward; the first unit adds the identity-path gradient `resid`"""
+        dev = cur.device
+        for i in range(top, 0, -1):
             u, prev = rec.units[i], rec.units[i - 1]
-            self._unit_wgrad(u, cur, grads, dtype, x_mat=last_xmat if u is last else None)
+            self._unit_wgrad(u, cur, grads, dtype, x_mat=last_xmat)
             last_xmat = None
             s2 = kn.new_stats(prev.c.shape[-1], 2, dev)
             # ReLU gate of prev and its BatchNorm-backward sums are fused into the dgrad epilogue
@@ -503,7 +612,15 @@ class Engine:
             cur = da
         first = rec.units[0]
         self._unit_wgrad(first, cur, grads, dtype)
-        return self._unit_dgrad(first, cur, dtype, resid=resid)
+        if gate is None:
+            return self._unit_dgrad(first, cur, dtype, resid=resid), None
+        y_prev, gapg_prev, hw_prev = gate
+        Cn = y_prev.shape[-1]
+        one, zero = self._unit_gate(Cn, dev)
+        sg = kn.new_stats(Cn, 2, dev)
+        dx = self._unit_dgrad(first, cur, dtype, resid=resid, gapg=gapg_prev, gap_scale=1.0 / hw_prev,
+                              mask=(y_prev, one, zero), sums=sg)
+        return dx, sg
 
     # ---- MLP heads -----------------------------------------------------------------------------
     @staticmethod

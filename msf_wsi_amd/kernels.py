@@ -236,7 +236,7 @@ def block_end_bwd(dy, y, gapg, gap_scale, c_main, c_ds, g, sums, HW):
     _req(y, "y")
     _opt(dy, "dy", y.dtype, M * Cn)
     _opt(gapg, "gapg", y.dtype, (M // HW) * Cn)
-    _req(c_main, "c_main", y.dtype, M * Cn)
+    _opt(c_main, "c_main", y.dtype, M * Cn)
     _opt(c_ds, "c_ds", y.dtype, M * Cn)
     _req(g, "g", y.dtype, M * Cn)
     _req(sums, "sums", torch.float64)
@@ -339,6 +339,32 @@ def gap_fwd(y, out, N, HW, Cn):
     _req(out, "out", y.dtype, N * Cn)
     _lib.check(lib.msfwsi_gap_fwd(dt_of(y), _p(y), _p(out), N, HW, Cn, _stream()), "gap_fwd")
     return out
+
+
+def fold_dots(W, Mm, out):
+    """out[k] = sum_c W[k][c] * Mm[k][c]   (fp64; the sum over pixels of g*c for c = W a, Mm = g^T a)"""
+    lib = _lib.load()
+    K = out.numel()
+    Cn = W.numel() // K
+    _req(W, "W", torch.float32, K * Cn)
+    _req(Mm, "M", torch.float32, K * Cn)
+    _req(out, "out", torch.float64, K)
+    _lib.check(lib.msfwsi_fold_dots(_p(W), _p(Mm), _p(out), K, Cn, _stream()), "fold_dots")
+
+
+def fold_weights(W, Mm, WA, k1, k2, k3, sa, dW, Wk1, Wk2, bvec):
+    """dW += k1 o Mm + k2 o WA + k3 (x) sa;  Wk1 = k1 o W;  Wk2 = k2 o W;  bvec += W^T k3"""
+    lib = _lib.load()
+    K = k1.numel()
+    Cn = W.numel() // K
+    for nm, t in (("W", W), ("M", Mm), ("WA", WA), ("dW", dW), ("Wk1", Wk1), ("Wk2", Wk2)):
+        _req(t, nm, torch.float32, K * Cn)
+    for nm, t in (("k1", k1), ("k2", k2), ("k3", k3)):
+        _req(t, nm, torch.float32, K)
+    _req(sa, "sa", torch.float64, Cn)
+    _req(bvec, "bvec", torch.float32, Cn)
+    _lib.check(lib.msfwsi_fold_weights(_p(W), _p(Mm), _p(WA), _p(k1), _p(k2), _p(k3), _p(sa), _p(dW), _p(Wk1), _p(Wk2),
+                                       _p(bvec), K, Cn, _stream()), "fold_weights")
 
 
 def colsum(x, sums):

@@ -27,6 +27,12 @@ SHAPES = [  # name, H, C, K, R, stride, pro
     ("l3.conv2 3x3 256->256 nopro", 14, 256, 256, 3, 1, False),
     ("l3.conv1 1x1 1024->256", 14, 1024, 256, 1, 1, False),
     ("l4.conv2 3x3 512->512 pro", 7, 512, 512, 3, 1, True),
+    ("l1.conv3 1x1 64->256 nopro", 56, 64, 256, 1, 1, False),
+    ("l2.conv1 1x1 512->128", 28, 512, 128, 1, 1, False),
+    ("l2.conv3 1x1 128->512 nopro", 28, 128, 512, 1, 1, False),
+    ("l3.conv3 1x1 256->1024 nopro", 14, 256, 1024, 1, 1, False),
+    ("l4.conv1 1x1 2048->512", 7, 2048, 512, 1, 1, False),
+    ("l4.conv3 1x1 512->2048 nopro", 7, 512, 2048, 1, 1, False),
 ]
 
 
@@ -65,5 +71,5 @@ for name, H, C, K, R, st, pro in SHAPES:
         t_f = timeit(lambda: kn.conv_fwd(d, x, w, y, pro=p, stats=stats))
         t_d = timeit(lambda: kn.conv_dgrad(d, dy, w, dx))
     t_w = timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=p))
-    print(f"{name:30s} M={M:9d} fwd {t_f:7.3f} ms {fl / t_f / 1e9:7.1f} TF {by / t_f / 1e6:7.1f} GB/s | "
+    print(f"{name:30s} M={M:9d} algMB x {x.numel() * 2 / 1e6:.0f} y {y.numel() * 2 / 1e6:.0f} | fwd {t_f:7.3f} ms {fl / t_f / 1e9:7.1f} TF {by / t_f / 1e6:7.1f} GB/s | "
           f"dgrad {t_d:7.3f} ms {fl / t_d / 1e9:7.1f} TF | wgrad {t_w:7.3f} ms {fl / t_w / 1e9:7.1f} TF", flush=True)

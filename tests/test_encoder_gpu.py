@@ -41,6 +41,40 @@ def test_resnet50_trunk_matches_reference(hip_lib):
     assert np.allclose(rv, vec["bn/layer3.0.downsample.1/running_var"], rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_folded_bn3_backward_equals_explicit(hip_lib, dt):
+    """the folded conv3+bn3 backward (no c3 in backward) against the explicit one (c3 re-made, bn_bwd_apply):
+    the same algebra, so in fp32 every parameter gradient agrees to rounding"""
+    from msf_wsi_amd.engine import Engine
+    from msf_wsi_amd.models import resnet
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 3, 96, 96, generator=g).cuda()
+    Rs = [torch.randn(6, d, generator=g).cuda() for d in (256, 512, 1024, 2048)]
+    grads = []
+    for fold in (False, True):
+        torch.manual_seed(MODEL_SEED)
+        enc = resnet.resnet50(zero_init_residual=False, return_features=True)
+        enc.fc = torch.nn.Identity()
+        enc = enc.cuda().train()
+        enc._engine = Engine()
+        enc._engine.fold_bn3 = fold
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+            feats = enc(x)
+        loss = sum((f.float() * r).sum() for f, r in zip(feats, Rs))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.double().cpu() for k, p in enc.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) == 159
+    errs = {k: ((grads[0][k] - grads[1][k]).norm() / (grads[0][k].norm() + 1e-30)).item() for k in grads[0]}
+    worst = max(errs, key=errs.get)
+    if dt == torch.float32:
+        # ReLU gates downstream of a folded block can flip on 1e-7 differences: median is the rounding level
+        assert np.median(list(errs.values())) < 2e-5 and errs[worst] < 5e-3, (worst, errs[worst])
+    else:
+        assert np.median(list(errs.values())) < 2e-2 and errs[worst] < 1e-1, (worst, errs[worst])
+
+
 def test_encoder_inference_mode_and_bf16(hip_lib):
     from msf_wsi_amd.models import resnet
 
