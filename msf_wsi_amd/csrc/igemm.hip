@@ -69,7 +69,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, bool K2 = false>
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 struct IgemmCfg {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int BK = ElemTraits<T>::BK;  // 64-byte operand rows
@@ -87,7 +87,7 @@ struct IgemmCfg {
     static constexpr int A_BYTES = BM * 64;
     static constexpr int B_BYTES = DGRAD ? BK * ROWB : BN * 64;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int NSTAGE_MAX = APRO ? 2 : (K2 ? 4 : 3);  // slab slots: prologue 2; DMA 3; DMA two-slab stages 2x2
+    static constexpr int NSTAGE_MAX = APRO ? 2 : 3;  // slab slots: register-staged prologue 2; pure DMA 3
     static constexpr int AB_BYTES = NSTAGE_MAX * STAGE_BYTES;
     static constexpr int C_BYTES = BM * LDC * (int)sizeof(T);
     static constexpr int MAIN_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
@@ -107,9 +107,152 @@ __device__ __forceinline__ int nat_off(int k, int cb) {
 // swizzled position of logical chunk c (0..3) of operand row `row`
 __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 2) & 3); }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, bool K2>
+// Shared epilogue: accumulators -> LDS tile (storage type) -> coalesced 16-byte row chunks, with the optional
+// bias / residual / pooled-gradient adds, the fused ReLU gate and the per-channel statistics.
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, typename Acc>
+__device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, const IgemmParams& prm, char* smem,
+                                               int tile_m, int m0, int n0) {
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
+    constexpr int VEC = Cfg::VEC, TM = Cfg::TM, TN = Cfg::TN, NW = Cfg::NW, NT = 64 * Cfg::NW, LDC = Cfg::LDC;
+    T* Cs = reinterpret_cast<T*>(smem);                             // [BM][LDC]
+    float* red = reinterpret_cast<float*>(smem + Cfg::MAIN_BYTES);  // [NW][BN][2]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int PQ = prm.P * prm.Q;
+    // ---------------- epilogue: accumulators -> LDS tile (storage type) ----------------
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ncol = (wn * TN + tn) * 32 + 8 * g + 4 * lh;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (prm.bias != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n0 + ncol + e < prm.Nout) bv[e] = prm.bias[n0 + ncol + e];
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = (wm * TM + tm) * 32 + l31;
+                T* dst = Cs + row * LDC + ncol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) store_elem<T>(dst, e, acc[tn][tm][g * 4 + e] + bv[e]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- row-chunk pass: coalesced 16-byte stores + per-channel statistics ----------------
+    constexpr int CPR = BN / VEC;        // chunks per tile row
+    constexpr int RPP = NT / CPR;        // rows per pass
+    const int cc = tid % CPR;
+    const int rr = tid / CPR;
+    const int ncol = n0 + cc * VEC;
+    const bool col_ok = ncol < prm.Nout;
+    T* __restrict__ out = reinterpret_cast<T*>(prm.out);
+    const T* __restrict__ resid = reinterpret_cast<const T*>(prm.resid);
+    float ssum[VEC], ssq[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
+    const T* __restrict__ mask_c = reinterpret_cast<const T*>(prm.mask_c);
+    float msc[VEC], msh[VEC];
+    if (mask_c != nullptr && col_ok) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            msc[e] = prm.mask_scale[ncol + e];
+            msh[e] = prm.mask_shift[ncol + e];
+        }
+    }
+
+#pragma unroll 2
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int row = rr + pass * RPP;
+        const int m = m0 + row;
+        if (m < prm.M && col_ok) {
+            uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
+            const long off = (long)m * prm.Nout + ncol;
+            if (resid != nullptr || prm.gapg != nullptr) {
+                float f[VEC];
+                unpack16<T>(v, f);
+                if (resid != nullptr) {
+                    float g[VEC];
+                    unpack16<T>(*reinterpret_cast<const uint4*>(resid + off), g);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[e] += g[e];
+                }
+                if (prm.gapg != nullptr) {
+                    float gp[VEC];
+                    unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) +
+                                                                (long)(m / PQ) * prm.Nout + ncol), gp);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
+                }
+                v = pack16<T>(f);
+            }
+            if (mask_c != nullptr) {
+                // fused backward of the producer's relu(bn(c)): gate, then accumulate {sum g, sum g*c}
+                float f[VEC], cv[VEC];
+                unpack16<T>(v, f);
+                unpack16<T>(*reinterpret_cast<const uint4*>(mask_c + off), cv);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (!(fmaf(cv[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
+                    ssum[e] += f[e];
+                    ssq[e] = fmaf(f[e], cv[e], ssq[e]);
+                }
+                v = pack16<T>(f);
+                *reinterpret_cast<uint4*>(out + off) = v;
+            } else {
+                *reinterpret_cast<uint4*>(out + off) = v;
+                if (prm.stats != nullptr) {
+                    float f[VEC];
+                    unpack16<T>(v, f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        ssum[e] += f[e];
+                        ssq[e] = fmaf(f[e], f[e], ssq[e]);
+                    }
+                }
+            }
+        }
+    }
+
+    if (prm.stats != nullptr) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+            for (int off = CPR; off < 64; off <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], off, 64);
+                ssq[e] += __shfl_xor(ssq[e], off, 64);
+            }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                red[(wave * BN + lane * VEC + e) * 2 + 0] = ssum[e];
+                red[(wave * BN + lane * VEC + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += NT) {
+            const int col = i % BN, which = i / BN;
+            if (n0 + col < prm.Nout) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += red[(w * BN + col) * 2 + which];
+                double* dst = prm.stats + ((long)(tile_m % prm.nshard) * 2 + which) * prm.Nout + n0 + col;
+                atomicAdd(dst, (double)t);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams prm) {
-    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO, K2> Cfg;
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
     constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
     constexpr bool PD = !APRO;                 // pure-DMA staging: deep (3-stage) pipeline with counted vmcnt
     constexpr int NST = PD ? 3 : 2;
@@ -242,7 +385,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         char* Ab = As + buf * Cfg::A_BYTES;
         char* Bb = Bs + buf * Cfg::B_BYTES;
         const int tap_t = (tap_r * prm.S + tap_s) & 31;
-        const bool slab_ok = k0 < prm.Ktot;  // wave-uniform: the tail slab of a two-slab stage may not exist
+        const bool slab_ok = true;
         long tap_delta;  // element offset of tap (r,s) relative to tap (0,0)
         if (DGRAD)
             tap_delta = prm.stride == 1 ? -((long)tap_r * prm.W + tap_s) * prm.C
@@ -435,25 +578,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 
     // ---------------- main loop ----------------
     const int nk = (prm.Ktot + BK - 1) / BK;
-    if constexpr (PD && K2) {
-        // two slabs per stage, two stages: one barrier per 2*BK of depth (16 MFMAs per wave between barriers)
-        const int nk2 = (nk + 1) / 2;
-        fetch(0, 0);
-        fetch(BK, 1);
-        for (int kt2 = 0; kt2 < nk2; ++kt2) {
-            const int cb = (kt2 & 1) * 2, nb = 2 - cb;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt2 + 1 < nk2) {
-                fetch((2 * kt2 + 2) * BK, nb);
-                fetch((2 * kt2 + 3) * BK, nb + 1);
-            }
-            compute(cb);
-            compute(cb + 1);
-        }
-        __syncthreads();
-    } else if constexpr (PD) {
+    if constexpr (PD) {
         // every byte arrives by LDS-DMA: keep TWO slabs in flight.  Per wave and slab exactly DMA_PER_SLAB
         // instructions are issued, so "slab kt has landed" == at most DMA_PER_SLAB newer ones outstanding.
         constexpr int DMA_PER_SLAB = A_IT + (DGRAD ? Cfg::NAT_IT : B_IT);
@@ -490,142 +615,258 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         }
     }
 
-    // ---------------- epilogue: accumulators -> LDS tile (storage type) ----------------
+    igemm_epilogue<T, BM, BN, WM, WN, DGRAD, APRO>(acc, prm, smem, tile_m, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pure-DMA kernel for the common case (no BatchNorm prologue, C % BK == 0, R*S <= 32): every operand byte
+// arrives by `buffer_load_dwordx4 ... lds`.  Per lane the byte offset of each 16-byte piece is CONSTANT for the
+// whole k loop; the filter tap and channel slab move only the wave-uniform scalar offset, and out-of-image
+// taps / out-of-range rows use an out-of-range offset (the buffer range check then writes zeros).  The k loop
+// therefore carries almost no address arithmetic: per slab one s_mov m0 + one buffer_load per piece.
+// (The generic kernel above spends >100 SALU + ~45 VALU instructions per slab on 64-bit address selects --
+// measured 13 SALU + 6 VALU per MFMA -- which, not the MFMA pipe or HBM, bounded it.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff,
+                                             soff, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams prm) {
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, false> Cfg;
+    constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
+    constexpr int NW = Cfg::NW;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int NB = DGRAD ? Cfg::NAT_IT : B_IT;
+    constexpr int OOB = (int)0x80000000;  // byte offset beyond num_records: the load returns zeros
+    typedef typename Frag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                                   // [3][BM][64 B]
+    char* Bs = smem + Cfg::NSTAGE_MAX * Cfg::A_BYTES;  // [3][BN][64 B] or [3][BK][ROWB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const unsigned wgid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = wgid % prm.ntile_n;
+    const int tile_m = wgid / prm.ntile_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int PQ = prm.P * prm.Q;
+    const int RS = prm.R * prm.S;
+    const int sh = (DGRAD && prm.stride == 2) ? 1 : 0;
+
+    // source pixel (linear index over [img][H][W], may be negative inside the padding) of filter tap (0,0)
+    auto tap0_pixel = [&](int m, int& hb, int& wb) -> long {
+        const int img = m / PQ;
+        const int rem = m - img * PQ;
+        const int p = rem / prm.Q;
+        const int q = rem - p * prm.Q;
+        if (DGRAD) {
+            hb = p + prm.pad;
+            wb = q + prm.pad;
+        } else {
+            hb = p * prm.stride - prm.pad;
+            wb = q * prm.stride - prm.pad;
+        }
+        return ((long)img * prm.H + (hb >> sh)) * prm.W + (wb >> sh);
+    };
+    // reference pixel of the workgroup: source = ref + lane offset (pix - pix(m0) + W+1 >= 0, the margin covers the
+    // non-monotonic rows of the stride-2 input gradient) + tap shift (maxd - tap distance >= 0)
+    int hb0, wb0;
+    const long maxd = DGRAD ? ((long)((prm.R - 1) >> sh) * prm.W + ((prm.S - 1) >> sh)) : 0;
+    const long ref_pix = tap0_pixel(m0, hb0, wb0) - (prm.W + 1) - maxd;
+    const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(reinterpret_cast<const T*>(prm.src)) + ref_pix * prm.C, 0, 0x7fffffff, 0x00020000);
+    const long wbytes = (long)prm.Nout * prm.Ktot * ES;
+    const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(prm.wgt), 0, (int)(wbytes < 0x7fffffffL ? wbytes : 0x7fffffffL), 0x00020000);
+
+    // ---- per-lane constants: group g = it*NW + wave covers operand rows 16g .. 16g+15; lane l owns the LDS
+    // bytes [16g*64 + 16*l, +16) = row 16g + l/4, slot l%4, and fetches the logical chunk slot ^ swizzle(row)
+    int a_voff[A_IT];
+    unsigned a_mask[A_IT];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ncol = (wn * TN + tn) * 32 + 8 * g + 4 * lh;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (prm.bias != nullptr) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n0 + ncol + e < prm.Nout) bv[e] = prm.bias[n0 + ncol + e];
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = (i * NW + wave) * 16 + (lane >> 2);
+        const int kc = swz(row, lane & 3);
+        const int m = m0 + row;
+        const bool rowok = m < prm.M;
+        int hb, wb;
+        const long pix = tap0_pixel(rowok ? m : m0, hb, wb);
+        unsigned mask = 0;
+        for (int r = 0; r < prm.R; ++r)
+            for (int s2 = 0; s2 < prm.S; ++s2) {
+                int h, w;
+                bool ok = rowok;
+                if (DGRAD) {
+                    const int th = hb - r, tw = wb - s2;
+                    if (sh) ok = ok && (((th | tw) & 1) == 0);
+                    h = th >> sh;
+                    w = tw >> sh;
+                    ok = ok && th >= 0 && tw >= 0;
+                } else {
+                    h = hb + r;
+                    w = wb + s2;
+                }
+                ok = ok && (unsigned)h < (unsigned)prm.H && (unsigned)w < (unsigned)prm.W;
+                mask |= (ok ? 1u : 0u) << (r * prm.S + s2);
             }
+        a_mask[i] = mask;
+        a_voff[i] = (int)(((pix - ref_pix - maxd) * prm.C + kc * VEC) * ES);
+    }
+    int b_voff[NB];
+    if (!DGRAD) {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int row = (i * NW + wave) * 16 + (lane >> 2);
+            const int n = n0 + row;
+            b_voff[i] = n < prm.Nout ? (int)(((long)n * prm.Ktot + swz(row, lane & 3) * VEC) * ES) : OOB;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            constexpr int CPRW = ROWB / 16;
+            const int krow = (i * NW + wave) * Cfg::NAT_RPI + lane / CPRW;
+            const int cp = lane % CPRW;
+            const int g = (ROWB >= 256) ? (krow & 3) : ((krow >> 1) & 1);
+            const int n = n0 + ((((cp >> 2) ^ g) << 2) | (cp & 3)) * VEC;
+            b_voff[i] = n < prm.Nout ? (int)(((long)krow * RS * prm.Nout + n) * ES) : OOB;
+        }
+    }
+
+    // running tap state (wave-uniform scalars)
+    int tap_r = 0, tap_s = 0, tap_c = 0, tap_t = 0, k0 = 0;
+    int soff_tap = 0;
+    int voff_eff[A_IT];
+    auto fetch = [&](int buf) {
+        if (tap_c == 0) {  // new filter tap: which rows have a source pixel, and the tap's scalar shift
+            tap_t = tap_r * prm.S + tap_s;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) voff_eff[i] = ((a_mask[i] >> tap_t) & 1u) ? a_voff[i] : OOB;
+            const long d = DGRAD ? maxd - ((long)(tap_r >> sh) * prm.W + (tap_s >> sh)) : (long)tap_r * prm.W + tap_s;
+            soff_tap = (int)(d * prm.C * ES);
+        }
+        char* Ab = As + buf * Cfg::A_BYTES + wave * 1024;
+        char* Bb = Bs + buf * Cfg::B_BYTES + wave * 1024;
+        const int soff_a = soff_tap + tap_c * ES;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) dma16_buf(srd_a, Ab + i * NW * 1024, voff_eff[i], soff_a);
+        const int soff_b = DGRAD ? (int)(((long)tap_c * RS + tap_t) * prm.Nout * ES) : k0 * ES;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) dma16_buf(srd_b, Bb + i * NW * 1024, b_voff[i], soff_b);
+        k0 += BK;
+        tap_c += BK;
+        if (tap_c >= prm.C) {
+            tap_c = 0;
+            if (++tap_s == prm.S) {
+                tap_s = 0;
+                ++tap_r;
+            }
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+
+    auto compute = [&](int buf) {
+        const char* Ab = As + buf * Cfg::A_BYTES;
+        const char* Bb = Bs + buf * Cfg::B_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            frag_t xf[TM], wf[TN];
+            const int cidx = ks * 2 + lh;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int row = (wm * TM + tm) * 32 + l31;
-                T* dst = Cs + row * LDC + ncol;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) store_elem<T>(dst, e, acc[tn][tm][g * 4 + e] + bv[e]);
+                xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * 64 + swz(row, cidx) * 16);
             }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int ncol = (wn * TN + tn) * 32;
+                if (!DGRAD) {
+                    const int row = ncol + l31;
+                    wf[tn] = *reinterpret_cast<const frag_t*>(Bb + row * 64 + swz(row, cidx) * 16);
+                } else if constexpr (sizeof(T) == 2) {
+                    // transposed LDS read: 16-lane group G -> columns 16*(G&1).., k-half G>>1
+                    const int li = lane & 15, G = lane >> 4;
+                    const int q = li >> 2, p = li & 3;
+                    const int kbase = ks * 16 + (G >> 1) * 8 + q;
+                    const int cb = (ncol + (G & 1) * 16 + p * 4) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Bb + nat_off<ROWB>(kbase, cb)));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Bb + nat_off<ROWB>(kbase + 4, cb)));
+                    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    wf[tn] = __builtin_bit_cast(frag_t, both);
+                } else {
+                    frag_t t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        t[e] = *reinterpret_cast<const float*>(Bb + nat_off<ROWB>(ks * 8 + lh * 4 + e, (ncol + l31) * 4));
+                    wf[tn] = t;
+                }
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) mma_step<T>(acc[tn][tm], wf[tn], xf[tm]);
         }
+    };
+
+    // ---------------- main loop: TWO slabs in flight, counted vmcnt ----------------
+    const int nk = prm.Ktot / BK;
+    constexpr int DMA_PER_SLAB = A_IT + NB;
+    static_assert(DMA_PER_SLAB >= 2 && DMA_PER_SLAB <= 6, "unexpected DMA count per slab");
+    fetch(0);
+    if (nk > 1) fetch(1);
+    int st_c = 0, st_f = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            if constexpr (DMA_PER_SLAB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (DMA_PER_SLAB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if constexpr (DMA_PER_SLAB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (DMA_PER_SLAB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // slab kt visible to all waves; stage st_f (read in kt-1) is free
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) fetch(st_f);
+        compute(st_c);
+        st_c = st_c == 2 ? 0 : st_c + 1;
+        st_f = st_f == 2 ? 0 : st_f + 1;
     }
     __syncthreads();
-
-    // ---------------- row-chunk pass: coalesced 16-byte stores + per-channel statistics ----------------
-    constexpr int CPR = BN / VEC;        // chunks per tile row
-    constexpr int RPP = NT / CPR;        // rows per pass
-    const int cc = tid % CPR;
-    const int rr = tid / CPR;
-    const int ncol = n0 + cc * VEC;
-    const bool col_ok = ncol < prm.Nout;
-    T* __restrict__ out = reinterpret_cast<T*>(prm.out);
-    const T* __restrict__ resid = reinterpret_cast<const T*>(prm.resid);
-    float ssum[VEC], ssq[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
-    const T* __restrict__ mask_c = reinterpret_cast<const T*>(prm.mask_c);
-    float msc[VEC], msh[VEC];
-    if (mask_c != nullptr && col_ok) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            msc[e] = prm.mask_scale[ncol + e];
-            msh[e] = prm.mask_shift[ncol + e];
-        }
-    }
-
-#pragma unroll 2
-    for (int pass = 0; pass < BM / RPP; ++pass) {
-        const int row = rr + pass * RPP;
-        const int m = m0 + row;
-        if (m < prm.M && col_ok) {
-            uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
-            const long off = (long)m * prm.Nout + ncol;
-            if (resid != nullptr || prm.gapg != nullptr) {
-                float f[VEC];
-                unpack16<T>(v, f);
-                if (resid != nullptr) {
-                    float g[VEC];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(resid + off), g);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) f[e] += g[e];
-                }
-                if (prm.gapg != nullptr) {
-                    float gp[VEC];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) +
-                                                                (long)(m / PQ) * prm.Nout + ncol), gp);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
-                }
-                v = pack16<T>(f);
-            }
-            if (mask_c != nullptr) {
-                // fused backward of the producer's relu(bn(c)): gate, then accumulate {sum g, sum g*c}
-                float f[VEC], cv[VEC];
-                unpack16<T>(v, f);
-                unpack16<T>(*reinterpret_cast<const uint4*>(mask_c + off), cv);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    if (!(fmaf(cv[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
-                    ssum[e] += f[e];
-                    ssq[e] = fmaf(f[e], cv[e], ssq[e]);
-                }
-                v = pack16<T>(f);
-                *reinterpret_cast<uint4*>(out + off) = v;
-            } else {
-                *reinterpret_cast<uint4*>(out + off) = v;
-                if (prm.stats != nullptr) {
-                    float f[VEC];
-                    unpack16<T>(v, f);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        ssum[e] += f[e];
-                        ssq[e] = fmaf(f[e], f[e], ssq[e]);
-                    }
-                }
-            }
-        }
-    }
-
-    if (prm.stats != nullptr) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-#pragma unroll
-            for (int off = CPR; off < 64; off <<= 1) {
-                ssum[e] += __shfl_xor(ssum[e], off, 64);
-                ssq[e] += __shfl_xor(ssq[e], off, 64);
-            }
-        }
-        if (lane < CPR) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                red[(wave * BN + lane * VEC + e) * 2 + 0] = ssum[e];
-                red[(wave * BN + lane * VEC + e) * 2 + 1] = ssq[e];
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < 2 * BN; i += NT) {
-            const int col = i % BN, which = i / BN;
-            if (n0 + col < prm.Nout) {
-                float t = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) t += red[(w * BN + col) * 2 + which];
-                double* dst = prm.stats + ((long)(tile_m % prm.nshard) * 2 + which) * prm.Nout + n0 + col;
-                atomicAdd(dst, (double)t);
-            }
-        }
-    }
+    igemm_epilogue<T, BM, BN, WM, WN, DGRAD, false>(acc, prm, smem, tile_m, m0, n0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, bool K2 = false>
+long g_fast_dma = 1;  // tunable through msfwsi_set_tuning(1, .): 0 = always the generic kernel
+
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 int launch_igemm(IgemmParams& prm, hipStream_t stream) {
-    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO, K2> Cfg;
+    typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
     const int ntm = (prm.M + BM - 1) / BM;
     prm.ntile_n = (prm.Nout + BN - 1) / BN;
     const long nblk = (long)ntm * prm.ntile_n;
     if (nblk <= 0 || nblk > 0x7fffffffL) return MSFWSI_EINVAL;
-    auto kern = igemm_kernel<T, BM, BN, WM, WN, DGRAD, APRO, K2>;
+    // pure-DMA fast kernel when no BatchNorm prologue is applied and a k-slab never straddles two filter taps
+    void (*kern)(const IgemmParams) = igemm_kernel<T, BM, BN, WM, WN, DGRAD, APRO>;
+    if constexpr (!APRO) {
+        if (g_fast_dma && prm.C % Cfg::BK == 0 && prm.R * prm.S <= 32) kern = igemm_dma_kernel<T, BM, BN, WM, WN, DGRAD>;
+    }
     if (Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -636,7 +877,6 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
 }
 
 long g_big_tile_min_blocks = 1024;  // tunable through msfwsi_set_tuning
-long g_k2_mode = 0;                 // 0: one slab per barrier; 1: two slabs per barrier (128x128); 2: also 256x128
 
 template <typename T, bool DGRAD, bool APRO>
 int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
@@ -646,13 +886,7 @@ int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
     // (the register-staged BatchNorm-prologue variant loses with 8 waves: measured 0.55 -> 0.76 ms)
     if (!APRO && sizeof(T) == 2 && (long)((prm.M + 255) / 256) * ((prm.Nout + 127) / 128) >= g_big_tile_min_blocks)
     {
-        if constexpr (!APRO) {
-            if (g_k2_mode >= 2) return launch_igemm<T, 256, 128, 4, 2, DGRAD, APRO, true>(prm, stream);
-        }
         return launch_igemm<T, 256, 128, 4, 2, DGRAD, APRO>(prm, stream);
-    }
-    if constexpr (!APRO) {
-        if (g_k2_mode >= 1) return launch_igemm<T, 128, 128, 2, 2, DGRAD, APRO, true>(prm, stream);
     }
     return launch_igemm<T, 128, 128, 2, 2, DGRAD, APRO>(prm, stream);
 }
@@ -680,7 +914,7 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
         return MSFWSI_OK;
     }
     if (key == 1) {
-        g_k2_mode = value;
+        g_fast_dma = value;
         return MSFWSI_OK;
     }
     return MSFWSI_EINVAL;
