@@ -908,7 +908,13 @@ int check_desc(const msfwsi_conv_desc* d) {
 
 }  // namespace
 
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v);
+
 extern "C" int msfwsi_set_tuning(int key, long value) {
+    if (key == 2) {
+        msfwsi_wgrad_set_lin(value);
+        return MSFWSI_OK;
+    }
     if (key == 0) {
         g_big_tile_min_blocks = value;
         return MSFWSI_OK;

@@ -63,6 +63,13 @@ __device__ __forceinline__ void wdma16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// same through a buffer descriptor: per-lane byte offset + wave-uniform byte offset, out-of-range -> zeros.
+// (kept in a __device__ helper: the builtin does not exist for the host pass of a __global__ template)
+__device__ __forceinline__ void wdma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff,
+                                             soff, 0, 0);
+}
+
 template <int ROWB>
 __device__ __forceinline__ int wswz(int k) {
     return (ROWB >= 256) ? (k & 3) : ((k >> 1) & 1);
@@ -98,8 +105,15 @@ __device__ __forceinline__ typename WFrag<T>::type read_tr_frag(const char* tile
     }
 }
 
-template <typename T, int BI, int BJ, bool XPRO>
+// LIN: stride 1 and P == H, Q == W ("same" padding or 1x1): the source pixel of output pixel m at tap (r,s) is
+// m + (r-pad)*W + (s-pad), linear in m.  Both tiles then arrive by `buffer_load_dwordx4 ... lds` whose per-lane
+// byte offsets are constant over the whole pixel loop; the slab only moves the scalar offset, rows past the end of
+// the split / tensor fall outside the buffer range (zeros), and the k loop carries no address arithmetic for 1x1
+// filters and ~13 VALU per piece (image-border test) for 3x3.  (The generic path spends two integer divisions per
+// piece and slab: measured 21 VALU instructions per MFMA.)
+template <typename T, int BI, int BJ, bool XPRO, bool LIN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
+    static_assert(!(XPRO && LIN), "the linear fast path is pure DMA");
     typedef WgradCfg<T, BI, BJ, XPRO> Cfg;
     constexpr int VEC = Cfg::VEC, BKM = Cfg::BKM, ROWI = Cfg::ROWI, ROWJ = Cfg::ROWJ;
     constexpr int WI = Cfg::WI, TI = Cfg::TI, TJ = Cfg::TJ;
@@ -171,9 +185,65 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
     uint4 b_reg[XPRO ? B_IT : 1];
     bool b_ok[XPRO ? B_IT : 1];
 
+    // ---- linear fast path: buffer descriptors + constant per-lane offsets ----
+    constexpr int ES = (int)sizeof(T);
+    constexpr int OOB = (int)0x80000000;
+    int la_voff[LIN ? A_IT : 1], lb_voff[LIN ? B_IT : 1], lb_eff[LIN ? B_IT : 1];
+    int lb_rem[LIN ? B_IT : 1], lb_pbad[LIN ? B_IT : 1], lb_qbad[LIN ? B_IT : 1];
+    int l_soff_a = 0, l_soff_b = 0;
+    const bool taps = prm.R * prm.S > 1;
+    const float inv_q = 1.0f / (float)prm.Q, inv_pq = 1.0f / (float)PQ;
+    const long dy_bytes = (long)(mend > mbeg ? mend - mbeg : 0) * prm.K * ES;
+    const __amdgpu_buffer_rsrc_t srd_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy) + (long)mbeg * prm.K, 0, (int)dy_bytes, 0x00020000);
+    const long dr_min = -((long)prm.pad * prm.W + prm.pad);
+    const long xbase = (long)mbeg + dr_min;  // pixel index of the descriptor base (may precede the tensor)
+    const long x_bytes_full = ((long)prm.M - xbase) * prm.C * ES;
+    const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(x) + xbase * prm.C, 0, (int)(x_bytes_full > 0x7fffffffL ? 0x7fffffffL : x_bytes_full), 0x00020000);
+    if constexpr (LIN) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) la_voff[i] = a_colok[i] ? (a_row[i] * prm.K + (a_col[i])) * ES : OOB;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const long dr = (long)(b_r[i] - prm.pad) * prm.W + (b_s[i] - prm.pad);
+            lb_voff[i] = b_colok[i] ? (int)(((b_row[i] + dr - dr_min) * prm.C + b_c[i]) * ES) : OOB;
+            lb_eff[i] = lb_voff[i];
+            // a tap leaves the image only on one row (p_bad) and / or one column (q_bad) of output pixels
+            const int hr = b_r[i] - prm.pad, ws = b_s[i] - prm.pad;
+            lb_pbad[i] = hr < 0 ? -hr - 1 : (hr > 0 ? prm.P - hr : -1);
+            lb_qbad[i] = ws < 0 ? -ws - 1 : (ws > 0 ? prm.Q - ws : -1);
+            lb_rem[i] = (mbeg + b_row[i]) % PQ;
+        }
+    }
+
     auto fetch = [&](int mb, int st) {
         char* Ab = As + st * Cfg::A_BYTES;
         char* Bb = Bs + st * Cfg::B_BYTES;
+        if constexpr (LIN) {  // slabs are fetched in order: the scalar offsets and the pixel position advance by BKM
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                wdma16_buf(srd_a, Ab + (i * 4 + wave) * 1024, la_voff[i], l_soff_a);
+            if (taps) {
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) {
+                    const int rem = lb_rem[i];
+                    const int pp = (int)(((float)rem + 0.5f) * inv_q);  // exact: rem < 2^21
+                    const int qq = rem - pp * prm.Q;
+                    // |hr|,|ws| <= 1 for the 3x3 filters this path serves (wider taps use the generic kernel)
+                    lb_eff[i] = (pp != lb_pbad[i] && qq != lb_qbad[i]) ? lb_voff[i] : OOB;
+                    int nr = rem + BKM;
+                    nr -= (int)(((float)nr + 0.5f) * inv_pq) * PQ;
+                    lb_rem[i] = nr;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                wdma16_buf(srd_b, Bb + (i * 4 + wave) * 1024, lb_eff[i], l_soff_b);
+            l_soff_a += BKM * prm.K * ES;
+            l_soff_b += BKM * prm.C * ES;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int m = mb + a_row[i];
@@ -302,6 +372,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
         }
 }
 
+long g_wgrad_lin = 1;  // msfwsi_set_tuning(2, .): 0 = always the generic staging
+
 template <typename T, int BI, int BJ>
 int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
     typedef WgradCfg<T, BI, BJ> Cfg;
@@ -320,16 +392,25 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
     if (tiles > 0x7fffffffL) return MSFWSI_EINVAL;
     constexpr int lds_pro = WgradCfg<T, BI, BJ, true>::LDS_BYTES;
     constexpr int lds_dma = WgradCfg<T, BI, BJ, false>::LDS_BYTES;
+    // linear fast path: stride 1, same-size output, taps at most one pixel outside, offsets within 2 GiB windows
+    const bool lin = g_wgrad_lin && prm.stride == 1 && prm.P == prm.H && prm.Q == prm.W && prm.pad <= 1 &&
+                     prm.R <= 3 && prm.S <= 3 && prm.R == 2 * prm.pad + 1 && prm.S == 2 * prm.pad + 1 &&
+                     (rows + 2L * prm.W + 4) * (prm.C > prm.K ? prm.C : prm.K) * (long)sizeof(T) < 0x7fffffffL;
     if (prm.pro_scale != nullptr)
-        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, true>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
+        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, true, false>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
                            lds_pro, stream, prm);
+    else if (lin)
+        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, false, true>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
+                           lds_dma, stream, prm);
     else
-        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, false>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
+        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, false, false>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
                            lds_dma, stream, prm);
     return msfwsi_launch_status();
 }
 
 }  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v) { g_wgrad_lin = v; }
 
 extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw,
                                  const float* pro_scale, const float* pro_shift, int target_blocks,

@@ -17,3 +17,17 @@ for dt in (torch.bfloat16, torch.float32):
             torch.cuda.synchronize()
             e = (y.float().cpu() - ref).norm() / ref.norm()
             print(dt, (N, H, C, K, R, st), "fast", fast, "rel", float(e), "y[0,0,0,:4]", y[0, 0, 0, :4].float().cpu().tolist(), "ref", ref[0, 0, 0, :4].tolist(), flush=True)
+print("---- wgrad ----")
+for dt in (torch.bfloat16, torch.float32):
+    for (N, H, C, K, R, st) in ((2, 14, 64, 64, 1, 1), (2, 14, 64, 64, 3, 1), (5, 7, 128, 96, 3, 1), (3, 2, 64, 64, 3, 1), (300, 9, 32, 128, 3, 1)):
+        x = torch.randn(N, H, H, C).to(dt)
+        d = kn.conv_desc(dt, N, H, H, C, K, R, R, st, R // 2)
+        dy = torch.randn(N, d.P, d.Q, K).to(dt)
+        ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (K, C, R, R), dy.float().permute(0, 3, 1, 2), stride=st, padding=R // 2).permute(0, 2, 3, 1)
+        for fast in (0, 1):
+            lib.msfwsi_set_tuning(2, fast)
+            dw = torch.zeros(K, R, R, C, device="cuda")
+            kn.conv_wgrad(d, x.cuda(), dy.cuda(), dw)
+            torch.cuda.synchronize()
+            e = (dw.cpu() - ref).norm() / ref.norm()
+            print(dt, (N, H, C, K, R, st), "lin", fast, "rel", float(e), flush=True)
