@@ -47,6 +47,7 @@ SIGNATURES = {
     "msfwsi_stem_pool_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "msfwsi_stem_pool_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "msfwsi_gap_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "msfwsi_bn_act_sum": [_i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
     "msfwsi_fold_dots": [_vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_fold_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_colsum": [_i, _vp, _vp, _l, _i, _vp],

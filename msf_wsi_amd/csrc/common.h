@@ -217,6 +217,24 @@ __device__ __forceinline__ void mma32<float>(f32x16& acc, const f32x4& a, const 
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
 }
 
+// exact unsigned division by a launch-time constant (Granlund-Montgomery): 4 VALU instead of ~25
+struct FastDiv {
+    unsigned mul, sh1, sh2;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned L = 0;
+    while ((1ull << L) < d) ++L;  // ceil(log2 d)
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+    f.sh1 = L < 1 ? L : 1;
+    f.sh2 = L > 0 ? L - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) {
+    const unsigned t = __umulhi(f.mul, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -33,6 +33,7 @@ struct WgradParams {
     int M, Jtot;
     int rows_per_split;
     int ntile_i;
+    FastDiv div_pq, div_q;
 };
 
 template <typename T, int BI, int BJ, bool XPRO = false>
@@ -258,9 +259,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
             bool ok = (m < mend) && b_colok[i];
             long off = 0;
             if (ok) {
-                const int img = m / PQ;
+                const int img = (int)fast_div((unsigned)m, prm.div_pq);
                 const int rem = m - img * PQ;
-                const int p = rem / prm.Q;
+                const int p = (int)fast_div((unsigned)rem, prm.div_q);
                 const int q = rem - p * prm.Q;
                 const int h = p * prm.stride - prm.pad + b_r[i];
                 const int w = q * prm.stride - prm.pad + b_s[i];
@@ -430,6 +431,8 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
     prm.R = d->R; prm.S = d->S; prm.stride = d->stride; prm.pad = d->pad;
     prm.M = d->N * d->P * d->Q;
     prm.Jtot = d->R * d->S * d->C;
+    prm.div_pq = make_fastdiv((unsigned)(d->P * d->Q));
+    prm.div_q = make_fastdiv((unsigned)d->Q);
     if (target_blocks <= 0) target_blocks = 1024;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool small_i = d->K <= 64;

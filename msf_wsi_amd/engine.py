@@ -187,8 +187,8 @@ class Engine:
         self.materialize_3x3 = os.environ.get("MSFWSI_MATERIALIZE_3X3", "1") != "0"
         self.materialize_wgrad = os.environ.get("MSFWSI_MATERIALIZE_WGRAD", "1") != "0"
         self.materialize_1x1 = os.environ.get("MSFWSI_MATERIALIZE_1X1", "1") != "0"
-        # halo-in-LDS 3x3 kernel: measured +14..25 % for the input gradient (natural 256-byte weight rows),
-        # -7..+2 % for the forward (64-byte weight rows): on for dgrad, off for fwd
+        # halo-in-LDS 3x3 kernel: since the pure-DMA gather kernel lost its per-slab address arithmetic it only wins
+        # for the 64-channel input gradient (494 vs 450 TFLOP/s); wider layers and the forward use the gather kernel
         self.halo3x3 = os.environ.get("MSFWSI_HALO3X3", "1") != "0"
         self.halo3x3_fwd = os.environ.get("MSFWSI_HALO3X3_FWD", "0") != "0"
         # Bottleneck conv3+bn3 backward folded into weights (no c3 in backward at all); 0 = keep / re-make c3
@@ -334,7 +334,7 @@ class Engine:
         d = u.desc
         dx = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dc.device)
         w = self.weights.get(u.op.weight, dtype)
-        if self.halo3x3 and gapg is None and kn.conv3x3_supported(d):
+        if self.halo3x3 and gapg is None and d.K <= 64 and kn.conv3x3_supported(d):
             kn.conv3x3_dgrad(d, dc, w, dx, resid=resid, mask=mask, sums=sums)
         else:
             kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale, mask=mask, sums=sums)
@@ -509,15 +509,15 @@ class Engine:
             sums = kn.new_stats(K, 3, dev)
             kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, None, rec.ds.c if rec.ds is not None else None, g,
                              sums, rec.HW)
-        a2 = self._normalised_operand(last)
+        a2 = torch.empty_like(last.x)  # relu(bn2(c2)) and its column sums in one pass
+        sa = torch.zeros(Cw, dtype=torch.float64, device=dev)
+        kn.bn_act_sum(last.x, last.x_pro.scale, last.x_pro.shift, a2, sa)
         W = WeightStore.physical(last.op.weight).view(K, 1, 1, Cw)
         Mm = torch.zeros(K, 1, 1, Cw, dtype=torch.float32, device=dev)
         kn.conv_wgrad(d, a2, g, Mm)
         dsq = kn.conv_desc(dtype, d.N, d.P, d.Q, Cw, Cw, 1, 1, 1, 0)
         A = torch.zeros(Cw, 1, 1, Cw, dtype=torch.float32, device=dev)
         kn.conv_wgrad(dsq, a2, a2, A)
-        sa = torch.zeros(Cw, dtype=torch.float64, device=dev)
-        kn.colsum(a2, sa)
         kn.fold_dots(W, Mm, sums[0, 1])  # slot 1 of shard 0; the other shards of that slot stay zero
         k = self._bn_bwd_coeffs(sums, ns, 1, last.bn, last.st, grads)
         kd = self._bn_bwd_coeffs(sums, 3, 2, rec.ds.bn, rec.ds.st, grads) if rec.ds is not None else None

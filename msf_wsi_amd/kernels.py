@@ -229,6 +229,21 @@ def bn_act(c, scale, shift, out, ident=None, id_scale=None, id_shift=None, relu=
     return out
 
 
+def bn_act_sum(c, scale, shift, out, sums):
+    """out = relu(scale*c+shift); sums[C] (fp64) += column sums of out"""
+    lib = _lib.load()
+    Cn = scale.numel()
+    M = c.numel() // Cn
+    _req(c, "c", None, M * Cn)
+    _req(out, "out", c.dtype, M * Cn)
+    _req(scale, "scale", torch.float32, Cn)
+    _req(shift, "shift", torch.float32, Cn)
+    _req(sums, "sums", torch.float64, Cn)
+    _lib.check(lib.msfwsi_bn_act_sum(dt_of(c), _p(c), _p(scale), _p(shift), _p(out), _p(sums), M, Cn, _stream()),
+               "bn_act_sum")
+    return out
+
+
 def block_end_bwd(dy, y, gapg, gap_scale, c_main, c_ds, g, sums, HW):
     lib = _lib.load()
     Cn = y.shape[-1]
