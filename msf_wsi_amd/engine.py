@@ -510,13 +510,13 @@ class Engine:
             kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, None, rec.ds.c if rec.ds is not None else None, g,
                              sums, rec.HW)
         a2 = torch.empty_like(last.x)  # relu(bn2(c2)) and its column sums in one pass
-        sa = torch.zeros(Cw, dtype=torch.float64, device=dev)
+        sa = kn.zeros((Cw,), torch.float64, dev)
         kn.bn_act_sum(last.x, last.x_pro.scale, last.x_pro.shift, a2, sa)
         W = WeightStore.physical(last.op.weight).view(K, 1, 1, Cw)
-        Mm = torch.zeros(K, 1, 1, Cw, dtype=torch.float32, device=dev)
+        Mm = kn.zeros((K, 1, 1, Cw), torch.float32, dev)
         kn.conv_wgrad(d, a2, g, Mm)
         dsq = kn.conv_desc(dtype, d.N, d.P, d.Q, Cw, Cw, 1, 1, 1, 0)
-        A = torch.zeros(Cw, 1, 1, Cw, dtype=torch.float32, device=dev)
+        A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
         kn.conv_wgrad(dsq, a2, a2, A)
         kn.fold_dots(W, Mm, sums[0, 1])  # slot 1 of shard 0; the other shards of that slot stay zero
         k = self._bn_bwd_coeffs(sums, ns, 1, last.bn, last.st, grads)
@@ -527,9 +527,9 @@ class Engine:
         kn.conv_fwd(dlin, W, A, WA)  # A is symmetric: [out][in] == [in][out]
         Wk1 = torch.empty_like(WA)
         Wk2 = torch.empty_like(WA)
-        bvec = torch.zeros(Cw, dtype=torch.float32, device=dev)
+        bvec = kn.zeros((Cw,), torch.float32, dev)
         kn.fold_weights(W, Mm, WA, k[0], k[1], k[2], sa, grads.get(last.op.weight), Wk1, Wk2, bvec)
-        G = torch.zeros(Cw, 1, 1, Cw, dtype=torch.float32, device=dev)
+        G = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
         kn.conv_wgrad(dlin, W, Wk2, G)  # G[i][j] = sum_k k2[k] W[k][i] W[k][j]
         if dtype != torch.float32:
             Gc, Wc = torch.empty_like(G, dtype=dtype), torch.empty_like(Wk1, dtype=dtype)

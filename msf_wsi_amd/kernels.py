@@ -68,8 +68,53 @@ def conv_desc(dtype: torch.dtype, N, H, W, Cin, K, R, S, stride, pad) -> ConvDes
     return ConvDesc(code, N, H, W, Cin, P, Q, K, R, S, stride, pad)
 
 
+class ZeroArena:
+    """Zero-initialised scratch for one step.  The step needs ~6000 small zeroed accumulators (sharded BatchNorm
+    statistics, fold matrices); instead of one fill kernel each, `begin_step` clears ONE buffer (sized from the
+    previous step's demand) and `zeros` hands out 256-byte aligned slices of it.  Inactive (plain torch.zeros)
+    outside PretrainStep.step and while the first step measures the demand."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.off = 0
+        self.demand = 0
+        self.active = False
+
+    def begin_step(self, device):
+        want = int(self.demand * 1.1) + (1 << 20)
+        if self.demand and (self.buf is None or self.buf.numel() < want or self.buf.device != torch.device(device)):
+            self.buf = torch.empty(want, dtype=torch.uint8, device=device)
+        if self.buf is not None:
+            self.buf.zero_()
+        self.off, self.demand, self.active = 0, 0, True
+
+    def end_step(self):
+        self.active = False
+
+    def zeros(self, shape, dtype, device) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
+        if not self.active:
+            return torch.zeros(shape, dtype=dtype, device=device)
+        self.demand += nbytes
+        if self.buf is None or self.off + nbytes > self.buf.numel() or self.buf.device != torch.device(device):
+            return torch.zeros(shape, dtype=dtype, device=device)
+        out = self.buf[self.off:self.off + nbytes].view(dtype)[:n].view(shape)
+        self.off += nbytes
+        return out
+
+
+ARENA = ZeroArena()
+
+
+def zeros(shape, dtype, device) -> torch.Tensor:
+    return ARENA.zeros(tuple(shape), dtype, device)
+
+
 def new_stats(C_: int, slots: int = 2, device=None) -> torch.Tensor:
-    return torch.zeros(NSHARD, slots, C_, dtype=torch.float64, device=device or "cuda")
+    return ARENA.zeros((NSHARD, slots, C_), torch.float64, device or "cuda")
 
 
 class KernelTimer:

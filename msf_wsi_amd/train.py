@@ -120,9 +120,14 @@ class PretrainStep:
         """one optimisation step; returns the (device-resident, fp64) loss of this minibatch"""
         bs = batch[0][0].shape[0]
         self.flats.zero_grads()
-        outs, rec, dps = self.forward_loss(batch, want_grad=True)
-        loss = self.loss_accum.clone()
-        self.engine.model_backward(self.model, rec, dps, self.grads, self.dtype, on_group_done=self.reducer.launch)
+        kn.ARENA.begin_step(self.device)  # one clear for all of this step's small zero-initialised accumulators
+        try:
+            outs, rec, dps = self.forward_loss(batch, want_grad=True)
+            loss = self.loss_accum.clone()
+            self.engine.model_backward(self.model, rec, dps, self.grads, self.dtype,
+                                       on_group_done=self.reducer.launch)
+        finally:
+            kn.ARENA.end_step()
         self.reducer.wait()
         self.optimizer_step()
         self.epoch_meter[0] += loss[0] * bs

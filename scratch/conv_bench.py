@@ -11,6 +11,7 @@ from msf_wsi_amd import _lib as _L  # noqa: E402
 
 _L.load().msfwsi_set_tuning(1, int(os.environ.get("TUNE_FAST", "1")))
 _L.load().msfwsi_set_tuning(0, int(os.environ.get("TUNE_BIG", "1024")))
+_L.load().msfwsi_set_tuning(3, int(os.environ.get("TUNE_TILE", "0")))
 N = int(os.environ.get("NIMG", "1024"))
 REP = int(os.environ.get("REP", "5"))
 ONLY = os.environ.get("ONLY", "")
@@ -27,6 +28,8 @@ SHAPES = [  # name, H, C, K, R, stride, pro
     ("l3.conv2 3x3 256->256 nopro", 14, 256, 256, 3, 1, False),
     ("l3.conv1 1x1 1024->256", 14, 1024, 256, 1, 1, False),
     ("l4.conv2 3x3 512->512 pro", 7, 512, 512, 3, 1, True),
+    ("l2.conv2 3x3 128->128 nopro", 28, 128, 128, 3, 1, False),
+    ("l4.conv2 3x3 512->512 nopro", 7, 512, 512, 3, 1, False),
     ("l1.conv3 1x1 64->256 nopro", 56, 64, 256, 1, 1, False),
     ("l2.conv1 1x1 512->128", 28, 512, 128, 1, 1, False),
     ("l2.conv3 1x1 128->512 nopro", 28, 128, 512, 1, 1, False),
@@ -71,5 +74,15 @@ for name, H, C, K, R, st, pro in SHAPES:
         t_f = timeit(lambda: kn.conv_fwd(d, x, w, y, pro=p, stats=stats))
         t_d = timeit(lambda: kn.conv_dgrad(d, dy, w, dx))
     t_w = timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=p))
+    if os.environ.get("FUSED", "0") != "0":
+        # the epilogue the engine really uses: residual add + ReLU gate of the producer + BatchNorm-backward sums
+        resid = torch.randn_like(dx)
+        mc = torch.randn_like(dx)
+        one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        sums = kn.new_stats(C, 2, "cuda")
+        t_df = timeit(lambda: kn.conv_dgrad(d, dy, w, dx, resid=resid, mask=(mc, one, zero), sums=sums))
+        byf = 2.0 * (dy.numel() + 3 * dx.numel())
+        print(f"{name:30s} fused dgrad (resid+gate+sums) {t_df:7.3f} ms {byf / t_df / 1e6:7.1f} GB/s | plain dgrad {2.0 * (dy.numel() + dx.numel()) / t_d / 1e6:7.1f} GB/s | "
+              f"fwd+stats {by / t_f / 1e6:7.1f} GB/s | wgrad {2.0 * (x.numel() + dy.numel()) / t_w / 1e6:7.1f} GB/s", flush=True)
     print(f"{name:30s} M={M:9d} algMB x {x.numel() * 2 / 1e6:.0f} y {y.numel() * 2 / 1e6:.0f} | fwd {t_f:7.3f} ms {fl / t_f / 1e9:7.1f} TF {by / t_f / 1e6:7.1f} GB/s | "
           f"dgrad {t_d:7.3f} ms {fl / t_d / 1e9:7.1f} TF | wgrad {t_w:7.3f} ms {fl / t_w / 1e9:7.1f} TF", flush=True)
