@@ -10,7 +10,7 @@ import sys
 def family(n):
     if "conv3x3_kernel" in n:
         return "conv_dgrad" if n.rstrip("E").endswith("Lb1") or "Lb1EE" in n else "conv_fwd"
-    if "igemm_kernel" in n:
+    if "igemm_kernel" in n or "igemm_dma_kernel" in n:
         import re
         flags = re.findall(r"Lb(\d)E", n)
         return "conv_dgrad" if flags and flags[0] == "1" else "conv_fwd"
