@@ -47,6 +47,13 @@ typedef struct msfwsi_conv_desc {
 int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, const float* pro_scale,
                     const float* pro_shift, const float* bias, double* stats, int nshard, void* stream);
 
+/* y = [relu]( round(conv(x, w)) * post_scale[k] + post_shift[k] + ident ): a conv whose consumer BatchNorm
+ * statistics are already known (from msfwsi_fold_matvec / msfwsi_fold_dots), so BatchNorm apply, the residual add and
+ * the ReLU of src/models/resnet.py:131-138 (bn3 -> += identity -> relu) run in the conv epilogue and the raw conv
+ * output never reaches HBM.  ident may be NULL. */
+int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, const float* post_scale,
+                         const float* post_shift, const void* ident, int relu, void* stream);
+
 /* dx = conv_transpose(dy, w) [+ resid] [+ gap_scale * gapg[image]]  (input gradient).  w is the forward
  * weight [K][R][S][C], read in place as the [k][n] operand.  resid: [N,H,W,C] added element-wise (the
  * identity-path gradient of a residual block); gapg: [N][C] broadcast over H*W (global-average-pool
@@ -151,6 +158,10 @@ int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW, int C, vo
  *   fold_weights: dW += k1 o M + k2 o WA + k3 (x) sa;  Wk1 = k1 o W;  Wk2 = k2 o W;  bvec[c] += sum_k k3[k] W[k][c]
  * (WA = W (a^T a), sa = column sums of a, k1..k3 from msfwsi_bn_bwd_finalize).  All fp32 / fp64. */
 int msfwsi_fold_dots(const float* W, const float* M, double* out, int K, int C, void* stream);
+/* out[k] = sum_c W[k][c]*v[c] (fp64).  With v = column sums of a and fold_dots(W, W (a^T a)) this yields the
+ * BatchNorm statistics {sum c, sum c^2} of c = W a WITHOUT forming c: the forward of conv3 -> bn3 then runs the
+ * conv once with the BatchNorm apply + residual + ReLU in its epilogue (msfwsi_conv_fwd_post). */
+int msfwsi_fold_matvec(const float* W, const double* v, double* out, int K, int C, void* stream);
 int msfwsi_fold_weights(const float* W, const float* M, const float* WA, const float* k1, const float* k2,
                         const float* k3, const double* sa, float* dW, float* Wk1, float* Wk2, float* bvec, int K, int C,
                         void* stream);

@@ -48,6 +48,8 @@ SIGNATURES = {
     "msfwsi_stem_pool_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "msfwsi_gap_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
     "msfwsi_bn_act_sum": [_i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
+    "msfwsi_fold_matvec": [_vp, _vp, _vp, _i, _i, _vp],
+    "msfwsi_conv_fwd_post": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_fold_dots": [_vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_fold_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_colsum": [_i, _vp, _vp, _l, _i, _vp],

@@ -663,6 +663,18 @@ __global__ void fold_dots_kernel(const float* __restrict__ W, const float* __res
     if (lane == 0) out[k] = acc;
 }
 
+// out[k] = sum_c W[k][c] * v[c]  (fp64; sum over pixels of c = W a from the column sums of a)
+__global__ void fold_matvec_kernel(const float* __restrict__ W, const double* __restrict__ v, double* __restrict__ out,
+                                   int K, int C) {
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= K) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int c = lane; c < C; c += 64) acc += (double)W[(long)k * C + c] * v[c];
+    acc = wave_sum_d(acc);
+    if (lane == 0) out[k] = acc;
+}
+
 constexpr int kFoldRows = 16;
 __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ Mm,
                                     const float* __restrict__ WA, const float* __restrict__ k1,
@@ -917,6 +929,12 @@ extern "C" int msfwsi_colsum(int dtype, const void* x, double* sums, long M, int
 extern "C" int msfwsi_fold_dots(const float* W, const float* M, double* out, int K, int C, void* stream) {
     MSFWSI_CHECK_ARG(W && M && out && K > 0 && C > 0);
     hipLaunchKernelGGL(fold_dots_kernel, dim3((K + 3) / 4), dim3(256), 0, ST(stream), W, M, out, K, C);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_fold_matvec(const float* W, const double* v, double* out, int K, int C, void* stream) {
+    MSFWSI_CHECK_ARG(W && v && out && K > 0 && C > 0);
+    hipLaunchKernelGGL(fold_matvec_kernel, dim3((K + 3) / 4), dim3(256), 0, ST(stream), W, v, out, K, C);
     return msfwsi_launch_status();
 }
 

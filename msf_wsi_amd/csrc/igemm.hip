@@ -46,6 +46,9 @@ struct IgemmParams {
     const void* mask_c;      // [M][Nout] raw conv output whose BatchNorm+ReLU gates this gradient, nullable
     const float* mask_scale; // with mask_c: out = acc * (mask_scale*c + mask_shift > 0), stats = {sum g, sum g*c}
     const float* mask_shift;
+    const float* post_scale; // per output channel, nullable: out = [relu](round(acc)*post_scale + post_shift + resid)
+    const float* post_shift;
+    int post_relu;
     int N, H, W, C;          // source tensor
     int P, Q, Nout;          // output tensor
     int R, S, stride, pad;
@@ -158,7 +161,14 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
 #pragma unroll
     for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
     const T* __restrict__ mask_c = reinterpret_cast<const T*>(prm.mask_c);
-    float msc[VEC], msh[VEC];
+    float msc[VEC], msh[VEC], psc[VEC], psh[VEC];
+    if (prm.post_scale != nullptr && col_ok) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            psc[e] = prm.post_scale[ncol + e];
+            psh[e] = prm.post_shift[ncol + e];
+        }
+    }
     if (mask_c != nullptr && col_ok) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -174,9 +184,14 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
         if (m < prm.M && col_ok) {
             uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
             const long off = (long)m * prm.Nout + ncol;
-            if (resid != nullptr || prm.gapg != nullptr) {
+            if (resid != nullptr || prm.gapg != nullptr || prm.post_scale != nullptr) {
                 float f[VEC];
                 unpack16<T>(v, f);
+                if (prm.post_scale != nullptr) {
+                    // fused BatchNorm apply of the consumer (statistics known beforehand, see conv_fwd_post)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[e] = fmaf(f[e], psc[e], psh[e]);
+                }
                 if (resid != nullptr) {
                     float g[VEC];
                     unpack16<T>(*reinterpret_cast<const uint4*>(resid + off), g);
@@ -189,6 +204,10 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                                                                 (long)(m / PQ) * prm.Nout + ncol), gp);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
+                }
+                if (prm.post_relu) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[e] = fmaxf(f[e], 0.f);
                 }
                 v = pack16<T>(f);
             }
@@ -954,6 +973,27 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool pro = pro_scale != nullptr;
     MSFWSI_WITH_T(d->dtype, return pro ? dispatch_tile<T, false, true>(prm, st) : dispatch_tile<T, false, false>(prm, st));
+    return MSFWSI_EINVAL;
+}
+
+extern "C" int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, const void* w, void* y,
+                                    const float* post_scale, const float* post_shift, const void* ident, int relu,
+                                    void* stream) {
+    int rc = check_desc(d);
+    if (rc != MSFWSI_OK) return rc;
+    MSFWSI_CHECK_ARG(x != nullptr && w != nullptr && y != nullptr && post_scale != nullptr && post_shift != nullptr);
+    IgemmParams prm{};
+    prm.src = x; prm.wgt = w; prm.out = y;
+    prm.post_scale = post_scale; prm.post_shift = post_shift; prm.post_relu = relu ? 1 : 0;
+    prm.resid = ident;
+    prm.nshard = 1;
+    prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C;
+    prm.P = d->P; prm.Q = d->Q; prm.Nout = d->K;
+    prm.R = d->R; prm.S = d->S; prm.stride = d->stride; prm.pad = d->pad;
+    prm.M = d->N * d->P * d->Q;
+    prm.Ktot = d->R * d->S * d->C;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MSFWSI_WITH_T(d->dtype, return dispatch_tile<T, false, false>(prm, st));
     return MSFWSI_EINVAL;
 }
 

@@ -48,8 +48,9 @@ class Unit:
     desc: object
     x: torch.Tensor                  # operand tensor (raw)
     x_pro: Optional[BNState]         # BatchNorm+ReLU to apply to x on load
-    c: torch.Tensor                  # raw output
+    c: torch.Tensor                  # raw output (None: never formed / dropped, see _conv_bn_res_fwd)
     st: Optional[BNState] = None
+    gram: Optional[Tuple[torch.Tensor, torch.Tensor]] = None  # (a^T a, sum a) of the normalised operand, fp32/fp64
 
 
 @dataclass
@@ -195,6 +196,9 @@ class Engine:
         self.fold_bn3 = os.environ.get("MSFWSI_FOLD_BN3", "1") != "0"
         # ... and the closing ReLU gate of a folded block applied by the producer of its output gradient
         self.fuse_gate = os.environ.get("MSFWSI_FUSE_GATE", "1") != "0"
+        # forward of conv3 -> bn3 -> += identity -> relu in ONE conv launch: bn3's batch statistics come from the
+        # Gram matrix of conv3's operand (sum c3 = W sum(a2), sum c3^2 = diag(W (a2^T a2) W^T)), c3 never exists
+        self.fold_bn3_fwd = os.environ.get("MSFWSI_FOLD_BN3_FWD", "1") != "0"
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ---- configuration ---------------------------------------------------------------------
@@ -298,6 +302,39 @@ class Engine:
             u.st = self._bn_finalize(stats, N * d.P * d.Q, bn)
         return u
 
+    def _conv_bn_res_fwd(self, conv: nn.Module, bn: nn.Module, c_in: torch.Tensor, pro: BNState, ident: torch.Tensor,
+                         geom, dtype: torch.dtype):
+        """y = relu(bn(conv1x1(a)) + ident), a = relu(pro(c_in)), without the conv output c = W a ever reaching HBM
+        (src/models/resnet.py:131-138 for a Bottleneck without downsample).  BatchNorm's batch statistics are
+        quadratic in c and follow from the operand alone:
+            sum_p c[k]   = W[k,:] . sum_p a            sum_p c[k]^2 = W[k,:] (a^T a) W[k,:]^T
+        so: one pass over a for its Gram matrix (a weight-gradient launch, 1/4 of the conv's FLOPs), tiny [K][C]
+        algebra, then the conv with BatchNorm apply + residual + ReLU in its epilogue.  The Gram matrix and the
+        column sums are kept: the folded backward (_block_end_folded) needs exactly them."""
+        N, H, W, Cw = geom
+        K = conv.out_channels
+        dev = c_in.device
+        d = kn.conv_desc(dtype, N, H, W, Cw, K, 1, 1, 1, 0)
+        a = torch.empty_like(c_in)
+        sa = kn.zeros((Cw,), torch.float64, dev)
+        kn.bn_act_sum(c_in, pro.scale, pro.shift, a, sa)
+        dsq = kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0)
+        A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
+        kn.conv_wgrad(dsq, a, a, A)
+        w = self.weights.get(conv.weight, dtype)
+        Wq = w if dtype == torch.float32 else w.float()  # the values the MFMA multiplies
+        dlin = kn.conv_desc(torch.float32, K, 1, 1, Cw, Cw, 1, 1, 1, 0)
+        WA = torch.empty(K, 1, 1, Cw, dtype=torch.float32, device=dev)
+        kn.conv_fwd(dlin, Wq, A, WA)  # A is symmetric
+        stats = kn.zeros((1, 2, K), torch.float64, dev)
+        kn.fold_matvec(Wq, sa, stats[0, 0])
+        kn.fold_dots(Wq, WA, stats[0, 1])
+        st = self._bn_finalize(stats, N * H * W, bn)
+        y = torch.empty(N, H, W, K, dtype=dtype, device=dev)
+        kn.conv_fwd_post(d, a, w, y, st.scale, st.shift, ident=ident, relu=True)
+        u = Unit(conv, bn, False, d, c_in, pro, None, st, gram=(A, sa))
+        return u, y
+
     def _normalised_operand(self, u: Unit) -> torch.Tensor:
         """relu(bn(x)) of a unit's operand as a transient tensor (one streaming pass)"""
         xm = torch.empty_like(u.x)
@@ -372,12 +409,24 @@ class Engine:
                 units: List[Unit] = []
                 cur, cur_pro, gh, gw = y, None, h, w
                 main = blk.main_branch()
-                for ui, (conv, bn) in enumerate(main):
+                conv3 = main[-1][0]
+                fused_tail = (self.fold_bn3_fwd and len(main) == 3 and blk.downsample is None
+                              and conv3.kernel_size == (1, 1) and conv3.stride == (1, 1) and conv3.bias is None)
+                for ui, (conv, bn) in enumerate(main[:-1] if fused_tail else main):
                     u = self._unit_fwd(conv, bn, ui + 1 < len(main), cur, cur_pro, (N, gh, gw, cur.shape[-1]), dtype)
                     units.append(u)
                     cur, cur_pro, gh, gw = u.c, u.st, u.desc.P, u.desc.Q
-                last = units[-1]
                 ds = None
+                if fused_tail:
+                    u, y_out = self._conv_bn_res_fwd(conv3, main[-1][1], cur, cur_pro, y, (N, gh, gw, cur.shape[-1]),
+                                                     dtype)
+                    units.append(u)
+                    last = u
+                    if save:
+                        blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1))
+                    y, h, w = y_out, gh, gw
+                    continue
+                last = units[-1]
                 y_out = torch.empty_like(last.c)
                 if blk.downsample is not None:
                     ds = self._unit_fwd(blk.downsample[0], blk.downsample[1], False, y, None, (N, h, w, cin), dtype)
@@ -509,15 +558,21 @@ class Engine:
             sums = kn.new_stats(K, 3, dev)
             kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, None, rec.ds.c if rec.ds is not None else None, g,
                              sums, rec.HW)
-        a2 = torch.empty_like(last.x)  # relu(bn2(c2)) and its column sums in one pass
-        sa = kn.zeros((Cw,), torch.float64, dev)
-        kn.bn_act_sum(last.x, last.x_pro.scale, last.x_pro.shift, a2, sa)
+        a2 = torch.empty_like(last.x)
+        if last.gram is not None:  # Gram matrix and column sums of a2 kept by the fused forward
+            A, sa = last.gram
+            kn.bn_act(last.x, last.x_pro.scale, last.x_pro.shift, a2, relu=True)
+        else:  # relu(bn2(c2)) and its column sums in one pass
+            A = None
+            sa = kn.zeros((Cw,), torch.float64, dev)
+            kn.bn_act_sum(last.x, last.x_pro.scale, last.x_pro.shift, a2, sa)
         W = WeightStore.physical(last.op.weight).view(K, 1, 1, Cw)
         Mm = kn.zeros((K, 1, 1, Cw), torch.float32, dev)
         kn.conv_wgrad(d, a2, g, Mm)
         dsq = kn.conv_desc(dtype, d.N, d.P, d.Q, Cw, Cw, 1, 1, 1, 0)
-        A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
-        kn.conv_wgrad(dsq, a2, a2, A)
+        if A is None:
+            A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
+            kn.conv_wgrad(dsq, a2, a2, A)
         kn.fold_dots(W, Mm, sums[0, 1])  # slot 1 of shard 0; the other shards of that slot stay zero
         k = self._bn_bwd_coeffs(sums, ns, 1, last.bn, last.st, grads)
         kd = self._bn_bwd_coeffs(sums, 3, 2, rec.ds.bn, rec.ds.st, grads) if rec.ds is not None else None

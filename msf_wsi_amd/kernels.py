@@ -181,6 +181,34 @@ def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
     return y
 
 
+def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu=True):
+    """y = [relu](round(conv(x, w)) * post_scale + post_shift + ident): conv with its consumer BatchNorm (statistics
+    known beforehand), the residual add and the ReLU in the epilogue"""
+    lib = _lib.load()
+    dt = x.dtype
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(w, "w", dt, d.K * d.R * d.S * d.C)
+    _req(y, "y", dt, d.N * d.P * d.Q * d.K)
+    _req(post_scale, "post_scale", torch.float32, d.K)
+    _req(post_shift, "post_shift", torch.float32, d.K)
+    _opt(ident, "ident", dt, d.N * d.P * d.Q * d.K)
+    _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
+        lib.msfwsi_conv_fwd_post(C.byref(d), _p(x), _p(w), _p(y), _p(post_scale), _p(post_shift), _p(ident),
+                                 int(bool(relu)), _stream()), "conv_fwd_post"))
+    return y
+
+
+def fold_matvec(W, v, out):
+    """out[k] = sum_c W[k][c] * v[c]   (fp64)"""
+    lib = _lib.load()
+    K = out.numel()
+    Cn = v.numel()
+    _req(W, "W", torch.float32, K * Cn)
+    _req(v, "v", torch.float64, Cn)
+    _req(out, "out", torch.float64, K)
+    _lib.check(lib.msfwsi_fold_matvec(_p(W), _p(v), _p(out), K, Cn, _stream()), "fold_matvec")
+
+
 def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mask=None, sums=None):
     """mask = (c, scale, shift) of the activation that produced the conv input: fuses its ReLU gate and the
     BatchNorm-backward sums {sum g, sum g*c} (-> sums [nshard,2,C]) into the epilogue."""

@@ -78,6 +78,49 @@ def test_conv_fwd(hip_lib, dt, geom, pro):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(2, 14, 14, 64, 256, 1, 1, 0), (3, 7, 7, 128, 200, 1, 1, 0), (2, 9, 9, 32, 64, 3, 1, 1)])
+@pytest.mark.parametrize("with_ident", [True, False])
+def test_conv_fwd_post(hip_lib, dt, geom, with_ident):
+    """conv with the consumer's BatchNorm apply + residual + ReLU in the epilogue (Bottleneck tail, resnet.py:131-138)
+    and the Gram-matrix route to that BatchNorm's batch statistics (fold_matvec / fold_dots)"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K, R, st, pad = geom
+    g = torch.Generator().manual_seed(11)
+    x = F.relu(rnd((N, Cc, H, W), dt, g) + 0.3).to(dt).float()
+    w = rnd((K, Cc, R, R), dt, g, 1.0 / math.sqrt(Cc * R * R))
+    ps, pb = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    d = kn.conv_desc(dt, N, H, W, Cc, K, R, R, st, pad)
+    ident = rnd((N, K, d.P, d.Q), dt, g)
+    c = F.conv2d(x.double(), w.double(), stride=st, padding=pad)
+    ref = c.float().to(dt).double() * ps.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1)
+    if with_ident:
+        ref = ref + ident.double()
+    ref = F.relu(ref).float()
+    y = torch.empty(N, d.P, d.Q, K, dtype=dt, device="cuda")
+    xd, wd = nhwc(x).to(dt).cuda(), nhwc(w).to(dt).cuda()
+    kn.conv_fwd_post(d, xd, wd, y, ps.cuda(), pb.cuda(), ident=nhwc(ident).to(dt).cuda() if with_ident else None)
+    torch.cuda.synchronize()
+    assert rel(y.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt)
+    if R == 1:  # statistics of c = W a from the Gram matrix of a
+        A = torch.zeros(Cc, 1, 1, Cc, device="cuda")
+        dsq = kn.conv_desc(dt, N, H, W, Cc, Cc, 1, 1, 1, 0)
+        kn.conv_wgrad(dsq, xd, xd, A)
+        sa = torch.zeros(Cc, dtype=torch.float64, device="cuda")
+        kn.colsum(xd, sa)
+        Wq = wd.float()
+        WA = torch.empty(K, 1, 1, Cc, device="cuda")
+        kn.conv_fwd(kn.conv_desc(torch.float32, K, 1, 1, Cc, Cc, 1, 1, 1, 0), Wq, A, WA)
+        s = torch.zeros(2, K, dtype=torch.float64, device="cuda")
+        kn.fold_matvec(Wq, sa, s[0])
+        kn.fold_dots(Wq, WA, s[1])
+        torch.cuda.synchronize()
+        cc = c.permute(0, 2, 3, 1).reshape(-1, K)
+        assert torch.allclose(s[0].cpu(), cc.sum(0), rtol=1e-5, atol=1e-4)
+        assert torch.allclose(s[1].cpu(), (cc * cc).sum(0), rtol=2e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", CONVS)
 def test_conv_dgrad(hip_lib, dt, geom):
     from msf_wsi_amd import kernels as kn
