@@ -26,13 +26,15 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = {"resnet18": 363.37e9, "resnet50": 848.8e9}  # SURVEY.md 8(d), fwd+bwd per tile pair
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of `family` from the committed PMC summary (separate rocprofv3 --pmc passes)"""
+def pmc_traffic(symbol):
+    """L2-miss (fabric) bytes per launch of the kernel whose mangled name contains `symbol`, from the committed PMC
+    summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, scratch/pmc_summary.py)"""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as f:
-            fam = json.load(f)["families"].get(family)
-        return None if fam is None else round(fam["hbm_bytes_per_launch"])
+            tab = json.load(f).get("kernels", {})
+        hit = [v for k, v in tab.items() if symbol in k]
+        return round(hit[0]["hbm_bytes_per_launch"]) if hit else None
     except (OSError, ValueError, KeyError):
         return None
 
@@ -167,26 +169,32 @@ def main():
                        "step_TFLOPs_algorithmic": round(FLOP_PER_PAIR.get(args.arch, 0) * pairs / dt / 1e12, 1)},
         }
         if timer is not None:
-            summ = timer.summary()
-            dom = max(summ, key=lambda k: summ[k]["seconds"])
+            fam = timer.summary()
+            summ = timer.summary(by_symbol=True)
+            dom = max(summ, key=lambda k: summ[k]["seconds"])  # the kernel (template instance) with the most time
             s = summ[dom]
             tf = s["flops"] / s["seconds"] / 1e12
             gbs = s["bytes"] / s["seconds"] / 1e9
             frac_m, frac_h = tf / PEAK_TFLOPS[args.dtype], gbs / PEAK_HBM_GBS
             bound = "mfma" if frac_m >= frac_h else "hbm"
             out["roofline"] = {
-                "kernel": dom, "bound": bound,
+                "kernel": dom, "family": s["family"], "bound": bound,
                 "achieved": round(tf if bound == "mfma" else gbs, 2),
                 "peak": PEAK_TFLOPS[args.dtype] if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                 "frac": round(max(frac_m, frac_h), 4), "traffic": pmc_traffic(dom),
                 "launches": s["launches"], "avg_launch_ms": round(1e3 * s["seconds"] / s["launches"], 4),
+                "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                 "alt": {"TFLOP/s": round(tf, 2), "frac_mfma": round(frac_m, 4), "GB/s": round(gbs, 1),
                         "frac_hbm": round(frac_h, 4)},
+                "kernels": {k: {"launches": v["launches"], "ms": round(1e3 * v["seconds"], 2),
+                                "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 2),
+                                "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)}
+                            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:8]},
                 "families": {k: {"launches": v["launches"], "ms": round(1e3 * v["seconds"], 2),
                                  "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 2),
-                                 "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in summ.items()},
-                "timed_fraction_of_step": round(sum(v["seconds"] for v in summ.values()) / dt, 3),
+                                 "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in fam.items()},
+                "timed_fraction_of_step": round(sum(v["seconds"] for v in fam.values()) / dt, 3),
             }
         if world == 1 and not args.no_cpu_baseline:
             del ts, model, batch

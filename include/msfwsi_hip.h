@@ -78,7 +78,7 @@ int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* 
                          int nshard, void* stream);
 
 /* dw[K][R][S][C] (fp32) += dy^T * act(x)   (weight gradient, split over pixels, fp32 atomics).
- * target_blocks: workgroup budget used to pick the split factor (<=0: default).
+ * target_blocks: workgroup budget used to pick the split factor (<=0: the workgroups resident on the device at once).
  * Replaces: convolution_backward(weight) / linear backward(weight), tools/ssl_train.py:472. */
 int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* pro_scale,
                       const float* pro_shift, int target_blocks, void* stream);

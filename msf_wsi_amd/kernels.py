@@ -7,6 +7,7 @@ include/msfwsi_hip.h.  Nothing here computes on the CPU or through torch operato
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -123,35 +124,76 @@ class KernelTimer:
     bytes (each operand / result tensor counted once) next to the event pair."""
 
     def __init__(self):
-        self.records = []  # (kind, flops, bytes, ev0, ev1)
+        self.records = []  # (kind, symbol, flops, bytes, ev0, ev1)
 
-    def summary(self):
+    def summary(self, by_symbol: bool = False):
+        """per kernel family (conv_fwd / conv_dgrad / conv_wgrad) or, by_symbol, per kernel symbol (the template
+        instance the C side dispatches to -- the name rocprofv3 --kernel-trace --stats reports)"""
         torch.cuda.synchronize()
         agg = {}
-        for kind, fl, by, e0, e1 in self.records:
-            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
+        for kind, sym, fl, by, e0, e1 in self.records:
+            a = agg.setdefault(sym if by_symbol else kind, [0, 0.0, 0.0, 0.0, kind])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += fl
             a[3] += by
-        return {k: {"launches": v[0], "seconds": v[1], "flops": v[2], "bytes": v[3]} for k, v in agg.items()}
+        return {k: {"launches": v[0], "seconds": v[1], "flops": v[2], "bytes": v[3], "family": v[4]}
+                for k, v in agg.items()}
 
 
 TIMER: Optional[KernelTimer] = None
 
 
-def _timed(kind, d: ConvDesc, esize: int, fn):
+_TCODE = {4: "f", 2: "DF16b"}  # Itanium codes of float / __bf16 (fp16 "DF16_" is set by the caller's dtype)
+BIG_TILE_MIN_BLOCKS = int(os.environ.get("MSFWSI_BIG_TILE_MIN_BLOCKS", "1024"))
+
+
+def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False) -> str:
+    """The mangled template-instance fragment of the kernel this launch reaches; mirrors dispatch_tile() /
+    launch_igemm() (csrc/igemm.hip), msfwsi_conv_wgrad() (csrc/wgrad.hip) and conv3x3.hip.  Only used to label
+    timings so that bench.py's roofline names the same kernel as the rocprofv3 summary."""
+    es = 4 if tcode == "f" else 2
+    bk = 16 if es == 4 else 32
+    if kind == "conv_wgrad":
+        bi = 64 if d.K <= 64 else 128
+        bj = 64 if d.R * d.S * d.C <= 64 else 128
+        lin = (not pro and os.environ.get("MSFWSI_WGRAD_LIN", "1") != "0" and d.stride == 1 and d.P == d.H
+               and d.Q == d.W and d.pad <= 1 and d.R <= 3 and d.S <= 3 and d.R == 2 * d.pad + 1 and d.S == 2 * d.pad + 1)
+        return f"wgrad_kernelI{tcode}Li{bi}ELi{bj}ELb{int(pro)}ELb{int(lin)}E"
+    dgrad = kind == "conv_dgrad"
+    if halo:
+        bn = 64 if (d.C if dgrad else d.K) <= 64 else 128
+        return f"conv3x3_kernelI{tcode}Li{bn}ELb{int(dgrad)}E"
+    M = d.N * (d.H * d.W if dgrad else d.P * d.Q)
+    nout, csrc = (d.C, d.K) if dgrad else (d.K, d.C)
+    if nout <= 64:
+        tile = (128, 64, 2, 2)
+    elif not pro and es == 2 and ((M + 255) // 256) * ((nout + 127) // 128) >= BIG_TILE_MIN_BLOCKS:
+        tile = (256, 128, 4, 2)
+    else:
+        tile = (128, 128, 2, 2)
+    t = "Li%dELi%dELi%dELi%dE" % tile
+    if not pro and os.environ.get("MSFWSI_FAST_DMA", "1") != "0" and csrc % bk == 0 and d.R * d.S <= 32:
+        return f"igemm_dma_kernelI{tcode}{t}Lb{int(dgrad)}E"
+    return f"igemm_kernelI{tcode}{t}Lb{int(dgrad)}ELb{int(pro)}E"
+
+
+def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = False, halo: bool = False,
+           dtype=None):
+    """extra_elems: elements of the additional activation-sized operands the launch reads in its epilogue
+    (residual / identity, the gate's activation) -- algorithmic bytes of the fused work, counted once each"""
     if TIMER is None:
         return fn()
     M = d.N * d.P * d.Q
     flops = 2.0 * M * d.K * d.R * d.S * d.C
-    nbytes = float(esize) * (d.N * d.H * d.W * d.C + M * d.K) + float(esize if kind != "conv_wgrad" else 4) * (
-        d.K * d.R * d.S * d.C)
+    nbytes = float(esize) * (d.N * d.H * d.W * d.C + M * d.K + extra_elems) + float(
+        esize if kind != "conv_wgrad" else 4) * (d.K * d.R * d.S * d.C)
+    tcode = "DF16_" if dtype == torch.float16 else _TCODE[esize]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     r = fn()
     e1.record()
-    TIMER.records.append((kind, flops, nbytes, e0, e1))
+    TIMER.records.append((kind, _symbol(kind, d, tcode, pro, halo), flops, nbytes, e0, e1))
     return r
 
 
@@ -177,7 +219,7 @@ def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
             raise ValueError("stats must be [nshard,2,K]")
     _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(ps), _p(psh), _p(bias), _p(stats), nsh, _stream()),
-        "conv_fwd"))
+        "conv_fwd"), pro=pro is not None, dtype=dt)
     return y
 
 
@@ -194,7 +236,8 @@ def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu
     _opt(ident, "ident", dt, d.N * d.P * d.Q * d.K)
     _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_fwd_post(C.byref(d), _p(x), _p(w), _p(y), _p(post_scale), _p(post_shift), _p(ident),
-                                 int(bool(relu)), _stream()), "conv_fwd_post"))
+                                 int(bool(relu)), _stream()), "conv_fwd_post"),
+        extra_elems=ident.numel() if ident is not None else 0, dtype=dt)
     return y
 
 
@@ -234,11 +277,12 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mas
         raise ValueError("sums without mask")
     _timed("conv_dgrad", d, dy.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(gapg), float(gap_scale), _p(mc),
-                              _p(msc), _p(msh), _p(sums), nsh, _stream()), "conv_dgrad"))
+                              _p(msc), _p(msh), _p(sums), nsh, _stream()), "conv_dgrad"),
+        extra_elems=(dx.numel() if resid is not None else 0) + (dx.numel() if mask is not None else 0), dtype=dt)
     return dx
 
 
-def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=1024):
+def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=0):
     lib = _lib.load()
     dt = x.dtype
     _req(x, "x", dt, d.N * d.H * d.W * d.C)
@@ -251,7 +295,7 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=1024):
         _req(psh, "pro_shift", torch.float32, d.C)
     _timed("conv_wgrad", d, x.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ps), _p(psh), int(target_blocks), _stream()),
-        "conv_wgrad"))
+        "conv_wgrad"), pro=pro is not None, dtype=x.dtype)
     return dw
 
 
@@ -585,7 +629,8 @@ def conv3x3_fwd(d: ConvDesc, x, w, y, stats=None):
         if stats.numel() != nsh * 2 * d.K:
             raise ValueError("stats must be [nshard,2,K]")
     _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
-        lib.msfwsi_conv3x3_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(stats), nsh, _stream()), "conv3x3_fwd"))
+        lib.msfwsi_conv3x3_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(stats), nsh, _stream()), "conv3x3_fwd"),
+        halo=True, dtype=x.dtype)
     return y
 
 
@@ -611,5 +656,7 @@ def conv3x3_dgrad(d: ConvDesc, dy, w, dx, resid=None, mask=None, sums=None):
         raise ValueError("sums without mask")
     _timed("conv_dgrad", d, dy.element_size(), lambda: _lib.check(
         lib.msfwsi_conv3x3_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(mc), _p(msc), _p(msh), _p(sums),
-                                 nsh, _stream()), "conv3x3_dgrad"))
+                                 nsh, _stream()), "conv3x3_dgrad"),
+        extra_elems=(dx.numel() if resid is not None else 0) + (dx.numel() if mask is not None else 0), halo=True,
+        dtype=dy.dtype)
     return dx

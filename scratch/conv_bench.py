@@ -73,7 +73,7 @@ for name, H, C, K, R, st, pro in SHAPES:
     else:
         t_f = timeit(lambda: kn.conv_fwd(d, x, w, y, pro=p, stats=stats))
         t_d = timeit(lambda: kn.conv_dgrad(d, dy, w, dx))
-    t_w = timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=p))
+    t_w = timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=p, target_blocks=int(os.environ.get("WG_BLOCKS", "0"))))
     if os.environ.get("FUSED", "0") != "0":
         # the epilogue the engine really uses: residual add + ReLU gate of the producer + BatchNorm-backward sums
         resid = torch.randn_like(dx)

@@ -21,20 +21,31 @@ def family(n):
 
 def load(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
+    ker = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        f = family(r["Kernel_Name"]) or "other"
+        n = r["Kernel_Name"]
+        f = family(n) or "other"
         agg[f][0] += 1
         agg[f][1] += float(r["Counter_Value"])
-    return agg
+        if f != "other":
+            ker[n][0] += 1
+            ker[n][1] += float(r["Counter_Value"])
+    return agg, ker
 
 
-fetch, write = load(sys.argv[1]), load(sys.argv[2])
+(fetch, kf), (write, kw) = load(sys.argv[1]), load(sys.argv[2])
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, python3 bench.py --steps 1 --warmup 1",
-       "note": "bytes = 1024*(2*FETCH_SIZE + WRITE_SIZE); FETCH doubled per the gfx950 correction", "families": {}}
+       "note": "bytes = 1024*(2*FETCH_SIZE + WRITE_SIZE); FETCH doubled per the gfx950 correction; these are L2-miss "
+               "(fabric) bytes: Infinity-Cache hits are included", "families": {}, "kernels": {}}
 for k in fetch:
     n = fetch[k][0]
     fb, wb = 2 * 1024 * fetch[k][1], 1024 * write.get(k, [0, 0.0])[1]
     out["families"][k] = {"launches": n, "fetch_bytes": fb, "write_bytes": wb,
                           "hbm_bytes_per_launch": (fb + wb) / max(1, n)}
+for k in kf:
+    n = kf[k][0]
+    fb, wb = 2 * 1024 * kf[k][1], 1024 * kw.get(k, [0, 0.0])[1]
+    out["kernels"][k] = {"launches": n, "fetch_bytes": fb, "write_bytes": wb,
+                         "hbm_bytes_per_launch": (fb + wb) / max(1, n)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["families"], indent=1))
