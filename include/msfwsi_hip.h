@@ -50,9 +50,10 @@ int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, voi
 /* y = [relu]( round(conv(x, w)) * post_scale[k] + post_shift[k] + ident ): a conv whose consumer BatchNorm
  * statistics are already known (from msfwsi_fold_matvec / msfwsi_fold_dots), so BatchNorm apply, the residual add and
  * the ReLU of src/models/resnet.py:131-138 (bn3 -> += identity -> relu) run in the conv epilogue and the raw conv
- * output never reaches HBM.  ident may be NULL. */
+ * output never reaches HBM.  ident may be NULL.  gate_out (nullable): [N*P*Q][K/vec] bytes, bit e of a byte = (y > 0)
+ * for element e of that 16-byte chunk (vec = 4 fp32 / 8 16-bit) -- the ReLU gate msfwsi_conv_dgrad reads back. */
 int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, const float* post_scale,
-                         const float* post_shift, const void* ident, int relu, void* stream);
+                         const float* post_shift, const void* ident, int relu, unsigned char* gate_out, void* stream);
 
 /* dx = conv_transpose(dy, w) [+ resid] [+ gap_scale * gapg[image]]  (input gradient).  w is the forward
  * weight [K][R][S][C], read in place as the [k][n] operand.  resid: [N,H,W,C] added element-wise (the
@@ -60,11 +61,13 @@ int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, const void* w
  * gradient).  mask_c != NULL fuses the backward of the activation that produced the conv input,
  * a = relu(mask_scale*c + mask_shift): dx is gated by (mask_scale*c + mask_shift > 0) and
  * sums[shard][2][C] += {sum dx, sum dx*c} (what msfwsi_act_bwd_reduce would compute in a second pass).
+ * mask_bits != NULL (instead of mask_c): the gate comes from the bytes msfwsi_conv_fwd_post wrote
+ * ([N*H*W][C/vec]); sums slot 0 += sum dx, slot 1 is left alone.
  * Replaces: autograd's convolution_backward(input) / linear backward(input) (+ threshold_backward and the
  * reduction half of batch_norm_backward) reached through scaler.scale(loss).backward(), ssl_train.py:472. */
 int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx, const void* resid,
                       const void* gapg, float gap_scale, const void* mask_c, const float* mask_scale,
-                      const float* mask_shift, double* sums, int nshard, void* stream);
+                      const float* mask_shift, const unsigned char* mask_bits, double* sums, int nshard, void* stream);
 
 /* Specialised 3x3 / stride 1 / pad 1 path: the input patch of 256 raster pixels (+ halo) is staged once per
  * channel slab in LDS and reused by all nine taps (see csrc/conv3x3.hip).  Same results as msfwsi_conv_fwd /

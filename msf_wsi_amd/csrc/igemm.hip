@@ -49,6 +49,8 @@ struct IgemmParams {
     const float* post_scale; // per output channel, nullable: out = [relu](round(acc)*post_scale + post_shift + resid)
     const float* post_shift;
     int post_relu;
+    unsigned char* gate_out;        // [M][Nout/VEC], nullable: bit e of a byte = (out[m][VEC*chunk+e] > 0)
+    const unsigned char* mask_bits; // same layout, nullable: gates this gradient instead of mask_c (stats = {sum g, 0})
     int N, H, W, C;          // source tensor
     int P, Q, Nout;          // output tensor
     int R, S, stride, pad;
@@ -177,7 +179,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
         }
     }
 
-#pragma unroll 2
+#pragma unroll
     for (int pass = 0; pass < BM / RPP; ++pass) {
         const int row = rr + pass * RPP;
         const int m = m0 + row;
@@ -210,6 +212,14 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                     for (int e = 0; e < VEC; ++e) f[e] = fmaxf(f[e], 0.f);
                 }
                 v = pack16<T>(f);
+                if (prm.gate_out != nullptr) {
+                    // one byte per 16-byte chunk: the ReLU gate of this output for the backward pass (read there
+                    // instead of the 16 bytes of the activation itself)
+                    unsigned b = 0;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
+                    prm.gate_out[(long)m * (prm.Nout / VEC) + (ncol / VEC)] = (unsigned char)b;
+                }
             }
             if (mask_c != nullptr) {
                 // fused backward of the producer's relu(bn(c)): gate, then accumulate {sum g, sum g*c}
@@ -221,6 +231,17 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                     if (!(fmaf(cv[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
                     ssum[e] += f[e];
                     ssq[e] = fmaf(f[e], cv[e], ssq[e]);
+                }
+                v = pack16<T>(f);
+                *reinterpret_cast<uint4*>(out + off) = v;
+            } else if (prm.mask_bits != nullptr) {
+                float f[VEC];
+                unpack16<T>(v, f);
+                const unsigned b = prm.mask_bits[(long)m * (prm.Nout / VEC) + (ncol / VEC)];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (!((b >> e) & 1u)) f[e] = 0.f;
+                    ssum[e] += f[e];
                 }
                 v = pack16<T>(f);
                 *reinterpret_cast<uint4*>(out + off) = v;
@@ -978,7 +999,7 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
 
 extern "C" int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, const void* w, void* y,
                                     const float* post_scale, const float* post_shift, const void* ident, int relu,
-                                    void* stream) {
+                                    unsigned char* gate_out, void* stream) {
     int rc = check_desc(d);
     if (rc != MSFWSI_OK) return rc;
     MSFWSI_CHECK_ARG(x != nullptr && w != nullptr && y != nullptr && post_scale != nullptr && post_shift != nullptr);
@@ -986,6 +1007,7 @@ extern "C" int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, co
     prm.src = x; prm.wgt = w; prm.out = y;
     prm.post_scale = post_scale; prm.post_shift = post_shift; prm.post_relu = relu ? 1 : 0;
     prm.resid = ident;
+    prm.gate_out = gate_out;
     prm.nshard = 1;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C;
     prm.P = d->P; prm.Q = d->Q; prm.Nout = d->K;
@@ -999,17 +1021,19 @@ extern "C" int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, co
 
 extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
                                  const void* resid, const void* gapg, float gap_scale, const void* mask_c,
-                                 const float* mask_scale, const float* mask_shift, double* sums, int nshard,
-                                 void* stream) {
+                                 const float* mask_scale, const float* mask_shift, const unsigned char* mask_bits,
+                                 double* sums, int nshard, void* stream) {
     int rc = check_desc(d);
     if (rc != MSFWSI_OK) return rc;
     MSFWSI_CHECK_ARG(dy != nullptr && w != nullptr && dx != nullptr);
     MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
-    MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
+    MSFWSI_CHECK_ARG(mask_c == nullptr || mask_bits == nullptr);
+    MSFWSI_CHECK_ARG((mask_c == nullptr && mask_bits == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
     IgemmParams prm{};
     prm.src = dy; prm.wgt = w; prm.out = dx;
     prm.resid = resid; prm.gapg = gapg; prm.gap_scale = gap_scale;
     prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
+    prm.mask_bits = mask_bits;
     prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
     // source = dY [N,P,Q,K]; output = dX [N,H,W,C]
     prm.N = d->N; prm.H = d->P; prm.W = d->Q; prm.C = d->K;

@@ -62,6 +62,7 @@ class BlockRec:
     HW: int
     stage: int
     stage_end: bool
+    gate_bits: Optional[torch.Tensor] = None  # (y_out > 0) as one byte per 16-byte chunk (fused tail forward)
 
 
 @dataclass
@@ -199,6 +200,8 @@ class Engine:
         # forward of conv3 -> bn3 -> += identity -> relu in ONE conv launch: bn3's batch statistics come from the
         # Gram matrix of conv3's operand (sum c3 = W sum(a2), sum c3^2 = diag(W (a2^T a2) W^T)), c3 never exists
         self.fold_bn3_fwd = os.environ.get("MSFWSI_FOLD_BN3_FWD", "1") != "0"
+        # ... which also emits the block's closing ReLU gate as one byte per 16-byte chunk for the backward pass
+        self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ---- configuration ---------------------------------------------------------------------
@@ -303,7 +306,7 @@ class Engine:
         return u
 
     def _conv_bn_res_fwd(self, conv: nn.Module, bn: nn.Module, c_in: torch.Tensor, pro: BNState, ident: torch.Tensor,
-                         geom, dtype: torch.dtype):
+                         geom, dtype: torch.dtype, want_bits: bool = False):
         """y = relu(bn(conv1x1(a)) + ident), a = relu(pro(c_in)), without the conv output c = W a ever reaching HBM
         (src/models/resnet.py:131-138 for a Bottleneck without downsample).  BatchNorm's batch statistics are
         quadratic in c and follow from the operand alone:
@@ -331,9 +334,10 @@ class Engine:
         kn.fold_dots(Wq, WA, stats[0, 1])
         st = self._bn_finalize(stats, N * H * W, bn)
         y = torch.empty(N, H, W, K, dtype=dtype, device=dev)
-        kn.conv_fwd_post(d, a, w, y, st.scale, st.shift, ident=ident, relu=True)
+        bits = kn.gate_bytes(N * H * W, K, dtype, dev) if want_bits else None
+        kn.conv_fwd_post(d, a, w, y, st.scale, st.shift, ident=ident, relu=True, gate_out=bits)
         u = Unit(conv, bn, False, d, c_in, pro, None, st, gram=(A, sa))
-        return u, y
+        return u, y, bits
 
     def _normalised_operand(self, u: Unit) -> torch.Tensor:
         """relu(bn(x)) of a unit's operand as a transient tensor (one streaming pass)"""
@@ -367,14 +371,15 @@ class Engine:
             kn.add_f64_to_f32(cs, grads.get(bias), 1.0)
 
     def _unit_dgrad(self, u: Unit, dc: torch.Tensor, dtype: torch.dtype, resid=None, gapg=None, gap_scale=0.0,
-                    mask=None, sums=None):
+                    mask=None, sums=None, mask_bits=None):
         d = u.desc
         dx = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dc.device)
         w = self.weights.get(u.op.weight, dtype)
-        if self.halo3x3 and gapg is None and d.K <= 64 and kn.conv3x3_supported(d):
+        if self.halo3x3 and gapg is None and mask_bits is None and d.K <= 64 and kn.conv3x3_supported(d):
             kn.conv3x3_dgrad(d, dc, w, dx, resid=resid, mask=mask, sums=sums)
         else:
-            kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale, mask=mask, sums=sums)
+            kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale, mask=mask, sums=sums,
+                          mask_bits=mask_bits)
         return dx
 
     # ---- encoder -------------------------------------------------------------------------------
@@ -418,12 +423,13 @@ class Engine:
                     cur, cur_pro, gh, gw = u.c, u.st, u.desc.P, u.desc.Q
                 ds = None
                 if fused_tail:
-                    u, y_out = self._conv_bn_res_fwd(conv3, main[-1][1], cur, cur_pro, y, (N, gh, gw, cur.shape[-1]),
-                                                     dtype)
+                    u, y_out, bits = self._conv_bn_res_fwd(conv3, main[-1][1], cur, cur_pro, y,
+                                                           (N, gh, gw, cur.shape[-1]), dtype,
+                                                           want_bits=save and self.fuse_gate and self.gate_bits)
                     units.append(u)
                     last = u
                     if save:
-                        blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1))
+                        blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1, gate_bits=bits))
                     y, h, w = y_out, gh, gw
                     continue
                 last = units[-1]
@@ -514,7 +520,7 @@ class Engine:
                 if self._foldable(pr) and pr.ds is None:
                     # the producer of pr's output gradient (this block's first conv) applies pr's closing ReLU gate,
                     # adds pr's pooled-feature gradient and reduces sum(g) in its own epilogue
-                    gate = (pr.y_out, dfeats[pr.stage] if pr.stage_end else None, pr.HW)
+                    gate = (pr.y_out, dfeats[pr.stage] if pr.stage_end else None, pr.HW, pr.gate_bits)
             dy, pre = self._block_bwd(rec, dy, gapg, grads, dtype, pre=pre, gate=gate)
             rec.units = []  # release activations
             rec.ds = None
@@ -669,12 +675,16 @@ class Engine:
         self._unit_wgrad(first, cur, grads, dtype)
         if gate is None:
             return self._unit_dgrad(first, cur, dtype, resid=resid), None
-        y_prev, gapg_prev, hw_prev = gate
+        y_prev, gapg_prev, hw_prev, bits_prev = gate
         Cn = y_prev.shape[-1]
-        one, zero = self._unit_gate(Cn, dev)
         sg = kn.new_stats(Cn, 2, dev)
-        dx = self._unit_dgrad(first, cur, dtype, resid=resid, gapg=gapg_prev, gap_scale=1.0 / hw_prev,
-                              mask=(y_prev, one, zero), sums=sg)
+        if bits_prev is not None:  # 1/16 of the bytes of y_prev
+            dx = self._unit_dgrad(first, cur, dtype, resid=resid, gapg=gapg_prev, gap_scale=1.0 / hw_prev,
+                                  mask_bits=bits_prev, sums=sg)
+        else:
+            one, zero = self._unit_gate(Cn, dev)
+            dx = self._unit_dgrad(first, cur, dtype, resid=resid, gapg=gapg_prev, gap_scale=1.0 / hw_prev,
+                                  mask=(y_prev, one, zero), sums=sg)
         return dx, sg
 
     # ---- MLP heads -----------------------------------------------------------------------------

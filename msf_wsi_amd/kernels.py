@@ -223,7 +223,12 @@ def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
     return y
 
 
-def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu=True):
+def gate_bytes(d_or_rows, Cn: int = 0, dtype=None, device="cuda") -> torch.Tensor:
+    """uint8 [rows][C/vec] buffer for the ReLU-gate bits of a [rows][C] activation (vec = 4 fp32 / 8 16-bit)"""
+    return torch.empty(int(d_or_rows), Cn // vec_of(dtype), dtype=torch.uint8, device=device)
+
+
+def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu=True, gate_out=None):
     """y = [relu](round(conv(x, w)) * post_scale + post_shift + ident): conv with its consumer BatchNorm (statistics
     known beforehand), the residual add and the ReLU in the epilogue"""
     lib = _lib.load()
@@ -234,9 +239,10 @@ def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu
     _req(post_scale, "post_scale", torch.float32, d.K)
     _req(post_shift, "post_shift", torch.float32, d.K)
     _opt(ident, "ident", dt, d.N * d.P * d.Q * d.K)
+    _opt(gate_out, "gate_out", torch.uint8, d.N * d.P * d.Q * (d.K // vec_of(dt)))
     _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_fwd_post(C.byref(d), _p(x), _p(w), _p(y), _p(post_scale), _p(post_shift), _p(ident),
-                                 int(bool(relu)), _stream()), "conv_fwd_post"),
+                                 int(bool(relu)), _p(gate_out), _stream()), "conv_fwd_post"),
         extra_elems=ident.numel() if ident is not None else 0, dtype=dt)
     return y
 
@@ -252,9 +258,10 @@ def fold_matvec(W, v, out):
     _lib.check(lib.msfwsi_fold_matvec(_p(W), _p(v), _p(out), K, Cn, _stream()), "fold_matvec")
 
 
-def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mask=None, sums=None):
+def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mask=None, sums=None, mask_bits=None):
     """mask = (c, scale, shift) of the activation that produced the conv input: fuses its ReLU gate and the
-    BatchNorm-backward sums {sum g, sum g*c} (-> sums [nshard,2,C]) into the epilogue."""
+    BatchNorm-backward sums {sum g, sum g*c} (-> sums [nshard,2,C]) into the epilogue.  mask_bits: the gate as
+    the bytes conv_fwd_post wrote (sums slot 0 only)."""
     lib = _lib.load()
     dt = dy.dtype
     _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
@@ -273,12 +280,19 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mas
         nsh = sums.numel() // (2 * d.C)
         if nsh * 2 * d.C != sums.numel():
             raise ValueError("sums must be [nshard,2,C]")
+    elif mask_bits is not None:
+        _req(mask_bits, "mask_bits", torch.uint8, d.N * d.H * d.W * (d.C // vec_of(dt)))
+        _req(sums, "sums", torch.float64)
+        nsh = sums.numel() // (2 * d.C)
+        if nsh * 2 * d.C != sums.numel():
+            raise ValueError("sums must be [nshard,2,C]")
     elif sums is not None:
         raise ValueError("sums without mask")
     _timed("conv_dgrad", d, dy.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(gapg), float(gap_scale), _p(mc),
-                              _p(msc), _p(msh), _p(sums), nsh, _stream()), "conv_dgrad"),
-        extra_elems=(dx.numel() if resid is not None else 0) + (dx.numel() if mask is not None else 0), dtype=dt)
+                              _p(msc), _p(msh), _p(mask_bits), _p(sums), nsh, _stream()), "conv_dgrad"),
+        extra_elems=(dx.numel() if resid is not None else 0) + (dx.numel() if mask is not None else 0)
+        + (dx.numel() // 16 if mask_bits is not None else 0), dtype=dt)
     return dx
 
 

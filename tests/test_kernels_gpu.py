@@ -121,6 +121,39 @@ def test_conv_fwd_post(hip_lib, dt, geom, with_ident):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_gate_bits_roundtrip(hip_lib, dt):
+    """the ReLU gate written as bits by conv_fwd_post gates a later input gradient exactly like the activation"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, Cc, K = 3, 10, 32, 200 if dt == torch.float32 else 208
+    g = torch.Generator().manual_seed(12)
+    x = nhwc(rnd((N, Cc, H, H), dt, g)).to(dt).cuda()
+    w = nhwc(rnd((K, Cc, 1, 1), dt, g, 0.2)).to(dt).cuda()
+    ps, pb = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3).cuda()
+    d = kn.conv_desc(dt, N, H, H, Cc, K, 1, 1, 1, 0)
+    y = torch.empty(N, H, H, K, dtype=dt, device="cuda")
+    bits = kn.gate_bytes(N * H * H, K, dt)
+    kn.conv_fwd_post(d, x, w, y, ps, pb, relu=True, gate_out=bits)
+    vec = 4 if dt == torch.float32 else 8
+    want = (y.reshape(-1, K // vec, vec) > 0).to(torch.int32) * (2 ** torch.arange(vec, device="cuda", dtype=torch.int32))
+    assert torch.equal(bits.to(torch.int32), want.sum(-1))
+    # a 1x1 conv K2 -> K whose input gradient is gated by y: bits vs activation
+    K2 = 64
+    d2 = kn.conv_desc(dt, N, H, H, K, K2, 1, 1, 1, 0)
+    dy = nhwc(rnd((N, K2, H, H), dt, g)).to(dt).cuda()
+    w2 = nhwc(rnd((K2, K, 1, 1), dt, g, 0.2)).to(dt).cuda()
+    resid = nhwc(rnd((N, K, H, H), dt, g)).to(dt).cuda()
+    one, zero = torch.ones(K, device="cuda"), torch.zeros(K, device="cuda")
+    dx_a, dx_b = torch.empty_like(y), torch.empty_like(y)
+    s_a, s_b = kn.new_stats(K), kn.new_stats(K)
+    kn.conv_dgrad(d2, dy, w2, dx_a, resid=resid, mask=(y, one, zero), sums=s_a)
+    kn.conv_dgrad(d2, dy, w2, dx_b, resid=resid, mask_bits=bits, sums=s_b)
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_b)
+    assert torch.allclose(s_a.sum(0)[0], s_b.sum(0)[0], rtol=1e-12, atol=1e-9) and float(s_b.sum(0)[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", CONVS)
 def test_conv_dgrad(hip_lib, dt, geom):
     from msf_wsi_amd import kernels as kn
