@@ -69,6 +69,14 @@ int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, 
                       const void* gapg, float gap_scale, const void* mask_c, const float* mask_scale,
                       const float* mask_shift, const unsigned char* mask_bits, double* sums, int nshard, void* stream);
 
+/* Two-source 1x1 input gradient: dx = gate( dy . w_cat[0:K] + src2 . w_cat[K:K+C2] + bias ), w_cat = [K+C2][C]
+ * (rows K.. are a second [C2][C] matrix), src2 = [N,H,W,C2], bias fp32 [C] nullable, gate / sums as in
+ * msfwsi_conv_dgrad.  One launch for the folded bn3 backward da2 = g (k1 o W) + a2 (W^T diag(k2) W) + W^T k3
+ * (see msfwsi_fold_weights).  MSFWSI_EUNSUPPORTED unless 1x1 / stride 1 with K and C2 multiples of the k slab. */
+int msfwsi_conv_dgrad2(const msfwsi_conv_desc* d, const void* dy, const void* w_cat, void* dx, const void* src2, int C2,
+                       const float* bias, const void* mask_c, const float* mask_scale, const float* mask_shift,
+                       double* sums, int nshard, void* stream);
+
 /* Specialised 3x3 / stride 1 / pad 1 path: the input patch of 256 raster pixels (+ halo) is staged once per
  * channel slab in LDS and reused by all nine taps (see csrc/conv3x3.hip).  Same results as msfwsi_conv_fwd /
  * msfwsi_conv_dgrad without prologue/bias/gapg; `supported` tells whether a geometry qualifies.

@@ -49,6 +49,8 @@ struct IgemmParams {
     const float* post_scale; // per output channel, nullable: out = [relu](round(acc)*post_scale + post_shift + resid)
     const float* post_shift;
     int post_relu;
+    const void* src2;        // DGRAD 1x1 only, nullable: second source [M][C2] whose k-range follows the first
+    int C2;                  //   (out = src . W[0:C] + src2 . W[C:C+C2]; Ktot = C + C2)
     unsigned char* gate_out;        // [M][Nout/VEC], nullable: bit e of a byte = (out[m][VEC*chunk+e] > 0)
     const unsigned char* mask_bits; // same layout, nullable: gates this gradient instead of mask_c (stats = {sum g, 0})
     int N, H, W, C;          // source tensor
@@ -761,6 +763,23 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         a_mask[i] = mask;
         a_voff[i] = (int)(((pix - ref_pix - maxd) * prm.C + kc * VEC) * ES);
     }
+    // optional second source (1x1 input gradient with a concatenated k range)
+    const bool two = DGRAD && prm.src2 != nullptr;
+    const __amdgpu_buffer_rsrc_t srd_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(reinterpret_cast<const T*>(two ? prm.src2 : prm.src)) + ref_pix * (two ? prm.C2 : prm.C), 0,
+        0x7fffffff, 0x00020000);
+    int a_voff2[DGRAD ? A_IT : 1];
+    if (DGRAD) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int row = (i * NW + wave) * 16 + (lane >> 2);
+            const int m = m0 + row;
+            int hb, wb;
+            const long pix = tap0_pixel(m < prm.M ? m : m0, hb, wb);
+            a_voff2[i] = (two && m < prm.M)
+                             ? (int)(((pix - ref_pix - maxd) * prm.C2 + swz(row, lane & 3) * VEC) * ES) : OOB;
+        }
+    }
     int b_voff[NB];
     if (!DGRAD) {
 #pragma unroll
@@ -786,6 +805,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     int soff_tap = 0;
     int voff_eff[A_IT];
     auto fetch = [&](int buf) {
+        if constexpr (DGRAD) {
+            if (two && k0 >= prm.C) {  // second source: channel slab k0 - C of src2, weight rows k0 .. k0+BK
+                char* Ab2 = As + buf * Cfg::A_BYTES + wave * 1024;
+                char* Bb2 = Bs + buf * Cfg::B_BYTES + wave * 1024;
+                const int soff2 = (k0 - prm.C) * ES;
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) dma16_buf(srd_a2, Ab2 + i * NW * 1024, a_voff2[i], soff2);
+                const int soffb2 = (int)((long)k0 * prm.Nout * ES);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) dma16_buf(srd_b, Bb2 + i * NW * 1024, b_voff[i], soffb2);
+                k0 += BK;
+                return;
+            }
+        }
         if (tap_c == 0) {  // new filter tap: which rows have a source pixel, and the tap's scalar shift
             tap_t = tap_r * prm.S + tap_s;
 #pragma unroll
@@ -994,6 +1027,34 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool pro = pro_scale != nullptr;
     MSFWSI_WITH_T(d->dtype, return pro ? dispatch_tile<T, false, true>(prm, st) : dispatch_tile<T, false, false>(prm, st));
+    return MSFWSI_EINVAL;
+}
+
+extern "C" int msfwsi_conv_dgrad2(const msfwsi_conv_desc* d, const void* dy, const void* w_cat, void* dx,
+                                  const void* src2, int C2, const float* bias, const void* mask_c,
+                                  const float* mask_scale, const float* mask_shift, double* sums, int nshard,
+                                  void* stream) {
+    int rc = check_desc(d);
+    if (rc != MSFWSI_OK) return rc;
+    MSFWSI_CHECK_ARG(dy != nullptr && w_cat != nullptr && dx != nullptr && src2 != nullptr && C2 > 0);
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
+    const int bk = d->dtype == MSFWSI_DT_F32 ? 16 : 32;
+    // only the pure-DMA kernel knows the second source: 1x1 / stride 1, whole k slabs in both ranges
+    if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->K % bk != 0 || C2 % bk != 0 || !g_fast_dma)
+        return MSFWSI_EUNSUPPORTED;
+    IgemmParams prm{};
+    prm.src = dy; prm.wgt = w_cat; prm.out = dx;
+    prm.src2 = src2; prm.C2 = C2; prm.bias = bias;
+    prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
+    prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = d->N; prm.H = d->P; prm.W = d->Q; prm.C = d->K;
+    prm.P = d->H; prm.Q = d->W; prm.Nout = d->C;
+    prm.R = 1; prm.S = 1; prm.stride = 1; prm.pad = 0;
+    prm.M = d->N * d->H * d->W;
+    prm.Ktot = d->K + C2;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MSFWSI_WITH_T(d->dtype, return dispatch_tile<T, true, false>(prm, st));
     return MSFWSI_EINVAL;
 }
 

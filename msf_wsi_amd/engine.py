@@ -202,6 +202,7 @@ class Engine:
         self.fold_bn3_fwd = os.environ.get("MSFWSI_FOLD_BN3_FWD", "1") != "0"
         # ... which also emits the block's closing ReLU gate as one byte per 16-byte chunk for the backward pass
         self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
+        self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ---- configuration ---------------------------------------------------------------------
@@ -592,17 +593,19 @@ class Engine:
         kn.fold_weights(W, Mm, WA, k[0], k[1], k[2], sa, grads.get(last.op.weight), Wk1, Wk2, bvec)
         G = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
         kn.conv_wgrad(dlin, W, Wk2, G)  # G[i][j] = sum_k k2[k] W[k][i] W[k][j]
-        if dtype != torch.float32:
-            Gc, Wc = torch.empty_like(G, dtype=dtype), torch.empty_like(Wk1, dtype=dtype)
-            kn.cast_lowp(G, Gc)
-            kn.cast_lowp(Wk1, Wc)
-        else:
-            Gc, Wc = G, Wk1
-        t = torch.empty_like(a2)
-        kn.conv_fwd(dsq, a2, Gc, t, bias=bvec)
         s2 = kn.new_stats(Cw, 2, dev)
         da = torch.empty_like(a2)
-        kn.conv_dgrad(d, g, Wc, da, resid=t, mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2)
+        gate = (prev.c, prev.st.scale, prev.st.shift)
+        # one launch: da2 = gate([g | a2] . [k1 o W ; G] + W^T k3), the k range of a2 follows the one of g
+        wcat32 = torch.cat([Wk1.view(K, Cw), G.view(Cw, Cw)], 0)
+        wcat = wcat32 if dtype == torch.float32 else kn.cast_lowp(wcat32, torch.empty_like(wcat32, dtype=dtype))
+        if self.fuse_two_source and kn.conv_dgrad2(d, g, wcat, da, a2, bias=bvec, mask=gate, sums=s2):
+            return g, da, s2, kd
+        # shapes without a two-source kernel: the a2 term as a separate w -> w conv, added as the residual
+        Wc, Gc = wcat[:K].view(K, 1, 1, Cw), wcat[K:].view(Cw, 1, 1, Cw)
+        t = torch.empty_like(a2)
+        kn.conv_fwd(dsq, a2, Gc, t, bias=bvec)
+        kn.conv_dgrad(d, g, Wc, da, resid=t, mask=gate, sums=s2)
         return g, da, s2, kd
 
     def _block_bwd(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype, pre=None, gate=None):

@@ -296,6 +296,39 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mas
     return dx
 
 
+def conv_dgrad2(d: ConvDesc, dy, w_cat, dx, src2, bias=None, mask=None, sums=None) -> bool:
+    """dx = gate(dy . w_cat[0:K] + src2 . w_cat[K:] + bias) in one launch (1x1 only); False if the library has no
+    kernel for this shape (the caller then adds the second product as a residual)"""
+    lib = _lib.load()
+    dt = dy.dtype
+    C2 = src2.shape[-1]
+    _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
+    _req(w_cat, "w_cat", dt, (d.K + C2) * d.C)
+    _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
+    _req(src2, "src2", dt, d.N * d.H * d.W * C2)
+    _opt(bias, "bias", torch.float32, d.C)
+    mc = msc = msh = None
+    nsh = 1
+    if mask is not None:
+        mc, msc, msh = mask
+        _req(mc, "mask_c", dt, d.N * d.H * d.W * d.C)
+        _req(msc, "mask_scale", torch.float32, d.C)
+        _req(msh, "mask_shift", torch.float32, d.C)
+        _req(sums, "sums", torch.float64)
+        nsh = sums.numel() // (2 * d.C)
+    rc = [0]
+
+    def run():
+        rc[0] = lib.msfwsi_conv_dgrad2(C.byref(d), _p(dy), _p(w_cat), _p(dx), _p(src2), int(C2), _p(bias), _p(mc), _p(msc),
+                                       _p(msh), _p(sums), nsh, _stream())
+        if rc[0] != -2:
+            _lib.check(rc[0], "conv_dgrad2")
+
+    _timed("conv_dgrad", d, dy.element_size(), run,
+           extra_elems=src2.numel() + (dx.numel() if mask is not None else 0), dtype=dt)
+    return rc[0] == 0
+
+
 def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=0):
     lib = _lib.load()
     dt = x.dtype

@@ -74,6 +74,14 @@ for name, H, C, K, R, st, pro in SHAPES:
         t_f = timeit(lambda: kn.conv_fwd(d, x, w, y, pro=p, stats=stats))
         t_d = timeit(lambda: kn.conv_dgrad(d, dy, w, dx))
     t_w = timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=p, target_blocks=int(os.environ.get("WG_BLOCKS", "0"))))
+    if os.environ.get("POST", "0") != "0" and R == 1:
+        ident = torch.randn_like(y)
+        ps, pb = torch.rand(K, device="cuda") + 0.5, torch.randn(K, device="cuda")
+        bits = kn.gate_bytes(M, K, dt)
+        t_p = timeit(lambda: kn.conv_fwd_post(d, x, w, y, ps, pb, ident=ident, relu=True, gate_out=bits))
+        t_p0 = timeit(lambda: kn.conv_fwd_post(d, x, w, y, ps, pb, ident=None, relu=True))
+        byp = 2.0 * (x.numel() + 2 * y.numel())
+        print(f"{name:30s} fwd_post+ident+bits {t_p:7.3f} ms {byp / t_p / 1e6:7.1f} GB/s | fwd_post plain {t_p0:7.3f} ms {by / t_p0 / 1e6:7.1f} GB/s | fwd+stats {t_f:7.3f} ms {by / t_f / 1e6:7.1f} GB/s", flush=True)
     if os.environ.get("FUSED", "0") != "0":
         # the epilogue the engine really uses: residual add + ReLU gate of the producer + BatchNorm-backward sums
         resid = torch.randn_like(dx)

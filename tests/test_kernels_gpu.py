@@ -121,6 +121,41 @@ def test_conv_fwd_post(hip_lib, dt, geom, with_ident):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(3, 10, 256, 64, 64), (2, 7, 512, 128, 128), (1, 5, 64, 32, 32)])
+def test_conv_dgrad2_two_sources(hip_lib, dt, shape):
+    """dx = gate(dy . W1 + src2 . W2 + bias): the two-source 1x1 input gradient of the folded bn3 backward"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, K, Cc, C2 = shape
+    g = torch.Generator().manual_seed(13)
+    dy = rnd((N * H * H, K), dt, g)
+    s2 = rnd((N * H * H, C2), dt, g)
+    W1 = rnd((K, Cc), dt, g, 1.0 / math.sqrt(K))
+    W2 = rnd((C2, Cc), dt, g, 1.0 / math.sqrt(C2))
+    bias = torch.randn(Cc, generator=g) * 0.1
+    c = rnd((N * H * H, Cc), dt, g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    ref = dy.double() @ W1.double() + s2.double() @ W2.double() + bias.double()
+    gate = (c.double() * sc.double() + sh.double()) > 0
+    refg = torch.where(gate, ref.float().to(dt).double(), torch.zeros_like(ref))
+    d = kn.conv_desc(dt, N, H, H, Cc, K, 1, 1, 1, 0)
+    dx = torch.empty(N, H, H, Cc, dtype=dt, device="cuda")
+    sums = kn.new_stats(Cc)
+    wcat = torch.cat([W1, W2], 0).to(dt).cuda()
+    ok = kn.conv_dgrad2(d, dy.to(dt).cuda().view(N, H, H, K), wcat, dx, s2.to(dt).cuda().view(N, H, H, C2),
+                        bias=bias.cuda(), mask=(c.to(dt).cuda().view(N, H, H, Cc), sc.cuda(), sh.cuda()), sums=sums)
+    torch.cuda.synchronize()
+    assert ok
+    got = dx.double().cpu().view(-1, Cc)
+    # gate decisions at |scale*c+shift| ~ 0 may differ between fp64 and the kernel's fp32 fma: compare where clear
+    clear = ((c.double() * sc.double() + sh.double()).abs() > 1e-3)
+    assert rel(torch.where(clear, got, refg), refg) < tol(dt)
+    st = sums.sum(0).cpu()
+    assert torch.allclose(st[0], got.sum(0), rtol=1e-6, atol=1e-4)
+    assert torch.allclose(st[1], (got * c.to(dt).double()).sum(0), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_gate_bits_roundtrip(hip_lib, dt):
     """the ReLU gate written as bits by conv_fwd_post gates a later input gradient exactly like the activation"""
     from msf_wsi_amd import kernels as kn
