@@ -115,10 +115,11 @@ int msfwsi_shard_sum(const double* in, int nshard, int n, double* out, void* str
 int msfwsi_bn_act(int dtype, const void* c, const float* scale, const float* shift, const void* ident,
                   const float* id_scale, const float* id_shift, int relu, void* out, long M, int C, void* stream);
 
-/* msfwsi_bn_act (relu, no identity) that also adds the column sums of its output into sums[C] (fp64): the
- * re-normalised conv3 operand of the folded bn3 backward and its sum in one pass. */
+/* msfwsi_bn_act (relu, no identity) that also adds the column sums of its output into sums[shard][C] (fp64,
+ * nshard replicas: 2048 workgroups adding into ONE replica serialise on 64 addresses for ~300 us): the normalised
+ * conv3 operand of the folded bn3 forward / backward and its sum in one pass. */
 int msfwsi_bn_act_sum(int dtype, const void* c, const float* scale, const float* shift, void* out, double* sums,
-                      long M, int C, void* stream);
+                      int nshard, long M, int C, void* stream);
 
 /* Backward at a residual-block output y = relu(bn(c_main) + identity):
  * g = (dy + gap_scale*gapg[image]) * (y>0); sums[shard][3][C] += {sum g, sum g*c_main, sum g*c_ds}.

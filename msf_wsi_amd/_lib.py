@@ -47,7 +47,7 @@ SIGNATURES = {
     "msfwsi_stem_pool_fwd": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "msfwsi_stem_pool_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "msfwsi_gap_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
-    "msfwsi_bn_act_sum": [_i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
+    "msfwsi_bn_act_sum": [_i, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp],
     "msfwsi_fold_matvec": [_vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_conv_dgrad2": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_conv_fwd_post": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],

@@ -595,8 +595,8 @@ __global__ void colsum_kernel(const T* __restrict__ x, double* sums, long M, int
 // backward needs sum_p a2, see fold_weights_kernel; one pass instead of bn_act + colsum)
 template <typename T>
 __global__ void bn_act_sum_kernel(const T* __restrict__ c, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, T* __restrict__ out, double* sums, long M, int C,
-                                  int cw, int nrl, int rows_per_block) {
+                                  const float* __restrict__ shift, T* __restrict__ out, double* sums, int nshard,
+                                  long M, int C, int cw, int nrl, int rows_per_block) {
     constexpr int VEC = ElemTraits<T>::VEC;
     extern __shared__ float smem_f[];
     const int tid = threadIdx.x;
@@ -640,7 +640,7 @@ __global__ void bn_act_sum_kernel(const T* __restrict__ c, const float* __restri
             }
         }
     }
-    col_commit<1, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, 1);
+    col_commit<1, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -817,13 +817,15 @@ extern "C" int msfwsi_bn_act(int dtype, const void* c, const float* scale, const
 }
 
 extern "C" int msfwsi_bn_act_sum(int dtype, const void* c, const float* scale, const float* shift, void* out,
-                                 double* sums, long M, int C, void* stream) {
-    MSFWSI_CHECK_ARG(dtype_ok(dtype) && c && scale && shift && out && sums && M > 0 && C % vec_of(dtype) == 0);
+                                 double* sums, int nshard, long M, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && c && scale && shift && out && sums && nshard >= 1 && M > 0);
+    MSFWSI_CHECK_ARG(C % vec_of(dtype) == 0);
     const int vec = vec_of(dtype);
     ColGrid cg = make_col_grid(M, C, vec, 2048);
     const size_t lds = (size_t)kThreads * vec * sizeof(float);
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(bn_act_sum_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)c,
-                                            scale, shift, (T*)out, sums, M, C, cg.cw, cg.nrl, cg.rows_per_block));
+                                            scale, shift, (T*)out, sums, nshard, M, C, cg.cw, cg.nrl,
+                                            cg.rows_per_block));
     return msfwsi_launch_status();
 }
 

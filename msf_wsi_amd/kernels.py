@@ -394,7 +394,7 @@ def bn_act(c, scale, shift, out, ident=None, id_scale=None, id_shift=None, relu=
 
 
 def bn_act_sum(c, scale, shift, out, sums):
-    """out = relu(scale*c+shift); sums[C] (fp64) += column sums of out"""
+    """out = relu(scale*c+shift); sums[C] (fp64) = column sums of out"""
     lib = _lib.load()
     Cn = scale.numel()
     M = c.numel() // Cn
@@ -403,8 +403,11 @@ def bn_act_sum(c, scale, shift, out, sums):
     _req(scale, "scale", torch.float32, Cn)
     _req(shift, "shift", torch.float32, Cn)
     _req(sums, "sums", torch.float64, Cn)
-    _lib.check(lib.msfwsi_bn_act_sum(dt_of(c), _p(c), _p(scale), _p(shift), _p(out), _p(sums), M, Cn, _stream()),
-               "bn_act_sum")
+    # sharded accumulation (one replica would serialise ~2000 workgroups on C addresses), then one tiny reduction
+    part = ARENA.zeros((NSHARD, 1, Cn), torch.float64, c.device)
+    _lib.check(lib.msfwsi_bn_act_sum(dt_of(c), _p(c), _p(scale), _p(shift), _p(out), _p(part), NSHARD, M, Cn,
+                                     _stream()), "bn_act_sum")
+    shard_sum(part, sums)
     return out
 
 

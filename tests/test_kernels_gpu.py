@@ -156,6 +156,24 @@ def test_conv_dgrad2_two_sources(hip_lib, dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(5000, 64), (333, 256), (70, 2048)])
+def test_bn_act_sum(hip_lib, dt, shape):
+    from msf_wsi_amd import kernels as kn
+
+    M, Cc = shape
+    g = torch.Generator().manual_seed(14)
+    c = rnd((M, Cc), dt, g)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3
+    ref = F.relu(c * sc + sh).to(dt)
+    out = torch.empty(M, Cc, dtype=dt, device="cuda")
+    sa = torch.zeros(Cc, dtype=torch.float64, device="cuda")
+    kn.bn_act_sum(c.to(dt).cuda(), sc.cuda(), sh.cuda(), out, sa)
+    torch.cuda.synchronize()
+    assert rel(out.float().cpu(), ref.float()) < (1e-6 if dt == torch.float32 else tol(dt))
+    assert torch.allclose(sa.cpu(), out.double().cpu().sum(0), rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_gate_bits_roundtrip(hip_lib, dt):
     """the ReLU gate written as bits by conv_fwd_post gates a later input gradient exactly like the activation"""
     from msf_wsi_amd import kernels as kn
