@@ -116,9 +116,13 @@ __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 2) & 3)
 
 // Shared epilogue: accumulators -> LDS tile (storage type) -> coalesced 16-byte row chunks, with the optional
 // bias / residual / pooled-gradient adds, the fused ReLU gate and the per-channel statistics.
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, typename Acc>
+// EPI selects which epilogue features are COMPILED IN (the others cost SGPRs/VGPRs even when unused: with all of
+// them the input-gradient kernels spilled scalars): 0 = statistics / residual / pooled gradient / ReLU gate,
+// 1 = consumer BatchNorm apply + identity + ReLU + gate bits (msfwsi_conv_fwd_post), 2 = everything (generic kernel)
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, int EPI, typename Acc>
 __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, const IgemmParams& prm, char* smem,
                                                int tile_m, int m0, int n0) {
+    constexpr bool STD = EPI != 1, POST = EPI != 0;
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
     constexpr int VEC = Cfg::VEC, TM = Cfg::TM, TN = Cfg::TN, NW = Cfg::NW, NT = 64 * Cfg::NW, LDC = Cfg::LDC;
     T* Cs = reinterpret_cast<T*>(smem);                             // [BM][LDC]
@@ -164,12 +168,18 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
     float ssum[VEC], ssq[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
-    const T* __restrict__ mask_c = reinterpret_cast<const T*>(prm.mask_c);
+    const T* __restrict__ mask_c = STD ? reinterpret_cast<const T*>(prm.mask_c) : nullptr;
+    const float* post_scale = POST ? prm.post_scale : nullptr;
+    const T* gapg = STD ? reinterpret_cast<const T*>(prm.gapg) : nullptr;
+    const unsigned char* mask_bits = STD ? prm.mask_bits : nullptr;
+    unsigned char* gate_out = POST ? prm.gate_out : nullptr;
+    double* stats = STD ? prm.stats : nullptr;
+    const int post_relu = POST ? prm.post_relu : 0;
     float msc[VEC], msh[VEC], psc[VEC], psh[VEC];
-    if (prm.post_scale != nullptr && col_ok) {
+    if (post_scale != nullptr && col_ok) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            psc[e] = prm.post_scale[ncol + e];
+            psc[e] = post_scale[ncol + e];
             psh[e] = prm.post_shift[ncol + e];
         }
     }
@@ -181,17 +191,17 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
         }
     }
 
-#pragma unroll
+#pragma unroll 2
     for (int pass = 0; pass < BM / RPP; ++pass) {
         const int row = rr + pass * RPP;
         const int m = m0 + row;
         if (m < prm.M && col_ok) {
             uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
             const long off = (long)m * prm.Nout + ncol;
-            if (resid != nullptr || prm.gapg != nullptr || prm.post_scale != nullptr) {
+            if (resid != nullptr || gapg != nullptr || post_scale != nullptr) {
                 float f[VEC];
                 unpack16<T>(v, f);
-                if (prm.post_scale != nullptr) {
+                if (post_scale != nullptr) {
                     // fused BatchNorm apply of the consumer (statistics known beforehand, see conv_fwd_post)
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] = fmaf(f[e], psc[e], psh[e]);
@@ -202,25 +212,24 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] += g[e];
                 }
-                if (prm.gapg != nullptr) {
+                if (gapg != nullptr) {
                     float gp[VEC];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) +
-                                                                (long)(m / PQ) * prm.Nout + ncol), gp);
+                    unpack16<T>(*reinterpret_cast<const uint4*>(gapg + (long)(m / PQ) * prm.Nout + ncol), gp);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
                 }
-                if (prm.post_relu) {
+                if (post_relu) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] = fmaxf(f[e], 0.f);
                 }
                 v = pack16<T>(f);
-                if (prm.gate_out != nullptr) {
+                if (gate_out != nullptr) {
                     // one byte per 16-byte chunk: the ReLU gate of this output for the backward pass (read there
                     // instead of the 16 bytes of the activation itself)
                     unsigned b = 0;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
-                    prm.gate_out[(long)m * (prm.Nout / VEC) + (ncol / VEC)] = (unsigned char)b;
+                    gate_out[(long)m * (prm.Nout / VEC) + (ncol / VEC)] = (unsigned char)b;
                 }
             }
             if (mask_c != nullptr) {
@@ -236,10 +245,10 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 }
                 v = pack16<T>(f);
                 *reinterpret_cast<uint4*>(out + off) = v;
-            } else if (prm.mask_bits != nullptr) {
+            } else if (mask_bits != nullptr) {
                 float f[VEC];
                 unpack16<T>(v, f);
-                const unsigned b = prm.mask_bits[(long)m * (prm.Nout / VEC) + (ncol / VEC)];
+                const unsigned b = mask_bits[(long)m * (prm.Nout / VEC) + (ncol / VEC)];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     if (!((b >> e) & 1u)) f[e] = 0.f;
@@ -249,7 +258,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 *reinterpret_cast<uint4*>(out + off) = v;
             } else {
                 *reinterpret_cast<uint4*>(out + off) = v;
-                if (prm.stats != nullptr) {
+                if (stats != nullptr) {
                     float f[VEC];
                     unpack16<T>(v, f);
 #pragma unroll
@@ -262,7 +271,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
         }
     }
 
-    if (prm.stats != nullptr) {
+    if (stats != nullptr) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
 #pragma unroll
@@ -285,7 +294,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 float t = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) t += red[(w * BN + col) * 2 + which];
-                double* dst = prm.stats + ((long)(tile_m % prm.nshard) * 2 + which) * prm.Nout + n0 + col;
+                double* dst = stats + ((long)(tile_m % prm.nshard) * 2 + which) * prm.Nout + n0 + col;
                 atomicAdd(dst, (double)t);
             }
         }
@@ -657,7 +666,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
         }
     }
 
-    igemm_epilogue<T, BM, BN, WM, WN, DGRAD, APRO>(acc, prm, smem, tile_m, m0, n0);
+    igemm_epilogue<T, BM, BN, WM, WN, DGRAD, APRO, 2>(acc, prm, smem, tile_m, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -674,8 +683,9 @@ __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds
                                              soff, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD>
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, int EPI = 0, bool TWO = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams prm) {
+    static_assert(!(TWO && !DGRAD) && !(DGRAD && EPI != 0), "second source: input gradient; post epilogue: forward");
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, false> Cfg;
     constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
@@ -733,6 +743,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     // ---- per-lane constants: group g = it*NW + wave covers operand rows 16g .. 16g+15; lane l owns the LDS
     // bytes [16g*64 + 16*l, +16) = row 16g + l/4, slot l%4, and fetches the logical chunk slot ^ swizzle(row)
     int a_voff[A_IT];
+    int a_voff2[TWO ? A_IT : 1];
     unsigned a_mask[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -762,24 +773,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
             }
         a_mask[i] = mask;
         a_voff[i] = (int)(((pix - ref_pix - maxd) * prm.C + kc * VEC) * ES);
-    }
-    // optional second source (1x1 input gradient with a concatenated k range)
-    const bool two = DGRAD && prm.src2 != nullptr;
-    const __amdgpu_buffer_rsrc_t srd_a2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(reinterpret_cast<const T*>(two ? prm.src2 : prm.src)) + ref_pix * (two ? prm.C2 : prm.C), 0,
-        0x7fffffff, 0x00020000);
-    int a_voff2[DGRAD ? A_IT : 1];
-    if (DGRAD) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int row = (i * NW + wave) * 16 + (lane >> 2);
-            const int m = m0 + row;
-            int hb, wb;
-            const long pix = tap0_pixel(m < prm.M ? m : m0, hb, wb);
-            a_voff2[i] = (two && m < prm.M)
-                             ? (int)(((pix - ref_pix - maxd) * prm.C2 + swz(row, lane & 3) * VEC) * ES) : OOB;
+        if constexpr (TWO) {  // second source (two-source 1x1 input gradient): same pixel, its own row pitch
+            a_voff2[i] = rowok ? (int)(((pix - ref_pix - maxd) * prm.C2 + kc * VEC) * ES) : OOB;
         }
     }
+    // optional second source (1x1 input gradient with a concatenated k range)
+    const __amdgpu_buffer_rsrc_t srd_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(reinterpret_cast<const T*>(TWO ? prm.src2 : prm.src)) + ref_pix * (TWO ? prm.C2 : prm.C), 0,
+        0x7fffffff, 0x00020000);
     int b_voff[NB];
     if (!DGRAD) {
 #pragma unroll
@@ -805,8 +806,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     int soff_tap = 0;
     int voff_eff[A_IT];
     auto fetch = [&](int buf) {
-        if constexpr (DGRAD) {
-            if (two && k0 >= prm.C) {  // second source: channel slab k0 - C of src2, weight rows k0 .. k0+BK
+        if constexpr (TWO) {
+            if (k0 >= prm.C) {  // second source: channel slab k0 - C of src2, weight rows k0 .. k0+BK
                 char* Ab2 = As + buf * Cfg::A_BYTES + wave * 1024;
                 char* Bb2 = Bs + buf * Cfg::B_BYTES + wave * 1024;
                 const int soff2 = (k0 - prm.C) * ES;
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         st_f = st_f == 2 ? 0 : st_f + 1;
     }
     __syncthreads();
-    igemm_epilogue<T, BM, BN, WM, WN, DGRAD, false>(acc, prm, smem, tile_m, m0, n0);
+    igemm_epilogue<T, BM, BN, WM, WN, DGRAD, false, EPI>(acc, prm, smem, tile_m, m0, n0);
 }
 
 long g_fast_dma = 1;  // tunable through msfwsi_set_tuning(1, .): 0 = always the generic kernel
@@ -937,9 +938,20 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
     if (nblk <= 0 || nblk > 0x7fffffffL) return MSFWSI_EINVAL;
     // pure-DMA fast kernel when no BatchNorm prologue is applied and a k-slab never straddles two filter taps
     void (*kern)(const IgemmParams) = igemm_kernel<T, BM, BN, WM, WN, DGRAD, APRO>;
+    bool dma = false;
     if constexpr (!APRO) {
-        if (g_fast_dma && prm.C % Cfg::BK == 0 && prm.R * prm.S <= 32) kern = igemm_dma_kernel<T, BM, BN, WM, WN, DGRAD>;
+        if (g_fast_dma && prm.C % Cfg::BK == 0 && prm.R * prm.S <= 32) {
+            dma = true;
+            if constexpr (DGRAD) {
+                kern = prm.src2 != nullptr ? igemm_dma_kernel<T, BM, BN, WM, WN, true, 0, true>
+                                           : igemm_dma_kernel<T, BM, BN, WM, WN, true, 0, false>;
+            } else {
+                kern = prm.post_scale != nullptr ? igemm_dma_kernel<T, BM, BN, WM, WN, false, 1, false>
+                                                 : igemm_dma_kernel<T, BM, BN, WM, WN, false, 0, false>;
+            }
+        }
     }
+    if (prm.src2 != nullptr && !dma) return MSFWSI_EUNSUPPORTED;  // only the pure-DMA kernel has the second source
     if (Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
