@@ -69,6 +69,14 @@ int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, 
                       const void* gapg, float gap_scale, const void* mask_c, const float* mask_scale,
                       const float* mask_shift, const unsigned char* mask_bits, double* sums, int nshard, void* stream);
 
+/* Stem convolution (7x7 / stride 2 on 3 channels, src/models/resnet.py:174,234) on the pure-DMA kernel: x is
+ * [N,H,W,CP] with the channels zero-padded to ONE 16-byte chunk (CP = 4 fp32 / 8 16-bit), w_run is
+ * [K][R][run] where run = S*CP rounded up to whole k slabs (32 16-bit / 16 fp32 elements) and the padding columns are
+ * zero: the S taps of a filter row are contiguous in NHWC memory, so a filter row is one tap over `run` channels.
+ * y [N,P,Q,K] raw conv output, stats as in msfwsi_conv_fwd.  MSFWSI_EUNSUPPORTED for other shapes (K > 64 ...). */
+int msfwsi_stem_conv_fwd(int dtype, const void* x, const void* w_run, void* y, double* stats, int nshard, int N, int H,
+                         int W, int CP, int K, int R, int S, int stride, int pad, void* stream);
+
 /* Two-source 1x1 input gradient: dx = gate( dy . w_cat[0:K] + src2 . w_cat[K:K+C2] + bias ), w_cat = [K+C2][C]
  * (rows K.. are a second [C2][C] matrix), src2 = [N,H,W,C2], bias fp32 [C] nullable, gate / sums as in
  * msfwsi_conv_dgrad.  One launch for the folded bn3 backward da2 = g (k1 o W) + a2 (W^T diag(k2) W) + W^T k3

@@ -49,6 +49,7 @@ SIGNATURES = {
     "msfwsi_gap_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
     "msfwsi_bn_act_sum": [_i, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp],
     "msfwsi_fold_matvec": [_vp, _vp, _vp, _i, _i, _vp],
+    "msfwsi_stem_conv_fwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "msfwsi_conv_dgrad2": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_conv_fwd_post": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "msfwsi_fold_dots": [_vp, _vp, _vp, _i, _i, _vp],

@@ -49,6 +49,8 @@ struct IgemmParams {
     const float* post_scale; // per output channel, nullable: out = [relu](round(acc)*post_scale + post_shift + resid)
     const float* post_shift;
     int post_relu;
+    int pix_stride;          // RUN kernels: elements between consecutive source pixels (the k range of one filter row
+    int s_run;               //   is a run of s_run pixels x pix_stride channels, padded to C = a multiple of the slab)
     const void* src2;        // DGRAD 1x1 only, nullable: second source [M][C2] whose k-range follows the first
     int C2;                  //   (out = src . W[0:C] + src2 . W[C:C+C2]; Ktot = C + C2)
     unsigned char* gate_out;        // [M][Nout/VEC], nullable: bit e of a byte = (out[m][VEC*chunk+e] > 0)
@@ -683,9 +685,13 @@ __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds
                                              soff, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, int EPI = 0, bool TWO = false>
+// RUN (stem): the S filter taps of one filter row are contiguous in NHWC memory when the channel count is one chunk
+// (7 taps x 8 padded channels = 56 elements), so a filter row is ONE tap whose "channels" are that run, padded to 64
+// with a zero weight column: the 7x7/C=3 stem becomes 7 taps x 2 slabs on this kernel instead of the generic one.
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, int EPI = 0, bool TWO = false, bool RUN = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams prm) {
     static_assert(!(TWO && !DGRAD) && !(DGRAD && EPI != 0), "second source: input gradient; post epilogue: forward");
+    static_assert(!(RUN && (DGRAD || TWO || EPI != 0)), "run mode: plain forward only");
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, false> Cfg;
     constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
     constexpr int TM = Cfg::TM, TN = Cfg::TN, A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
@@ -734,8 +740,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     int hb0, wb0;
     const long maxd = DGRAD ? ((long)((prm.R - 1) >> sh) * prm.W + ((prm.S - 1) >> sh)) : 0;
     const long ref_pix = tap0_pixel(m0, hb0, wb0) - (prm.W + 1) - maxd;
+    const int pitch = RUN ? prm.pix_stride : prm.C;  // elements per source pixel
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(reinterpret_cast<const T*>(prm.src)) + ref_pix * prm.C, 0, 0x7fffffff, 0x00020000);
+        const_cast<T*>(reinterpret_cast<const T*>(prm.src)) + ref_pix * pitch, 0, 0x7fffffff, 0x00020000);
     const long wbytes = (long)prm.Nout * prm.Ktot * ES;
     const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(prm.wgt), 0, (int)(wbytes < 0x7fffffffL ? wbytes : 0x7fffffffL), 0x00020000);
@@ -754,6 +761,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         int hb, wb;
         const long pix = tap0_pixel(rowok ? m : m0, hb, wb);
         unsigned mask = 0;
+        if constexpr (RUN) {
+            // bit r*nsl + slab: this lane's chunk of that slab is pixel s = slab*(BK/pitch) + kc*(VEC/pitch) of the run
+            const int nsl = prm.C / BK;
+            for (int r = 0; r < prm.R; ++r)
+                for (int sl = 0; sl < nsl; ++sl) {
+                    const int sx = (sl * BK + kc * VEC) / pitch;
+                    const bool ok = rowok && sx < prm.s_run && (unsigned)(hb + r) < (unsigned)prm.H &&
+                                    (unsigned)(wb + sx) < (unsigned)prm.W;
+                    mask |= (ok ? 1u : 0u) << (r * nsl + sl);
+                }
+        } else
         for (int r = 0; r < prm.R; ++r)
             for (int s2 = 0; s2 < prm.S; ++s2) {
                 int h, w;
@@ -772,7 +790,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                 mask |= (ok ? 1u : 0u) << (r * prm.S + s2);
             }
         a_mask[i] = mask;
-        a_voff[i] = (int)(((pix - ref_pix - maxd) * prm.C + kc * VEC) * ES);
+        a_voff[i] = (int)(((pix - ref_pix - maxd) * pitch + kc * VEC) * ES);
         if constexpr (TWO) {  // second source (two-source 1x1 input gradient): same pixel, its own row pitch
             a_voff2[i] = rowok ? (int)(((pix - ref_pix - maxd) * prm.C2 + kc * VEC) * ES) : OOB;
         }
@@ -820,12 +838,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                 return;
             }
         }
-        if (tap_c == 0) {  // new filter tap: which rows have a source pixel, and the tap's scalar shift
-            tap_t = tap_r * prm.S + tap_s;
+        if (RUN || tap_c == 0) {  // new filter tap: which rows have a source pixel, and the tap's scalar shift
+            tap_t = RUN ? tap_r * (prm.C / BK) + tap_c / BK : tap_r * prm.S + tap_s;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) voff_eff[i] = ((a_mask[i] >> tap_t) & 1u) ? a_voff[i] : OOB;
             const long d = DGRAD ? maxd - ((long)(tap_r >> sh) * prm.W + (tap_s >> sh)) : (long)tap_r * prm.W + tap_s;
-            soff_tap = (int)(d * prm.C * ES);
+            soff_tap = (int)(d * pitch * ES);
         }
         char* Ab = As + buf * Cfg::A_BYTES + wave * 1024;
         char* Bb = Bs + buf * Cfg::B_BYTES + wave * 1024;
@@ -948,6 +966,9 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
             } else {
                 kern = prm.post_scale != nullptr ? igemm_dma_kernel<T, BM, BN, WM, WN, false, 1, false>
                                                  : igemm_dma_kernel<T, BM, BN, WM, WN, false, 0, false>;
+                if constexpr (BN == 64) {
+                    if (prm.pix_stride > 0) kern = igemm_dma_kernel<T, BM, BN, WM, WN, false, 0, false, true>;
+                }
             }
         }
     }
@@ -1039,6 +1060,31 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool pro = pro_scale != nullptr;
     MSFWSI_WITH_T(d->dtype, return pro ? dispatch_tile<T, false, true>(prm, st) : dispatch_tile<T, false, false>(prm, st));
+    return MSFWSI_EINVAL;
+}
+
+extern "C" int msfwsi_stem_conv_fwd(int dtype, const void* x, const void* w_run, void* y, double* stats, int nshard,
+                                    int N, int H, int W, int CP, int K, int R, int S, int stride, int pad,
+                                    void* stream) {
+    MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && x && w_run && y && N > 0 && H > 0 && W > 0 && K > 0 && K <= 64);
+    MSFWSI_CHECK_ARG(stats == nullptr || nshard >= 1);
+    const int vec = msfwsi_vec_of(dtype), bk = dtype == MSFWSI_DT_F32 ? 16 : 32;
+    // the run of S pixels x CP channels is padded to whole k slabs; a 16-byte chunk must be one pixel
+    const int run = ((S * CP + bk - 1) / bk) * bk;
+    if (CP != vec || K % vec != 0 || R * (run / bk) > 32 || (stride != 1 && stride != 2) || !g_fast_dma)
+        return MSFWSI_EUNSUPPORTED;
+    IgemmParams prm{};
+    prm.src = x; prm.wgt = w_run; prm.out = y;
+    prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = N; prm.H = H; prm.W = W; prm.C = run;
+    prm.P = (H + 2 * pad - R) / stride + 1; prm.Q = (W + 2 * pad - S) / stride + 1; prm.Nout = K;
+    prm.R = R; prm.S = 1; prm.stride = stride; prm.pad = pad;
+    prm.pix_stride = CP; prm.s_run = S;
+    if ((long)N * prm.P * prm.Q > 0x7fffffffL) return MSFWSI_EINVAL;
+    prm.M = N * prm.P * prm.Q;
+    prm.Ktot = R * run;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MSFWSI_WITH_T(dtype, return (launch_igemm<T, 128, 64, 2, 2, false, false>(prm, st)));
     return MSFWSI_EINVAL;
 }
 

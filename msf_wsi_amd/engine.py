@@ -203,6 +203,8 @@ class Engine:
         # ... which also emits the block's closing ReLU gate as one byte per 16-byte chunk for the backward pass
         self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
+        self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
+        self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ---- configuration ---------------------------------------------------------------------
@@ -297,7 +299,9 @@ class Engine:
             xin = torch.empty_like(x)
             kn.bn_act(x, pro[0], pro[1], xin, relu=True)
             pro = None
-        if self.halo3x3_fwd and pro is None and bias is None and not pad_c and kn.conv3x3_supported(d):
+        if pad_c and pro is None and bias is None and self.stem_run and self._stem_run_fwd(op, xin, c, stats, dtype, pad_c):
+            pass  # stem: 7 row taps over runs of contiguous pixels on the pure-DMA kernel
+        elif self.halo3x3_fwd and pro is None and bias is None and not pad_c and kn.conv3x3_supported(d):
             kn.conv3x3_fwd(d, xin, w, c, stats=stats)  # input patch staged once per channel slab, 9 taps reuse it
         else:
             kn.conv_fwd(d, xin, w, c, pro=pro, bias=bias.data if bias is not None else None, stats=stats)
@@ -305,6 +309,23 @@ class Engine:
         if bn is not None:
             u.st = self._bn_finalize(stats, N * d.P * d.Q, bn)
         return u
+
+    def _stem_run_fwd(self, op: nn.Module, x: torch.Tensor, c: torch.Tensor, stats, dtype, CP: int) -> bool:
+        """stem weights [K][R][S][CP] -> [K][R][run] (zero columns pad the S*CP run to whole k slabs), cached per
+        parameter version; False when the library has no run kernel for the shape"""
+        K, R, S = op.out_channels, op.kernel_size[0], op.kernel_size[1]
+        bk = 16 if dtype == torch.float32 else 32
+        run = (S * CP + bk - 1) // bk * bk
+        key = (id(op.weight), dtype, "run")
+        ver = (op.weight._version, op.weight.data_ptr())
+        hit = self._stem_cache.get(key)
+        if hit is None or hit[0] != ver:
+            wp = self.weights.get(op.weight, dtype, pad_to=CP)  # [K][R][S][CP]
+            w_run = torch.zeros(K, R, run, dtype=dtype, device=wp.device)
+            w_run[:, :, :S * CP] = wp.reshape(K, R, S * CP)
+            hit = (ver, w_run)
+            self._stem_cache[key] = hit
+        return kn.stem_conv_fwd(x, hit[1], c, stats, R, S, op.stride[0], op.padding[0])
 
     def _conv_bn_res_fwd(self, conv: nn.Module, bn: nn.Module, c_in: torch.Tensor, pro: BNState, ident: torch.Tensor,
                          geom, dtype: torch.dtype, want_bits: bool = False):

@@ -179,7 +179,7 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False) -
 
 
 def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = False, halo: bool = False,
-           dtype=None):
+           dtype=None, symbol_override: Optional[str] = None):
     """extra_elems: elements of the additional activation-sized operands the launch reads in its epilogue
     (residual / identity, the gate's activation) -- algorithmic bytes of the fused work, counted once each"""
     if TIMER is None:
@@ -193,7 +193,7 @@ def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = 
     e0.record()
     r = fn()
     e1.record()
-    TIMER.records.append((kind, _symbol(kind, d, tcode, pro, halo), flops, nbytes, e0, e1))
+    TIMER.records.append((kind, symbol_override or _symbol(kind, d, tcode, pro, halo), flops, nbytes, e0, e1))
     return r
 
 
@@ -226,6 +226,32 @@ def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
 def gate_bytes(d_or_rows, Cn: int = 0, dtype=None, device="cuda") -> torch.Tensor:
     """uint8 [rows][C/vec] buffer for the ReLU-gate bits of a [rows][C] activation (vec = 4 fp32 / 8 16-bit)"""
     return torch.empty(int(d_or_rows), Cn // vec_of(dtype), dtype=torch.uint8, device=device)
+
+
+def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad) -> bool:
+    """the stem conv as R row taps over runs of S contiguous pixels (x [N,H,W,CP], w_run [K][R][run], run = S*CP
+    padded to whole k slabs with zero columns); False if the library has no kernel for the shape"""
+    lib = _lib.load()
+    N, H, W, CP = x.shape
+    K = y.shape[-1]
+    _req(x, "x")
+    _req(w_run, "w_run", x.dtype)
+    _req(y, "y", x.dtype)
+    nsh = 1
+    if stats is not None:
+        _req(stats, "stats", torch.float64)
+        nsh = stats.shape[0]
+    d = conv_desc(x.dtype, N, H, W, CP, K, R, S, stride, pad)
+    rc = [0]
+
+    def run():
+        rc[0] = lib.msfwsi_stem_conv_fwd(dt_of(x), _p(x), _p(w_run), _p(y), _p(stats), nsh, N, H, W, CP, K, R, S,
+                                         stride, pad, _stream())
+        if rc[0] != -2:
+            _lib.check(rc[0], "stem_conv_fwd")
+
+    _timed("conv_fwd", d, x.element_size(), run, dtype=x.dtype, symbol_override="igemm_dma_kernel<stem run>")
+    return rc[0] == 0
 
 
 def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu=True, gate_out=None):

@@ -156,6 +156,37 @@ def test_conv_dgrad2_two_sources(hip_lib, dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hw", [(30, 30), (33, 17), (64, 64)])
+def test_stem_conv_as_row_runs(hip_lib, dt, hw):
+    """7x7 / stride 2 / pad 3 on 3 channels (resnet.py:174) as 7 row taps over runs of contiguous pixels"""
+    from msf_wsi_amd import kernels as kn
+
+    H, W = hw
+    N, K, R, CP = 3, 64, 7, (4 if dt == torch.float32 else 8)
+    g = torch.Generator().manual_seed(15)
+    x = rnd((N, 3, H, W), dt, g)
+    w = rnd((K, 3, R, R), dt, g, 1.0 / math.sqrt(3 * R * R))
+    ref = F.conv2d(x.double(), w.double(), stride=2, padding=3).float()
+    xp = torch.zeros(N, H, W, CP)
+    xp[..., :3] = nhwc(x)
+    bk = 16 if dt == torch.float32 else 32
+    run = (R * CP + bk - 1) // bk * bk
+    w_run = torch.zeros(K, R, run)
+    wp = torch.zeros(K, R, R, CP)
+    wp[..., :3] = nhwc(w)
+    w_run[:, :, :R * CP] = wp.reshape(K, R, R * CP)
+    P, Q = ref.shape[2], ref.shape[3]
+    y = torch.empty(N, P, Q, K, dtype=dt, device="cuda")
+    stats = kn.new_stats(K)
+    assert kn.stem_conv_fwd(xp.to(dt).cuda(), w_run.to(dt).cuda(), y, stats, R, R, 2, 3)
+    torch.cuda.synchronize()
+    assert rel(y.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt)
+    yy = y.double().cpu().reshape(-1, K)
+    assert torch.allclose(stats.sum(0).cpu()[0], yy.sum(0), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(stats.sum(0).cpu()[1], (yy * yy).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(5000, 64), (333, 256), (70, 2048)])
 def test_bn_act_sum(hip_lib, dt, shape):
     from msf_wsi_amd import kernels as kn
