@@ -115,7 +115,8 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.msfwsi_target.argtypes = []
     lib.msfwsi_target.restype = C.c_char_p
-    for key, env in ((0, "MSFWSI_BIG_TILE_MIN_BLOCKS"), (1, "MSFWSI_FAST_DMA"), (2, "MSFWSI_WGRAD_LIN")):  # A/B switches (see msfwsi_set_tuning)
+    for key, env in ((0, "MSFWSI_BIG_TILE_MIN_BLOCKS"), (1, "MSFWSI_FAST_DMA"), (2, "MSFWSI_WGRAD_LIN"),
+                     (4, "MSFWSI_SMALL_GRID_BLOCKS")):  # A/B switches (see msfwsi_set_tuning)
         if env in os.environ:
             lib.msfwsi_set_tuning(key, int(os.environ[env]))
     _lib = lib

@@ -984,6 +984,7 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
 
 long g_big_tile_min_blocks = 1024;  // tunable through msfwsi_set_tuning
 long g_tile_variant = 0;            // experiments (key 3)
+long g_small_grid_blocks = 100;     // key 4: 128x128 grids below this use 128x64 tiles (measured: helps <= 72 tiles, hurts at 144+)
 
 template <typename T, bool DGRAD, bool APRO>
 int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
@@ -998,6 +999,9 @@ int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
         }
         return launch_igemm<T, 256, 128, 4, 2, DGRAD, APRO>(prm, stream);
     }
+    // grids far below one workgroup per CU (small head GEMMs): halve the tile to put more CUs to work
+    if (!APRO && (long)((prm.M + 127) / 128) * ((prm.Nout + 127) / 128) < g_small_grid_blocks)
+        return launch_igemm<T, 128, 64, 2, 2, DGRAD, APRO>(prm, stream);
     return launch_igemm<T, 128, 128, 2, 2, DGRAD, APRO>(prm, stream);
 }
 
@@ -1027,6 +1031,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 3) {
         g_tile_variant = value;
+        return MSFWSI_OK;
+    }
+    if (key == 4) {
+        g_small_grid_blocks = value;
         return MSFWSI_OK;
     }
     if (key == 0) {

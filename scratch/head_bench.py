@@ -1,6 +1,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from msf_wsi_amd import kernels as kn
+from msf_wsi_amd import _lib as _L
+_L.load().msfwsi_set_tuning(4, int(os.environ.get("SMALL", "640")))
 dt = torch.bfloat16
 def timeit(fn, rep=5):
     fn(); torch.cuda.synchronize()
