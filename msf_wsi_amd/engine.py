@@ -204,6 +204,7 @@ class Engine:
         self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
+        self.mat_min_rows = int(os.environ.get("MSFWSI_MAT_MIN_ROWS", "1"))  # rows from which 1x1 operands are materialised
         self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
 
@@ -293,7 +294,7 @@ class Engine:
         stats = kn.new_stats(K, 2, x.device) if bn is not None else None
         bias = getattr(op, "bias", None)
         xin, pro = x, (x_pro.scale, x_pro.shift) if x_pro is not None else None
-        if pro is not None and self.materialize_3x3 and (R * S > 1 or (self.materialize_1x1 and N * H * W >= 8192)):
+        if pro is not None and self.materialize_3x3 and (R * S > 1 or (self.materialize_1x1 and N * H * W >= self.mat_min_rows)):
             # a 3x3 gather reads every input element 9 times: normalising it once into a transient tensor and
             # letting the conv stage by pure LDS-DMA is cheaper than re-applying BatchNorm+ReLU per tap
             xin = torch.empty_like(x)

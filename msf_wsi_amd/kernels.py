@@ -146,9 +146,10 @@ TIMER: Optional[KernelTimer] = None
 
 _TCODE = {4: "f", 2: "DF16b"}  # Itanium codes of float / __bf16 (fp16 "DF16_" is set by the caller's dtype)
 BIG_TILE_MIN_BLOCKS = int(os.environ.get("MSFWSI_BIG_TILE_MIN_BLOCKS", "1024"))
+SMALL_GRID_BLOCKS = int(os.environ.get("MSFWSI_SMALL_GRID_BLOCKS", "100"))
 
 
-def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False) -> str:
+def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, epi: int = 0, two: bool = False) -> str:
     """The mangled template-instance fragment of the kernel this launch reaches; mirrors dispatch_tile() /
     launch_igemm() (csrc/igemm.hip), msfwsi_conv_wgrad() (csrc/wgrad.hip) and conv3x3.hip.  Only used to label
     timings so that bench.py's roofline names the same kernel as the rocprofv3 summary."""
@@ -170,16 +171,18 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False) -
         tile = (128, 64, 2, 2)
     elif not pro and es == 2 and ((M + 255) // 256) * ((nout + 127) // 128) >= BIG_TILE_MIN_BLOCKS:
         tile = (256, 128, 4, 2)
+    elif not pro and ((M + 127) // 128) * ((nout + 127) // 128) < SMALL_GRID_BLOCKS:
+        tile = (128, 64, 2, 2)
     else:
         tile = (128, 128, 2, 2)
     t = "Li%dELi%dELi%dELi%dE" % tile
     if not pro and os.environ.get("MSFWSI_FAST_DMA", "1") != "0" and csrc % bk == 0 and d.R * d.S <= 32:
-        return f"igemm_dma_kernelI{tcode}{t}Lb{int(dgrad)}E"
+        return f"igemm_dma_kernelI{tcode}{t}Lb{int(dgrad)}ELi{epi}ELb{int(two)}ELb0E"
     return f"igemm_kernelI{tcode}{t}Lb{int(dgrad)}ELb{int(pro)}E"
 
 
 def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = False, halo: bool = False,
-           dtype=None, symbol_override: Optional[str] = None):
+           dtype=None, symbol_override: Optional[str] = None, epi: int = 0, two: bool = False):
     """extra_elems: elements of the additional activation-sized operands the launch reads in its epilogue
     (residual / identity, the gate's activation) -- algorithmic bytes of the fused work, counted once each"""
     if TIMER is None:
@@ -193,7 +196,7 @@ def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = 
     e0.record()
     r = fn()
     e1.record()
-    TIMER.records.append((kind, symbol_override or _symbol(kind, d, tcode, pro, halo), flops, nbytes, e0, e1))
+    TIMER.records.append((kind, symbol_override or _symbol(kind, d, tcode, pro, halo, epi, two), flops, nbytes, e0, e1))
     return r
 
 
@@ -250,7 +253,7 @@ def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad) -> bool:
         if rc[0] != -2:
             _lib.check(rc[0], "stem_conv_fwd")
 
-    _timed("conv_fwd", d, x.element_size(), run, dtype=x.dtype, symbol_override="igemm_dma_kernel<stem run>")
+    _timed("conv_fwd", d, x.element_size(), run, dtype=x.dtype, symbol_override="igemm_dma_kernelI%sLi128ELi64ELi2ELi2ELb0ELi0ELb0ELb1E" % ("DF16_" if x.dtype == torch.float16 else _TCODE[x.element_size()]))
     return rc[0] == 0
 
 
@@ -269,7 +272,7 @@ def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu
     _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_fwd_post(C.byref(d), _p(x), _p(w), _p(y), _p(post_scale), _p(post_shift), _p(ident),
                                  int(bool(relu)), _p(gate_out), _stream()), "conv_fwd_post"),
-        extra_elems=ident.numel() if ident is not None else 0, dtype=dt)
+        extra_elems=ident.numel() if ident is not None else 0, dtype=dt, epi=1)
     return y
 
 
@@ -351,7 +354,7 @@ def conv_dgrad2(d: ConvDesc, dy, w_cat, dx, src2, bias=None, mask=None, sums=Non
             _lib.check(rc[0], "conv_dgrad2")
 
     _timed("conv_dgrad", d, dy.element_size(), run,
-           extra_elems=src2.numel() + (dx.numel() if mask is not None else 0), dtype=dt)
+           extra_elems=src2.numel() + (dx.numel() if mask is not None else 0), dtype=dt, two=True)
     return rc[0] == 0
 
 
