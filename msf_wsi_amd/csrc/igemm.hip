@@ -983,7 +983,6 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
 }
 
 long g_big_tile_min_blocks = 1024;  // tunable through msfwsi_set_tuning
-long g_tile_variant = 0;            // experiments (key 3)
 long g_small_grid_blocks = 100;     // key 4: 128x128 grids below this use 128x64 tiles (measured: helps <= 72 tiles, hurts at 144+)
 
 template <typename T, bool DGRAD, bool APRO>
@@ -994,9 +993,6 @@ int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
     // (the register-staged BatchNorm-prologue variant loses with 8 waves: measured 0.55 -> 0.76 ms)
     if (!APRO && sizeof(T) == 2 && (long)((prm.M + 255) / 256) * ((prm.Nout + 127) / 128) >= g_big_tile_min_blocks)
     {
-        if constexpr (!APRO) {
-            if (g_tile_variant == 1) return launch_igemm<T, 256, 128, 2, 2, DGRAD, APRO>(prm, stream);
-        }
         return launch_igemm<T, 256, 128, 4, 2, DGRAD, APRO>(prm, stream);
     }
     // grids far below one workgroup per CU (small head GEMMs): halve the tile to put more CUs to work
@@ -1027,10 +1023,6 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
         msfwsi_wgrad_set_lin(value);
-        return MSFWSI_OK;
-    }
-    if (key == 3) {
-        g_tile_variant = value;
         return MSFWSI_OK;
     }
     if (key == 4) {

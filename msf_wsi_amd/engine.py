@@ -204,6 +204,7 @@ class Engine:
         self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
+        self.fold_ds = os.environ.get("MSFWSI_FOLD_DS", "1") != "0"  # stride-1 downsample branch folded like bn3
         self.mat_min_rows = int(os.environ.get("MSFWSI_MAT_MIN_ROWS", "1"))  # rows from which 1x1 operands are materialised
         self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -469,7 +470,10 @@ class Engine:
                         # backward (_block_end_folded) it is never needed again; otherwise _block_bwd re-runs the
                         # 1x1 conv3 from the kept c2 with the kept statistics
                         last.c = None
-                    blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1))
+                    rec_b = BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1)
+                    if self._foldable(rec_b) and self._ds_foldable(ds):
+                        ds.c = None  # the folded downsample backward never reads the branch output either
+                    blocks.append(rec_b)
                 y, h, w = y_out, gh, gw
             f = torch.empty(N, y.shape[-1], dtype=dtype, device=x.device)
             kn.gap_fwd(y, f, N, h * w, y.shape[-1])
@@ -540,7 +544,7 @@ class Engine:
             gate = None
             if i > 0 and self.fuse_gate:
                 pr = ps.blocks[i - 1]
-                if self._foldable(pr) and pr.ds is None:
+                if self._foldable(pr) and (pr.ds is None or self._ds_foldable(pr.ds)):
                     # the producer of pr's output gradient (this block's first conv) applies pr's closing ReLU gate,
                     # adds pr's pooled-feature gradient and reduces sum(g) in its own epilogue
                     gate = (pr.y_out, dfeats[pr.stage] if pr.stage_end else None, pr.HW, pr.gate_bits)
@@ -565,6 +569,56 @@ class Engine:
         return d.R == 1 and d.S == 1 and d.stride == 1 and rec.units[-1].x_pro is not None \
             and getattr(rec.units[-1].op, "bias", None) is None
 
+    def _ds_foldable(self, ds: Optional[Unit]) -> bool:
+        """downsample branch (1x1 conv + BatchNorm on the block input) whose BatchNorm backward folds into weights the
+        same way: stride 1 only (layer1.0) -- a strided branch would need the Gram matrix of a strided gather"""
+        if ds is None or not self.fold_ds:
+            return False
+        d = ds.desc
+        bk = 16 if d.dtype == 0 else 32
+        return (d.R == 1 and d.S == 1 and d.stride == 1 and ds.x_pro is None and getattr(ds.op, "bias", None) is None
+                and d.C % bk == 0 and d.K % bk == 0)
+
+    def _ds_folded_bwd(self, rec: BlockRec, g: torch.Tensor, sums: torch.Tensor, ns: int, grads: GradStore, dtype):
+        """input gradient of the downsample branch y_d = bn_d(W_d x) from the gated block-output gradient g, without
+        the branch output c_d (same algebra as _block_end_folded, the operand is the block input x itself):
+        returns d(x) of that branch = g (k1 o W_d) + x (W_d^T diag(k2) W_d) + W_d^T k3"""
+        u = rec.ds
+        d = u.desc
+        K, Ci = d.K, d.C
+        dev = g.device
+        x = u.x
+        Wd = WeightStore.physical(u.op.weight).view(K, 1, 1, Ci)
+        Md = kn.zeros((K, 1, 1, Ci), torch.float32, dev)
+        kn.conv_wgrad(d, x, g, Md)
+        Ax = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
+        kn.conv_wgrad(kn.conv_desc(dtype, d.N, d.H, d.W, Ci, Ci, 1, 1, 1, 0), x, x, Ax)
+        sx = kn.zeros((Ci,), torch.float64, dev)
+        kn.colsum(x, sx)
+        packed = torch.empty(ns * K, dtype=torch.float64, device=dev)
+        kn.shard_sum(sums, packed)  # slot 0 = sum(g) (local)
+        sd = kn.zeros((1, 2, K), torch.float64, dev)
+        sd[0, 0].copy_(packed[:K])
+        kn.fold_dots(Wd, Md, sd[0, 1])
+        kd = self._bn_bwd_coeffs(sd, 2, 1, u.bn, u.st, grads)
+        dlin = kn.conv_desc(torch.float32, K, 1, 1, Ci, Ci, 1, 1, 1, 0)
+        WA = torch.empty(K, 1, 1, Ci, dtype=torch.float32, device=dev)
+        kn.conv_fwd(dlin, Wd, Ax, WA)
+        Wk1, Wk2 = torch.empty_like(WA), torch.empty_like(WA)
+        bvec = kn.zeros((Ci,), torch.float32, dev)
+        kn.fold_weights(Wd, Md, WA, kd[0], kd[1], kd[2], sx, grads.get(u.op.weight), Wk1, Wk2, bvec)
+        Gd = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
+        kn.conv_wgrad(dlin, Wd, Wk2, Gd)
+        wcat32 = torch.cat([Wk1.view(K, Ci), Gd.view(Ci, Ci)], 0)
+        wcat = wcat32 if dtype == torch.float32 else kn.cast_lowp(wcat32, torch.empty_like(wcat32, dtype=dtype))
+        dx = torch.empty_like(x)
+        if self.fuse_two_source and kn.conv_dgrad2(d, g, wcat, dx, x, bias=bvec):
+            return dx
+        t = torch.empty_like(x)
+        kn.conv_fwd(kn.conv_desc(dtype, d.N, d.H, d.W, Ci, Ci, 1, 1, 1, 0), x, wcat[K:].view(Ci, 1, 1, Ci), t, bias=bvec)
+        kn.conv_dgrad(d, g, wcat[:K].view(K, 1, 1, Ci), dx, resid=t)
+        return dx
+
     def _block_end_folded(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype, pre=None):
         """Backward through y = relu(bn3(conv3(a2)) + identity) WITHOUT the 4x-wide conv3 output c3 = W a2:
         every c3-dependent term of the BatchNorm backward dc3 = k1*g + k2*c3 + k3 is folded into [K][C] / [C][C]
@@ -577,6 +631,7 @@ class Engine:
         d = last.desc
         K, Cw = d.K, d.C
         dev = rec.y_out.device
+        ds_fold = self._ds_foldable(rec.ds)
         if pre is not None:
             # dy is already the gated gradient (ReLU gate + pooled-feature gradient applied by its producer);
             # pre = [nshard][2][K] with slot 0 = sum(g); slot 1 is overwritten by fold_dots below
@@ -585,8 +640,8 @@ class Engine:
         else:
             g, ns = torch.empty_like(rec.y_out), 3
             sums = kn.new_stats(K, 3, dev)
-            kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, None, rec.ds.c if rec.ds is not None else None, g,
-                             sums, rec.HW)
+            kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, None,
+                             rec.ds.c if rec.ds is not None and not ds_fold else None, g, sums, rec.HW)
         a2 = torch.empty_like(last.x)
         if last.gram is not None:  # Gram matrix and column sums of a2 kept by the fused forward
             A, sa = last.gram
@@ -604,7 +659,8 @@ class Engine:
             kn.conv_wgrad(dsq, a2, a2, A)
         kn.fold_dots(W, Mm, sums[0, 1])  # slot 1 of shard 0; the other shards of that slot stay zero
         k = self._bn_bwd_coeffs(sums, ns, 1, last.bn, last.st, grads)
-        kd = self._bn_bwd_coeffs(sums, 3, 2, rec.ds.bn, rec.ds.st, grads) if rec.ds is not None else None
+        kd = self._bn_bwd_coeffs(sums, 3, 2, rec.ds.bn, rec.ds.st, grads) if rec.ds is not None and not ds_fold else None
+        resid_ds = self._ds_folded_bwd(rec, g, sums, ns, grads, dtype) if ds_fold else None
         # small fp32 matrices on the exact-fp32 MFMA path: WA = W A, G = W^T diag(k2) W
         dlin = kn.conv_desc(torch.float32, K, 1, 1, Cw, Cw, 1, 1, 1, 0)
         WA = torch.empty(K, 1, 1, Cw, dtype=torch.float32, device=dev)
@@ -622,20 +678,22 @@ class Engine:
         wcat32 = torch.cat([Wk1.view(K, Cw), G.view(Cw, Cw)], 0)
         wcat = wcat32 if dtype == torch.float32 else kn.cast_lowp(wcat32, torch.empty_like(wcat32, dtype=dtype))
         if self.fuse_two_source and kn.conv_dgrad2(d, g, wcat, da, a2, bias=bvec, mask=gate, sums=s2):
-            return g, da, s2, kd
+            return g, da, s2, kd, resid_ds
         # shapes without a two-source kernel: the a2 term as a separate w -> w conv, added as the residual
         Wc, Gc = wcat[:K].view(K, 1, 1, Cw), wcat[K:].view(Cw, 1, 1, Cw)
         t = torch.empty_like(a2)
         kn.conv_fwd(dsq, a2, Gc, t, bias=bvec)
         kn.conv_dgrad(d, g, Wc, da, resid=t, mask=gate, sums=s2)
-        return g, da, s2, kd
+        return g, da, s2, kd, resid_ds
 
     def _block_bwd(self, rec: BlockRec, dy, gapg, grads: GradStore, dtype, pre=None, gate=None):
         """returns (gradient w.r.t. the block input, its fused-gate sums or None -- see encoder_backward)"""
         if self._foldable(rec):
-            g, da, s2, kd = self._block_end_folded(rec, dy, gapg, grads, dtype, pre=pre)
+            g, da, s2, kd, resid_ds = self._block_end_folded(rec, dy, gapg, grads, dtype, pre=pre)
             resid = g
-            if rec.ds is not None:
+            if resid_ds is not None:
+                resid = resid_ds  # the skip connection IS the (folded) downsample branch
+            elif rec.ds is not None:
                 kn.bn_bwd_apply(g, rec.ds.c, kd[0], kd[1], kd[2], g)  # g becomes d(downsample conv output)
                 self._unit_wgrad(rec.ds, g, grads, dtype)
                 resid = self._unit_dgrad(rec.ds, g, dtype)

@@ -11,7 +11,6 @@ from msf_wsi_amd import _lib as _L  # noqa: E402
 
 _L.load().msfwsi_set_tuning(1, int(os.environ.get("TUNE_FAST", "1")))
 _L.load().msfwsi_set_tuning(0, int(os.environ.get("TUNE_BIG", "1024")))
-_L.load().msfwsi_set_tuning(3, int(os.environ.get("TUNE_TILE", "0")))
 N = int(os.environ.get("NIMG", "1024"))
 REP = int(os.environ.get("REP", "5"))
 ONLY = os.environ.get("ONLY", "")
