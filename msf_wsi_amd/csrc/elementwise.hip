@@ -271,10 +271,11 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
         const long rbeg = (long)blockIdx.y * rows_per_block;
         const long rend = rbeg + rows_per_block < M ? rbeg + rows_per_block : M;
         for (long m = rbeg + rl; m < rend; m += nrl) {
-            const int w = (int)(m % W);
-            const long t = m / W;
-            const int h = (int)(t % H);
-            const int n = (int)(t / H);
+            const unsigned mu = (unsigned)m;  // N*H*W < 2^31 (checked by the launcher): 32-bit divisions
+            const unsigned t = mu / (unsigned)W;
+            const int w = (int)(mu - t * (unsigned)W);
+            const int n = (int)(t / (unsigned)H);
+            const int h = (int)(t - (unsigned)n * (unsigned)H);
             float g[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) g[e] = 0.f;
@@ -290,10 +291,13 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
                     const long o = (((long)n * P + p) * Q + q) * C + ch;
                     float d[VEC];
                     unpack16<T>(*reinterpret_cast<const uint4*>(dp + o), d);
-                    const unsigned char* ap = amax + o;
+                    // the VEC argmax bytes of the chunk in one load
+                    unsigned long long ab;
+                    if constexpr (VEC == 8) ab = *reinterpret_cast<const unsigned long long*>(amax + o);
+                    else ab = *reinterpret_cast<const unsigned*>(amax + o);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e)
-                        if (ap[e] == r * 3 + s) g[e] += d[e];
+                        if ((int)((ab >> (8 * e)) & 0xffu) == r * 3 + s) g[e] += d[e];
                 }
             }
             float x[VEC];
@@ -844,7 +848,7 @@ extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned ch
                                     const float* scale, const float* shift, void* g0, double* sums, int nshard, int N,
                                     int H, int W, int C, void* stream) {
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && dp && argmax && c0 && scale && shift && g0 && sums && nshard >= 1);
-    MSFWSI_CHECK_ARG(N > 0 && H > 1 && W > 1 && C % vec_of(dtype) == 0);
+    MSFWSI_CHECK_ARG(N > 0 && H > 1 && W > 1 && C % vec_of(dtype) == 0 && (long)N * H * W <= 0x7fffffffL);
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     const int vec = vec_of(dtype);
     ColGrid g = make_col_grid((long)N * H * W, C, vec, 2048);
