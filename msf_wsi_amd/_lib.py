@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsfwsi_hip.so")
+LIB_PATH = os.environ.get("MSFWSI_LIB") or os.path.join(_HERE, "libmsfwsi_hip.so")  # override: A/B of two builds
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 DT_F32 = 0

@@ -721,7 +721,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     const int sh = (DGRAD && prm.stride == 2) ? 1 : 0;
 
     // source pixel (linear index over [img][H][W], may be negative inside the padding) of filter tap (0,0)
+    // 1x1 / stride 1 / no padding (most launches): the source pixel IS the output pixel -- no divisions at all
+    const bool unit = RS == 1 && prm.stride == 1 && prm.pad == 0;
     auto tap0_pixel = [&](int m, int& hb, int& wb) -> long {
+        if (unit) {
+            hb = 0;
+            wb = 0;
+            return m;
+        }
         const int img = m / PQ;
         const int rem = m - img * PQ;
         const int p = rem / prm.Q;
