@@ -55,6 +55,15 @@ int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, voi
 int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, const float* post_scale,
                          const float* post_shift, const void* ident, int relu, unsigned char* gate_out, void* stream);
 
+/* msfwsi_conv_fwd_post with a second source: y = [relu]( round(x . w_cat[:, 0:C] + src2 . w_cat[:, C:C+C2]) *
+ * post_scale + post_shift + ident ), w_cat = [K][C + C2] (each output row holds both weight rows), src2 = [N,P,Q,C2].
+ * A Bottleneck with a downsample branch is ONE such launch: relu(bn3(conv3(a2)) + bn_d(conv_d(x))) with the two
+ * BatchNorm scales folded into the weight rows and the shifts summed (src/models/resnet.py:131-138 with
+ * self.downsample).  MSFWSI_EUNSUPPORTED unless 1x1 / stride 1 with C and C2 multiples of the k slab. */
+int msfwsi_conv_fwd_post2(const msfwsi_conv_desc* d, const void* x, const void* w_cat, void* y, const void* src2, int C2,
+                          const float* post_scale, const float* post_shift, const void* ident, int relu,
+                          unsigned char* gate_out, void* stream);
+
 /* dx = conv_transpose(dy, w) [+ resid] [+ gap_scale * gapg[image]]  (input gradient).  w is the forward
  * weight [K][R][S][C], read in place as the [k][n] operand.  resid: [N,H,W,C] added element-wise (the
  * identity-path gradient of a residual block); gapg: [N][C] broadcast over H*W (global-average-pool
@@ -178,6 +187,10 @@ int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW, int C, vo
  *   fold_weights: dW += k1 o M + k2 o WA + k3 (x) sa;  Wk1 = k1 o W;  Wk2 = k2 o W;  bvec[c] += sum_k k3[k] W[k][c]
  * (WA = W (a^T a), sa = column sums of a, k1..k3 from msfwsi_bn_bwd_finalize).  All fp32 / fp64. */
 int msfwsi_fold_dots(const float* W, const float* M, double* out, int K, int C, void* stream);
+/* out[k] = [s1[k]*W1[k][0:C1] | s2[k]*W2[k][0:C2]] (fp32 [K][C1+C2]), shift[k] = b1[k] + b2[k]: two BatchNorm
+ * affines folded into the rows of the two 1x1 weight matrices whose outputs are summed (msfwsi_conv_fwd_post2). */
+int msfwsi_row_scale_cat(const float* W1, const float* s1, int C1, const float* W2, const float* s2, int C2,
+                         const float* b1, const float* b2, float* out, float* shift, int K, void* stream);
 /* out[k] = sum_c W[k][c]*v[c] (fp64).  With v = column sums of a and fold_dots(W, W (a^T a)) this yields the
  * BatchNorm statistics {sum c, sum c^2} of c = W a WITHOUT forming c: the forward of conv3 -> bn3 then runs the
  * conv once with the BatchNorm apply + residual + ReLU in its epilogue (msfwsi_conv_fwd_post). */

@@ -50,8 +50,10 @@ SIGNATURES = {
     "msfwsi_bn_act_sum": [_i, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp],
     "msfwsi_fold_matvec": [_vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_stem_conv_fwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "msfwsi_conv_fwd_post2": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "msfwsi_conv_dgrad2": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_conv_fwd_post": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "msfwsi_row_scale_cat": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_fold_dots": [_vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_fold_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_colsum": [_i, _vp, _vp, _l, _i, _vp],

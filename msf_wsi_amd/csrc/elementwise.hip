@@ -679,6 +679,20 @@ __global__ void fold_matvec_kernel(const float* __restrict__ W, const double* __
     if (lane == 0) out[k] = acc;
 }
 
+// out[k][0:C1] = s1[k]*W1[k][:],  out[k][C1:C1+C2] = s2[k]*W2[k][:],  shift[k] = b1[k] + b2[k]: two BatchNorms folded
+// into the weight rows of the two 1x1 convs they follow (Bottleneck tail + downsample branch in one GEMM)
+__global__ void row_scale_cat_kernel(const float* __restrict__ W1, const float* __restrict__ s1, int C1,
+                                     const float* __restrict__ W2, const float* __restrict__ s2, int C2,
+                                     const float* __restrict__ b1, const float* __restrict__ b2,
+                                     float* __restrict__ out, float* __restrict__ shift, int K) {
+    const int k = blockIdx.x;
+    const int Ct = C1 + C2;
+    const float a = s1[k], b = s2[k];
+    for (int c = threadIdx.x; c < Ct; c += blockDim.x)
+        out[(long)k * Ct + c] = c < C1 ? a * W1[(long)k * C1 + c] : b * W2[(long)k * C2 + (c - C1)];
+    if (threadIdx.x == 0) shift[k] = b1[k] + b2[k];
+}
+
 constexpr int kFoldRows = 16;
 __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ Mm,
                                     const float* __restrict__ WA, const float* __restrict__ k1,
@@ -941,6 +955,14 @@ extern "C" int msfwsi_fold_dots(const float* W, const float* M, double* out, int
 extern "C" int msfwsi_fold_matvec(const float* W, const double* v, double* out, int K, int C, void* stream) {
     MSFWSI_CHECK_ARG(W && v && out && K > 0 && C > 0);
     hipLaunchKernelGGL(fold_matvec_kernel, dim3((K + 3) / 4), dim3(256), 0, ST(stream), W, v, out, K, C);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_row_scale_cat(const float* W1, const float* s1, int C1, const float* W2, const float* s2, int C2,
+                                    const float* b1, const float* b2, float* out, float* shift, int K, void* stream) {
+    MSFWSI_CHECK_ARG(W1 && s1 && W2 && s2 && b1 && b2 && out && shift && C1 > 0 && C2 > 0 && K > 0);
+    hipLaunchKernelGGL(row_scale_cat_kernel, dim3(K), dim3(256), 0, ST(stream), W1, s1, C1, W2, s2, C2, b1, b2, out,
+                       shift, K);
     return msfwsi_launch_status();
 }
 

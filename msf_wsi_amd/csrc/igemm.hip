@@ -690,7 +690,8 @@ __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds
 // with a zero weight column: the 7x7/C=3 stem becomes 7 taps x 2 slabs on this kernel instead of the generic one.
 template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, int EPI = 0, bool TWO = false, bool RUN = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams prm) {
-    static_assert(!(TWO && !DGRAD) && !(DGRAD && EPI != 0), "second source: input gradient; post epilogue: forward");
+    static_assert(!(TWO && !DGRAD && EPI != 1) && !(DGRAD && EPI != 0),
+                  "second source: input gradient or post-epilogue forward; post epilogue: forward");
     static_assert(!(RUN && (DGRAD || TWO || EPI != 0)), "run mode: plain forward only");
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, false> Cfg;
     constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
@@ -838,7 +839,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                 const int soff2 = (k0 - prm.C) * ES;
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) dma16_buf(srd_a2, Ab2 + i * NW * 1024, a_voff2[i], soff2);
-                const int soffb2 = (int)((long)k0 * prm.Nout * ES);
+                const int soffb2 = DGRAD ? (int)((long)k0 * prm.Nout * ES) : k0 * ES;  // [k][n] rows / [n][k] columns
 #pragma unroll
                 for (int i = 0; i < NB; ++i) dma16_buf(srd_b, Bb2 + i * NW * 1024, b_voff[i], soffb2);
                 k0 += BK;
@@ -973,6 +974,10 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
             } else {
                 kern = prm.post_scale != nullptr ? igemm_dma_kernel<T, BM, BN, WM, WN, false, 1, false>
                                                  : igemm_dma_kernel<T, BM, BN, WM, WN, false, 0, false>;
+                if (prm.src2 != nullptr) {
+                    if (prm.post_scale == nullptr) return MSFWSI_EUNSUPPORTED;
+                    kern = igemm_dma_kernel<T, BM, BN, WM, WN, false, 1, true>;
+                }
                 if constexpr (BN == 64) {
                     if (prm.pix_stride > 0) kern = igemm_dma_kernel<T, BM, BN, WM, WN, false, 0, false, true>;
                 }
@@ -1140,6 +1145,32 @@ extern "C" int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, co
     prm.R = d->R; prm.S = d->S; prm.stride = d->stride; prm.pad = d->pad;
     prm.M = d->N * d->P * d->Q;
     prm.Ktot = d->R * d->S * d->C;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MSFWSI_WITH_T(d->dtype, return dispatch_tile<T, false, false>(prm, st));
+    return MSFWSI_EINVAL;
+}
+
+extern "C" int msfwsi_conv_fwd_post2(const msfwsi_conv_desc* d, const void* x, const void* w_cat, void* y,
+                                     const void* src2, int C2, const float* post_scale, const float* post_shift,
+                                     const void* ident, int relu, unsigned char* gate_out, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MSFWSI_OK) return rc;
+    MSFWSI_CHECK_ARG(x && w_cat && y && src2 && C2 > 0 && post_scale && post_shift);
+    const int bk = d->dtype == MSFWSI_DT_F32 ? 16 : 32;
+    if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->C % bk != 0 || C2 % bk != 0 || !g_fast_dma)
+        return MSFWSI_EUNSUPPORTED;
+    IgemmParams prm{};
+    prm.src = x; prm.wgt = w_cat; prm.out = y;
+    prm.src2 = src2; prm.C2 = C2;
+    prm.post_scale = post_scale; prm.post_shift = post_shift; prm.post_relu = relu ? 1 : 0;
+    prm.resid = ident;
+    prm.gate_out = gate_out;
+    prm.nshard = 1;
+    prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C;
+    prm.P = d->P; prm.Q = d->Q; prm.Nout = d->K;
+    prm.R = 1; prm.S = 1; prm.stride = 1; prm.pad = 0;
+    prm.M = d->N * d->P * d->Q;
+    prm.Ktot = d->C + C2;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     MSFWSI_WITH_T(d->dtype, return dispatch_tile<T, false, false>(prm, st));
     return MSFWSI_EINVAL;

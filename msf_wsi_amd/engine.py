@@ -205,6 +205,7 @@ class Engine:
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
         self.fold_ds = os.environ.get("MSFWSI_FOLD_DS", "1") != "0"  # stride-1 downsample branch folded like bn3
+        self.fold_ds_fwd = os.environ.get("MSFWSI_FOLD_DS_FWD", "1") != "0"  # ... and its forward: one two-source GEMM
         self.mat_min_rows = int(os.environ.get("MSFWSI_MAT_MIN_ROWS", "1"))  # rows from which 1x1 operands are materialised
         self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -329,6 +330,56 @@ class Engine:
             self._stem_cache[key] = hit
         return kn.stem_conv_fwd(x, hit[1], c, stats, R, S, op.stride[0], op.padding[0])
 
+    def _gram_stats(self, w: torch.Tensor, A: torch.Tensor, sa: torch.Tensor, bn: nn.Module, count: int, dtype) -> BNState:
+        """BatchNorm batch statistics of c = W a (1x1 conv) from the Gram matrix A = a^T a and the column sums of a:
+        sum c = W sum(a), sum c^2 = diag(W A W^T); w = the compute-dtype weights [K][1][1][C] the MFMA multiplies"""
+        K, Cw = w.shape[0], w.shape[-1]
+        dev = w.device
+        Wq = w if dtype == torch.float32 else w.float()
+        dlin = kn.conv_desc(torch.float32, K, 1, 1, Cw, Cw, 1, 1, 1, 0)
+        WA = torch.empty(K, 1, 1, Cw, dtype=torch.float32, device=dev)
+        kn.conv_fwd(dlin, Wq, A, WA)  # A is symmetric
+        stats = kn.zeros((1, 2, K), torch.float64, dev)
+        kn.fold_matvec(Wq, sa, stats[0, 0])
+        kn.fold_dots(Wq, WA, stats[0, 1])
+        return self._bn_finalize(stats, count, bn)
+
+    def _ds_tail_fwd(self, conv3, bn3, dconv, dbn, c2: torch.Tensor, pro: BNState, x: torch.Tensor, geom, dtype,
+                     want_bits: bool):
+        """y = relu(bn3(conv3(a2)) + bn_d(conv_d(x))) for a Bottleneck with a stride-1 downsample branch
+        (layer1.0, resnet.py:131-138 with self.downsample) as ONE two-source GEMM: both BatchNorms' batch statistics
+        come from Gram matrices (of a2 and of x), their scales are folded into the weight rows and their shifts
+        summed; neither conv output exists.  Returns (unit3, unit_ds, y, gate bits)."""
+        N, H, W, Cw = geom
+        K, Ci = conv3.out_channels, x.shape[-1]
+        dev = c2.device
+        d3 = kn.conv_desc(dtype, N, H, W, Cw, K, 1, 1, 1, 0)
+        dd = kn.conv_desc(dtype, N, H, W, Ci, K, 1, 1, 1, 0)
+        a2 = torch.empty_like(c2)
+        sa = kn.zeros((Cw,), torch.float64, dev)
+        kn.bn_act_sum(c2, pro.scale, pro.shift, a2, sa)
+        A2 = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
+        kn.conv_wgrad(kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0), a2, a2, A2)
+        Ax = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
+        kn.conv_wgrad(kn.conv_desc(dtype, N, H, W, Ci, Ci, 1, 1, 1, 0), x, x, Ax)
+        sx = kn.zeros((Ci,), torch.float64, dev)
+        kn.colsum(x, sx)
+        st3 = self._gram_stats(self.weights.get(conv3.weight, dtype), A2, sa, bn3, N * H * W, dtype)
+        std = self._gram_stats(self.weights.get(dconv.weight, dtype), Ax, sx, dbn, N * H * W, dtype)
+        wcat32 = torch.empty(K, Cw + Ci, dtype=torch.float32, device=dev)
+        shift = torch.empty(K, dtype=torch.float32, device=dev)
+        kn.row_scale_cat(WeightStore.physical(conv3.weight), st3.scale, WeightStore.physical(dconv.weight), std.scale,
+                         st3.shift, std.shift, wcat32, shift)
+        wcat = wcat32 if dtype == torch.float32 else kn.cast_lowp(wcat32, torch.empty_like(wcat32, dtype=dtype))
+        one, _ = self._unit_gate(K, dev)
+        y = torch.empty(N, H, W, K, dtype=dtype, device=dev)
+        bits = kn.gate_bytes(N * H * W, K, dtype, dev) if want_bits else None
+        if not kn.conv_fwd_post2(d3, a2, wcat, y, x, one, shift, relu=True, gate_out=bits):
+            return None
+        u3 = Unit(conv3, bn3, False, d3, c2, pro, None, st3, gram=(A2, sa))
+        ud = Unit(dconv, dbn, False, dd, x, None, None, std, gram=(Ax, sx))
+        return u3, ud, y, bits
+
     def _conv_bn_res_fwd(self, conv: nn.Module, bn: nn.Module, c_in: torch.Tensor, pro: BNState, ident: torch.Tensor,
                          geom, dtype: torch.dtype, want_bits: bool = False):
         """y = relu(bn(conv1x1(a)) + ident), a = relu(pro(c_in)), without the conv output c = W a ever reaching HBM
@@ -349,14 +400,7 @@ class Engine:
         A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
         kn.conv_wgrad(dsq, a, a, A)
         w = self.weights.get(conv.weight, dtype)
-        Wq = w if dtype == torch.float32 else w.float()  # the values the MFMA multiplies
-        dlin = kn.conv_desc(torch.float32, K, 1, 1, Cw, Cw, 1, 1, 1, 0)
-        WA = torch.empty(K, 1, 1, Cw, dtype=torch.float32, device=dev)
-        kn.conv_fwd(dlin, Wq, A, WA)  # A is symmetric
-        stats = kn.zeros((1, 2, K), torch.float64, dev)
-        kn.fold_matvec(Wq, sa, stats[0, 0])
-        kn.fold_dots(Wq, WA, stats[0, 1])
-        st = self._bn_finalize(stats, N * H * W, bn)
+        st = self._gram_stats(w, A, sa, bn, N * H * W, dtype)
         y = torch.empty(N, H, W, K, dtype=dtype, device=dev)
         bits = kn.gate_bytes(N * H * W, K, dtype, dev) if want_bits else None
         kn.conv_fwd_post(d, a, w, y, st.scale, st.shift, ident=ident, relu=True, gate_out=bits)
@@ -441,11 +485,33 @@ class Engine:
                 conv3 = main[-1][0]
                 fused_tail = (self.fold_bn3_fwd and len(main) == 3 and blk.downsample is None
                               and conv3.kernel_size == (1, 1) and conv3.stride == (1, 1) and conv3.bias is None)
-                for ui, (conv, bn) in enumerate(main[:-1] if fused_tail else main):
+                dsc = blk.downsample[0] if blk.downsample is not None else None
+                bkk = 16 if dtype == torch.float32 else 32
+                ds_tail = (self.fold_bn3_fwd and self.fold_bn3 and self.fold_ds and self.fold_ds_fwd and len(main) == 3
+                           and dsc is not None and conv3.kernel_size == (1, 1) and conv3.stride == (1, 1)
+                           and conv3.bias is None and dsc.kernel_size == (1, 1) and dsc.stride == (1, 1)
+                           and dsc.bias is None and dsc.in_channels % bkk == 0 and conv3.in_channels % bkk == 0
+                           and main[1][0].stride == (1, 1))
+                for ui, (conv, bn) in enumerate(main[:-1] if (fused_tail or ds_tail) else main):
                     u = self._unit_fwd(conv, bn, ui + 1 < len(main), cur, cur_pro, (N, gh, gw, cur.shape[-1]), dtype)
                     units.append(u)
                     cur, cur_pro, gh, gw = u.c, u.st, u.desc.P, u.desc.Q
                 ds = None
+                if ds_tail:
+                    got = self._ds_tail_fwd(conv3, main[-1][1], blk.downsample[0], blk.downsample[1], cur, cur_pro, y,
+                                            (N, gh, gw, cur.shape[-1]), dtype,
+                                            want_bits=save and self.fuse_gate and self.gate_bits)
+                    if got is not None:
+                        u, ds, y_out, bits = got
+                        units.append(u)
+                        if save:
+                            blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1, gate_bits=bits))
+                        y, h, w = y_out, gh, gw
+                        continue
+                    # no two-source kernel for this shape: conv3 in the ordinary way
+                    u = self._unit_fwd(conv3, main[-1][1], False, cur, cur_pro, (N, gh, gw, cur.shape[-1]), dtype)
+                    units.append(u)
+                    cur, cur_pro, gh, gw = u.c, u.st, u.desc.P, u.desc.Q
                 if fused_tail:
                     u, y_out, bits = self._conv_bn_res_fwd(conv3, main[-1][1], cur, cur_pro, y,
                                                            (N, gh, gw, cur.shape[-1]), dtype,
@@ -591,10 +657,13 @@ class Engine:
         Wd = WeightStore.physical(u.op.weight).view(K, 1, 1, Ci)
         Md = kn.zeros((K, 1, 1, Ci), torch.float32, dev)
         kn.conv_wgrad(d, x, g, Md)
-        Ax = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
-        kn.conv_wgrad(kn.conv_desc(dtype, d.N, d.H, d.W, Ci, Ci, 1, 1, 1, 0), x, x, Ax)
-        sx = kn.zeros((Ci,), torch.float64, dev)
-        kn.colsum(x, sx)
+        if u.gram is not None:  # kept by the two-source forward
+            Ax, sx = u.gram
+        else:
+            Ax = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
+            kn.conv_wgrad(kn.conv_desc(dtype, d.N, d.H, d.W, Ci, Ci, 1, 1, 1, 0), x, x, Ax)
+            sx = kn.zeros((Ci,), torch.float64, dev)
+            kn.colsum(x, sx)
         packed = torch.empty(ns * K, dtype=torch.float64, device=dev)
         kn.shard_sum(sums, packed)  # slot 0 = sum(g) (local)
         sd = kn.zeros((1, 2, K), torch.float64, dev)

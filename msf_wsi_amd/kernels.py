@@ -276,6 +276,47 @@ def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu
     return y
 
 
+def conv_fwd_post2(d: ConvDesc, x, w_cat, y, src2, post_scale, post_shift, ident=None, relu=True, gate_out=None) -> bool:
+    """y = [relu](round(x . w_cat[:, :C] + src2 . w_cat[:, C:]) * post_scale + post_shift + ident); False if the
+    library has no kernel for the shape"""
+    lib = _lib.load()
+    dt = x.dtype
+    C2 = src2.shape[-1]
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(w_cat, "w_cat", dt, d.K * (d.C + C2))
+    _req(y, "y", dt, d.N * d.P * d.Q * d.K)
+    _req(src2, "src2", dt, d.N * d.P * d.Q * C2)
+    _req(post_scale, "post_scale", torch.float32, d.K)
+    _req(post_shift, "post_shift", torch.float32, d.K)
+    _opt(ident, "ident", dt, d.N * d.P * d.Q * d.K)
+    _opt(gate_out, "gate_out", torch.uint8, d.N * d.P * d.Q * (d.K // vec_of(dt)))
+    rc = [0]
+
+    def run():
+        rc[0] = lib.msfwsi_conv_fwd_post2(C.byref(d), _p(x), _p(w_cat), _p(y), _p(src2), int(C2), _p(post_scale),
+                                          _p(post_shift), _p(ident), int(bool(relu)), _p(gate_out), _stream())
+        if rc[0] != -2:
+            _lib.check(rc[0], "conv_fwd_post2")
+
+    _timed("conv_fwd", d, x.element_size(), run, extra_elems=src2.numel() + (ident.numel() if ident is not None else 0),
+           dtype=dt, epi=1, two=True)
+    return rc[0] == 0
+
+
+def row_scale_cat(W1, s1, W2, s2, b1, b2, out, shift):
+    """out = [s1 o W1 | s2 o W2] (rows scaled, columns concatenated), shift = b1 + b2   (all fp32)"""
+    lib = _lib.load()
+    K = s1.numel()
+    C1, C2 = W1.numel() // K, W2.numel() // K
+    _req(W1, "W1", torch.float32, K * C1)
+    _req(W2, "W2", torch.float32, K * C2)
+    for nm, t in (("s1", s1), ("s2", s2), ("b1", b1), ("b2", b2), ("shift", shift)):
+        _req(t, nm, torch.float32, K)
+    _req(out, "out", torch.float32, K * (C1 + C2))
+    _lib.check(lib.msfwsi_row_scale_cat(_p(W1), _p(s1), C1, _p(W2), _p(s2), C2, _p(b1), _p(b2), _p(out), _p(shift), K,
+                                        _stream()), "row_scale_cat")
+
+
 def fold_matvec(W, v, out):
     """out[k] = sum_c W[k][c] * v[c]   (fp64)"""
     lib = _lib.load()

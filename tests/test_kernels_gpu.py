@@ -121,6 +121,34 @@ def test_conv_fwd_post(hip_lib, dt, geom, with_ident):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(3, 10, 64, 64, 256), (2, 7, 128, 256, 200), (1, 5, 32, 64, 64)])
+def test_conv_fwd_post2_two_sources(hip_lib, dt, shape):
+    """y = relu(round(x . W1^T + s2 . W2^T) * scale + shift): a Bottleneck tail with its downsample branch"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, C1, C2, K = shape
+    g = torch.Generator().manual_seed(16)
+    x = rnd((N * H * H, C1), dt, g)
+    s2 = rnd((N * H * H, C2), dt, g)
+    W1 = rnd((K, C1), dt, g, 1.0 / math.sqrt(C1))
+    W2 = rnd((K, C2), dt, g, 1.0 / math.sqrt(C2))
+    ps, pb = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    acc = x.double() @ W1.double().t() + s2.double() @ W2.double().t()
+    ref = F.relu(acc.float().to(dt).double() * ps.double() + pb.double()).float()
+    d = kn.conv_desc(dt, N, H, H, C1, K, 1, 1, 1, 0)
+    y = torch.empty(N, H, H, K, dtype=dt, device="cuda")
+    bits = kn.gate_bytes(N * H * H, K, dt)
+    wcat = torch.cat([W1, W2], 1).to(dt).cuda()
+    assert kn.conv_fwd_post2(d, x.to(dt).cuda().view(N, H, H, C1), wcat, y, s2.to(dt).cuda().view(N, H, H, C2),
+                             ps.cuda(), pb.cuda(), relu=True, gate_out=bits)
+    torch.cuda.synchronize()
+    assert rel(y.float().cpu().view(-1, K), ref) < tol(dt)
+    vec = 4 if dt == torch.float32 else 8
+    want = (y.reshape(-1, K // vec, vec) > 0).to(torch.int32) * (2 ** torch.arange(vec, device="cuda", dtype=torch.int32))
+    assert torch.equal(bits.to(torch.int32), want.sum(-1))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(3, 10, 256, 64, 64), (2, 7, 512, 128, 128), (1, 5, 64, 32, 32)])
 def test_conv_dgrad2_two_sources(hip_lib, dt, shape):
     """dx = gate(dy . W1 + src2 . W2 + bias): the two-source 1x1 input gradient of the folded bn3 backward"""
