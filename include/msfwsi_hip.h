@@ -208,6 +208,13 @@ int msfwsi_add_f64_to_f32(const double* in, float* out, int n, float alpha, void
 int msfwsi_rows_permute(int dtype, const void* in, const long* idx, void* out, int B, int K, int C, int scatter,
                         int accumulate, void* stream);
 
+/* Strided pixel subsampling of an NHWC tensor [N,H,W,C] and its adjoint (P = (H-1)/stride+1, Q likewise):
+ * expand == 0: out[N,P,Q,C] = in[:, ::stride, ::stride, :] -- the operand of a stride-s 1x1 conv (the downsample
+ * branch, src/models/resnet.py:222-225) as a dense tensor; expand == 1: out[N,H,W,C] = in[N,P,Q,C] zero-stuffed
+ * (the input gradient of that subsampling). */
+int msfwsi_pixel_stride(int dtype, const void* in, void* out, int N, int H, int W, int C, int stride, int expand,
+                        void* stream);
+
 /* dst[r][0:cols] (+)= src[r][0:cols] with row strides (fuser concat, backbone.py:195-202, and adjoint). */
 int msfwsi_copy2d(int dtype, const void* src, long src_ld, void* dst, long dst_ld, long rows, int cols,
                   int accumulate, void* stream);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "msfwsi_colsum": [_i, _vp, _vp, _l, _i, _vp],
     "msfwsi_add_f64_to_f32": [_vp, _vp, _i, _f, _vp],
     "msfwsi_rows_permute": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "msfwsi_pixel_stride": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "msfwsi_copy2d": [_i, _vp, _l, _vp, _l, _l, _i, _i, _vp],
     "msfwsi_cosine_loss": [_i, _vp, _vp, _l, _i, _f, _vp, _f, _vp, _vp, _vp],
     "msfwsi_nonfinite_check": [_vp, _l, _vp, _vp],

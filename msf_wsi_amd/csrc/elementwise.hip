@@ -725,6 +725,39 @@ __global__ void add_f64_to_f32_kernel(const double* __restrict__ in, float* out,
 // jigsaw row gather / scatter (backbone.py:147-158): out[b*K+k] = in[b*K+idx[b][k]]
 // scatter=1 is its adjoint: out[b*K+idx[b][k]] (+)= in[b*K+k]   (idx rows are permutations)
 // ---------------------------------------------------------------------------------------------
+// strided pixel subsampling of an NHWC tensor and its adjoint (the operand of a stride-s 1x1 conv as a dense tensor,
+// and the zero-stuffed full-resolution gradient of that operand):
+//   expand == 0: lo[n][p][q][:] = full[n][p*s][q*s][:]            (one thread per 16-byte chunk of lo)
+//   expand == 1: full[n][h][w][:] = (h%s == 0 && w%s == 0) ? lo[n][h/s][w/s][:] : 0   (one thread per chunk of full)
+template <typename T>
+__global__ void pixel_stride_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int P, int Q,
+                                    int C, int s, int expand) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int cpr = C / VEC;
+    const long total = (long)N * (expand ? (long)H * W : (long)P * Q) * cpr;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cpr);
+        long pix = i / cpr;
+        if (!expand) {
+            const int q = (int)(pix % Q);
+            pix /= Q;
+            const int p = (int)(pix % P);
+            const long n = pix / P;
+            const long src = ((n * H + (long)p * s) * W + (long)q * s) * C + cv * VEC;
+            *reinterpret_cast<uint4*>(out + i * VEC) = *reinterpret_cast<const uint4*>(in + src);
+        } else {
+            const int w = (int)(pix % W);
+            pix /= W;
+            const int h = (int)(pix % H);
+            const long n = pix / H;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (h % s == 0 && w % s == 0 && h / s < P && w / s < Q)
+                v = *reinterpret_cast<const uint4*>(in + ((n * P + h / s) * Q + w / s) * C + cv * VEC);
+            *reinterpret_cast<uint4*>(out + i * VEC) = v;
+        }
+    }
+}
+
 template <typename T>
 __global__ void rows_permute_kernel(const T* __restrict__ in, const long* __restrict__ idx, T* __restrict__ out,
                                     int B, int K, int C, int scatter, int accumulate) {
@@ -987,6 +1020,17 @@ extern "C" int msfwsi_rows_permute(int dtype, const void* in, const long* idx, v
     const long total = (long)B * K * (C / vec_of(dtype));
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(rows_permute_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
                            (const T*)in, idx, (T*)out, B, K, C, scatter, accumulate));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_pixel_stride(int dtype, const void* in, void* out, int N, int H, int W, int C, int stride,
+                                   int expand, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && in && out && N > 0 && H > 0 && W > 0 && stride >= 1);
+    MSFWSI_CHECK_ARG(C % vec_of(dtype) == 0);
+    const int P = (H - 1) / stride + 1, Q = (W - 1) / stride + 1;
+    const long total = (long)N * (expand ? (long)H * W : (long)P * Q) * (C / vec_of(dtype));
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(pixel_stride_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0,
+                                            ST(stream), (const T*)in, (T*)out, N, H, W, P, Q, C, stride, expand));
     return msfwsi_launch_status();
 }
 

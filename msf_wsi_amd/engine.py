@@ -51,6 +51,7 @@ class Unit:
     c: torch.Tensor                  # raw output (None: never formed / dropped, see _conv_bn_res_fwd)
     st: Optional[BNState] = None
     gram: Optional[Tuple[torch.Tensor, torch.Tensor]] = None  # (a^T a, sum a) of the normalised operand, fp32/fp64
+    lo: Optional[Tuple[int, tuple]] = None  # (stride, full-resolution shape): x is a strided subsampling of the input
 
 
 @dataclass
@@ -206,6 +207,7 @@ class Engine:
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
         self.fold_ds = os.environ.get("MSFWSI_FOLD_DS", "1") != "0"  # stride-1 downsample branch folded like bn3
         self.fold_ds_fwd = os.environ.get("MSFWSI_FOLD_DS_FWD", "1") != "0"  # ... and its forward: one two-source GEMM
+        self.fold_ds_strided = os.environ.get("MSFWSI_FOLD_DS_STRIDED", "1") != "0"  # ... also for the stride-2 branches
         self.mat_min_rows = int(os.environ.get("MSFWSI_MAT_MIN_ROWS", "1"))  # rows from which 1x1 operands are materialised
         self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -489,20 +491,27 @@ class Engine:
                 bkk = 16 if dtype == torch.float32 else 32
                 ds_tail = (self.fold_bn3_fwd and self.fold_bn3 and self.fold_ds and self.fold_ds_fwd and len(main) == 3
                            and dsc is not None and conv3.kernel_size == (1, 1) and conv3.stride == (1, 1)
-                           and conv3.bias is None and dsc.kernel_size == (1, 1) and dsc.stride == (1, 1)
-                           and dsc.bias is None and dsc.in_channels % bkk == 0 and conv3.in_channels % bkk == 0
-                           and main[1][0].stride == (1, 1))
+                           and conv3.bias is None and dsc.kernel_size == (1, 1) and dsc.stride in ((1, 1), (2, 2))
+                           and dsc.padding == (0, 0) and dsc.bias is None and dsc.in_channels % bkk == 0
+                           and conv3.in_channels % bkk == 0 and main[1][0].stride == dsc.stride
+                           and main[0][0].stride == (1, 1) and (dsc.stride == (1, 1) or self.fold_ds_strided))
                 for ui, (conv, bn) in enumerate(main[:-1] if (fused_tail or ds_tail) else main):
                     u = self._unit_fwd(conv, bn, ui + 1 < len(main), cur, cur_pro, (N, gh, gw, cur.shape[-1]), dtype)
                     units.append(u)
                     cur, cur_pro, gh, gw = u.c, u.st, u.desc.P, u.desc.Q
                 ds = None
                 if ds_tail:
-                    got = self._ds_tail_fwd(conv3, main[-1][1], blk.downsample[0], blk.downsample[1], cur, cur_pro, y,
+                    xs = y
+                    if dsc.stride[0] > 1:  # the branch's operand as a dense tensor: y[:, ::s, ::s, :]
+                        xs = torch.empty(N, gh, gw, cin, dtype=dtype, device=y.device)
+                        kn.pixel_stride(y, xs, dsc.stride[0], expand=False)
+                    got = self._ds_tail_fwd(conv3, main[-1][1], blk.downsample[0], blk.downsample[1], cur, cur_pro, xs,
                                             (N, gh, gw, cur.shape[-1]), dtype,
                                             want_bits=save and self.fuse_gate and self.gate_bits)
                     if got is not None:
                         u, ds, y_out, bits = got
+                        if dsc.stride[0] > 1:
+                            ds.lo = (dsc.stride[0], tuple(y.shape))
                         units.append(u)
                         if save:
                             blocks.append(BlockRec(y, units, ds, y_out, gh * gw, si, bi == nb - 1, gate_bits=bits))
@@ -762,6 +771,9 @@ class Engine:
             resid = g
             if resid_ds is not None:
                 resid = resid_ds  # the skip connection IS the (folded) downsample branch
+                if rec.ds.lo is not None:  # strided branch: its input gradient lives on the subsampled pixels
+                    resid = torch.empty(rec.ds.lo[1], dtype=dtype, device=resid_ds.device)
+                    kn.pixel_stride(resid_ds, resid, rec.ds.lo[0], expand=True)
             elif rec.ds is not None:
                 kn.bn_bwd_apply(g, rec.ds.c, kd[0], kd[1], kd[2], g)  # g becomes d(downsample conv output)
                 self._unit_wgrad(rec.ds, g, grads, dtype)

@@ -317,6 +317,21 @@ def row_scale_cat(W1, s1, W2, s2, b1, b2, out, shift):
                                         _stream()), "row_scale_cat")
 
 
+def pixel_stride(x, out, stride: int, expand: bool):
+    """expand=False: out[N,P,Q,C] = x[:, ::stride, ::stride, :]; expand=True: out[N,H,W,C] = x[N,P,Q,C] zero-stuffed"""
+    lib = _lib.load()
+    full, lo = (out, x) if expand else (x, out)
+    N, H, W, Cn = full.shape
+    P, Q = (H - 1) // stride + 1, (W - 1) // stride + 1
+    _req(x, "x")
+    _req(out, "out", x.dtype)
+    if tuple(lo.shape) != (N, P, Q, Cn):
+        raise ValueError(f"pixel_stride: low-resolution tensor must be {(N, P, Q, Cn)}, got {tuple(lo.shape)}")
+    _lib.check(lib.msfwsi_pixel_stride(dt_of(x), _p(x), _p(out), N, H, W, Cn, int(stride), int(bool(expand)), _stream()),
+               "pixel_stride")
+    return out
+
+
 def fold_matvec(W, v, out):
     """out[k] = sum_c W[k][c] * v[c]   (fp64)"""
     lib = _lib.load()

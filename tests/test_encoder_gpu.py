@@ -71,6 +71,7 @@ def test_folded_bn3_backward_equals_explicit(hip_lib, dt):
         enc._engine.fold_bn3_fwd = fold   # forward: bn3 statistics from the Gram matrix, conv3 runs once, fused
         enc._engine.fold_ds = fold        # backward of layer1.0's stride-1 downsample branch folded the same way
         enc._engine.fold_ds_fwd = fold    # ... and its forward as one two-source GEMM with both BatchNorms folded in
+        enc._engine.fold_ds_strided = fold  # ... also for the stride-2 branches (operand subsampled to a dense tensor)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
             feats = enc(x)
         loss = sum((f.float() * r).sum() for f, r in zip(feats, Rs))

@@ -215,6 +215,26 @@ def test_stem_conv_as_row_runs(hip_lib, dt, hw):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hw", [(8, 8), (7, 9), (1, 1)])
+def test_pixel_stride_gather_and_expand(hip_lib, dt, hw):
+    from msf_wsi_amd import kernels as kn
+
+    H, W = hw
+    N, Cc, s = 3, 64, 2
+    g = torch.Generator().manual_seed(17)
+    x = rnd((N, H, W, Cc), dt, g).to(dt).cuda()
+    P, Q = (H - 1) // s + 1, (W - 1) // s + 1
+    lo = torch.empty(N, P, Q, Cc, dtype=dt, device="cuda")
+    kn.pixel_stride(x, lo, s, expand=False)
+    assert torch.equal(lo, x[:, ::s, ::s, :].contiguous())
+    full = torch.full((N, H, W, Cc), 7.0, dtype=dt, device="cuda")
+    kn.pixel_stride(lo, full, s, expand=True)
+    want = torch.zeros_like(x)
+    want[:, ::s, ::s, :] = lo
+    assert torch.equal(full, want)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(5000, 64), (333, 256), (70, 2048)])
 def test_bn_act_sum(hip_lib, dt, shape):
     from msf_wsi_amd import kernels as kn
