@@ -199,8 +199,9 @@ int msfwsi_fold_weights(const float* W, const float* M, const float* WA, const f
                         const float* k3, const double* sa, float* dW, float* Wk1, float* Wk2, float* bvec, int K, int C,
                         void* stream);
 
-/* column sums of x[M][C] added into sums[C] (fp64) -- bias gradient of backbone.py:30's Linear. */
-int msfwsi_colsum(int dtype, const void* x, double* sums, long M, int C, void* stream);
+/* column sums of x[M][C] added into sums[shard][C] (fp64, nshard replicas against same-address atomic contention)
+ * -- bias gradient of backbone.py:30's Linear; column sums of a folded BatchNorm's operand. */
+int msfwsi_colsum(int dtype, const void* x, double* sums, int nshard, long M, int C, void* stream);
 int msfwsi_add_f64_to_f32(const double* in, float* out, int n, float alpha, void* stream);
 
 /* scatter == 0: out[b*K+k] = in[b*K+idx[b][k]] (jigsaw un-shuffle, src/models/backbone.py:147-158);

@@ -570,7 +570,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict
 
 // column sums of [M][C] (bias gradient of the predictor's last Linear, backbone.py:30): out[c] += sum_m x
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, double* sums, long M, int C, int cw, int nrl,
+__global__ void colsum_kernel(const T* __restrict__ x, double* sums, int nshard, long M, int C, int cw, int nrl,
                               int rows_per_block) {
     constexpr int VEC = ElemTraits<T>::VEC;
     extern __shared__ float smem_f[];
@@ -592,7 +592,7 @@ __global__ void colsum_kernel(const T* __restrict__ x, double* sums, long M, int
             for (int e = 0; e < VEC; ++e) acc[0][e] += f[e];
         }
     }
-    col_commit<1, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, 1);
+    col_commit<1, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
 }
 
 // bn_act with the column sums of its OUTPUT: out = relu(scale*c+shift), sums[c] += sum_m out  (the folded bn3
@@ -969,13 +969,13 @@ extern "C" int msfwsi_bn_bwd_apply(int dtype, const void* g, const void* c, cons
     return msfwsi_launch_status();
 }
 
-extern "C" int msfwsi_colsum(int dtype, const void* x, double* sums, long M, int C, void* stream) {
-    MSFWSI_CHECK_ARG(dtype_ok(dtype) && x && sums && M > 0 && C % vec_of(dtype) == 0);
+extern "C" int msfwsi_colsum(int dtype, const void* x, double* sums, int nshard, long M, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && x && sums && nshard >= 1 && M > 0 && C % vec_of(dtype) == 0);
     const int vec = vec_of(dtype);
     ColGrid cg = make_col_grid(M, C, vec, 1024);
     const size_t lds = (size_t)kThreads * vec * sizeof(float);
-    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)x, sums, M,
-                           C, cg.cw, cg.nrl, cg.rows_per_block));
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)x, sums,
+                           nshard, M, C, cg.cw, cg.nrl, cg.rows_per_block));
     return msfwsi_launch_status();
 }
 
