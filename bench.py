@@ -151,6 +151,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    peak_reserved = torch.cuda.max_memory_reserved() / 2 ** 30
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -165,7 +166,7 @@ def main():
                        "arch": args.arch, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "image_size": args.size, "parallelism": f"dp{world}",
                        "images_per_s": round(34 * pairs / dt, 1), "loss": float(loss),
-                       "peak_mem_GiB": round(peak_mem, 1),
+                       "peak_mem_GiB": round(peak_mem, 1), "peak_reserved_GiB": round(peak_reserved, 1),
                        "step_TFLOPs_algorithmic": round(FLOP_PER_PAIR.get(args.arch, 0) * pairs / dt / 1e12, 1)},
         }
         if timer is not None:
