@@ -12,19 +12,20 @@
 //         (the forward weight tensor read as a [k][n] operand -> no transposed weight copy).
 //
 // Activations are NHWC, weights are [Cout][R][S][Cin] (torch channels_last physical layout).
-// Tile: BM x BN outputs per 256-thread workgroup (4 waves), 64-byte k-slab per stage (32 bf16 / 16 fp32),
-// two LDS stages.  Staging:
-//   * operand rows are 64 bytes = four 16-byte chunks, stored UNPADDED with the chunk index XOR-swizzled by
-//     (row>>2)&3, which makes every ds_read_b128 fragment read conflict-free (16-lane groups hit 16 distinct
-//     16-byte slots of the 256-byte bank row);
-//   * tiles that need no arithmetic on the way in (weights; activations without a BatchNorm prologue; dY) go
-//     global -> LDS directly with global_load_lds_dwordx4 (LDS-DMA: no VGPRs, no ds_write); the swizzle sits on
-//     the per-lane SOURCE address, out-of-image taps / out-of-range rows read a 16-byte zero page;
-//   * activations with a BatchNorm+ReLU prologue are register-staged: load, fma+max, ds_write_b128 into the same
-//     image (a lane writes the chunk the DMA would have written, so writes are linear per wave).
-// MFMA 32x32 (bf16: 32x32x16, fp32: 32x32x2 exact-fp32).  The weight tile is the MFMA A operand and the
-// activation tile the B operand, so a lane's 16 accumulator registers hold 4x4 consecutive output channels of
-// ONE pixel; the tile is then transposed through LDS and leaves as 16-byte row chunks.
+// Tiles: BM x BN outputs per workgroup (128x64 / 128x128 with 4 waves, 256x128 with 8), 64-byte k-slab per stage
+// (32 16-bit / 16 fp32 values), three LDS stages (two slabs in flight behind a counted s_waitcnt vmcnt + s_barrier).
+// Two kernels share the MFMA loop and the epilogue:
+//   * igemm_dma_kernel (97 % of the time): every operand byte arrives by `buffer_load_dwordx4 ... lds`.  Operand
+//     rows are 64 bytes = four 16-byte chunks stored UNPADDED with the chunk index XOR-swizzled by (row>>2)&3 (the
+//     swizzle sits on the per-lane SOURCE offset), which makes every ds_read_b128 fragment read conflict-free.  The
+//     per-lane byte offset of each piece is constant over the k loop; tap and channel slab move a wave-uniform scalar
+//     offset; out-of-image taps / rows use an out-of-range offset (zeros).  Template switches keep instances lean:
+//     EPI (epilogue feature class), TWO (second source tensor with its own k range), RUN (stem: filter-row runs).
+//   * igemm_kernel (generic): `global_load_lds` with per-lane 64-bit addresses and a zero page, runtime tap
+//     arithmetic, optional register-staged BatchNorm+ReLU prologue (APRO) -- stem-like channel counts, small heads.
+// MFMA 32x32x16 (bf16 / f16) or 32x32x2 (exact fp32).  The weight tile is the MFMA A operand and the activation
+// tile the B operand, so a lane's 16 accumulator registers hold 4x4 consecutive output channels of ONE pixel; the
+// tile is then transposed through LDS and leaves as 16-byte row chunks (igemm_epilogue).
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 

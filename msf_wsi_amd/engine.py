@@ -7,9 +7,11 @@ and exposes them to torch autograd as ONE node, so `loss.backward()` of the refe
 (tools/ssl_train.py:472) lands in the same kernels and parameter `.grad`s appear as ordinary tensors
 (DDP / optimizers read them unchanged).
 
-Memory model: per conv only the RAW output c is kept (storage dtype); BatchNorm+ReLU are re-applied inside
-the consumer kernels' operand loads from (c, scale, shift), forward and backward.  Residual-block outputs
-are the only normalised activations that are materialised.
+Memory model: per conv only the RAW output c is kept (storage dtype); normalised operands relu(bn(c)) are transient
+(one streaming pass where a dense kernel needs them).  Residual-block outputs are the only normalised activations
+that are kept.  The 4x-wide conv3 output of a Bottleneck (and the downsample branch's output) never exist: their
+BatchNorm statistics come from Gram matrices of the operands, the conv runs once with BatchNorm apply + residual +
+ReLU in its epilogue, and the BatchNorm backward is folded into [K][C] weight-sized matrices.
 
 There is no CPU / eager-torch fallback: CPU tensors raise.
 """
