@@ -172,10 +172,13 @@ int msfwsi_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H,
 int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scale, const float* shift, void* out,
                          unsigned char* argmax, int N, int H, int W, int C, void* stream);
 
-/* g0 = relu'(.) * maxpool_backward(dp); sums[shard][2][C] += {sum g0, sum g0*c0}. */
+/* Backward of relu + maxpool at the stem (resnet.py:235-237), g = relu'(.) * maxpool_backward(dp), in the two passes
+ * BatchNorm's backward forces (all of sum g, sum g*c0 before any dc0):
+ *   k1 == NULL: sums[shard][2][C] += {sum g, sum g*c0}; g0 (nullable) = g
+ *   k1 != NULL: g0 = k1*g + k2*c0 + k3 (g re-derived from dp / argmax instead of written and re-read); sums nullable */
 int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax, const void* c0,
-                         const float* scale, const float* shift, void* g0, double* sums, int nshard, int N, int H,
-                         int W, int C, void* stream);
+                         const float* scale, const float* shift, void* g0, double* sums, int nshard, const float* k1,
+                         const float* k2, const float* k3, int N, int H, int W, int C, void* stream);
 
 /* out[n][c] = mean over HW of y[n][hw][c].  Replaces: AdaptiveAvgPool2d((1,1)) + flatten on the four
  * stage outputs, src/models/resnet.py:244-250. */

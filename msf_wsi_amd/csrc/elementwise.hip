@@ -249,7 +249,12 @@ template <typename T>
 __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ amax,
                                      const T* __restrict__ c0, const float* __restrict__ scale,
                                      const float* __restrict__ shift, T* __restrict__ g0, double* sums, int nshard,
-                                     int N, int H, int W, int C, int P, int Q, int cw, int nrl, int rows_per_block) {
+                                     const float* __restrict__ k1, const float* __restrict__ k2,
+                                     const float* __restrict__ k3, int N, int H, int W, int C, int P, int Q, int cw,
+                                     int nrl, int rows_per_block) {
+    // two modes (BatchNorm's backward needs the sums of ALL of g before any dc can be formed):
+    //   k1 == null: g = gated pool gradient, sums += {sum g, sum g*c}; g0 (if given) = g
+    //   k1 != null: g0 = k1*g + k2*c + k3  (g re-derived on the fly instead of being written and re-read)
     constexpr int VEC = ElemTraits<T>::VEC;
     extern __shared__ float smem_f[];
     const int tid = threadIdx.x;
@@ -261,11 +266,14 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = 0.f;
     if (active) {
-        float sc[VEC], sh[VEC];
+        float sc[VEC], sh[VEC], q1[VEC], q2[VEC], q3[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             sc[e] = scale[ch + e];
             sh[e] = shift[ch + e];
+            q1[e] = k1 != nullptr ? k1[ch + e] : 0.f;
+            q2[e] = k1 != nullptr ? k2[ch + e] : 0.f;
+            q3[e] = k1 != nullptr ? k3[ch + e] : 0.f;
         }
         const long M = (long)N * H * W;
         const long rbeg = (long)blockIdx.y * rows_per_block;
@@ -309,10 +317,14 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
                 acc[0][e] += g[e];
                 acc[1][e] = fmaf(g[e], x[e], acc[1][e]);
             }
-            *reinterpret_cast<uint4*>(g0 + m * C + ch) = pack16<T>(g);
+            if (k1 != nullptr) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = fmaf(q1[e], g[e], fmaf(q2[e], x[e], q3[e]));
+            }
+            if (g0 != nullptr) *reinterpret_cast<uint4*>(g0 + m * C + ch) = pack16<T>(g);
         }
     }
-    col_commit<2, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
+    if (sums != nullptr) col_commit<2, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -892,16 +904,19 @@ extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scal
 }
 
 extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax, const void* c0,
-                                    const float* scale, const float* shift, void* g0, double* sums, int nshard, int N,
-                                    int H, int W, int C, void* stream) {
-    MSFWSI_CHECK_ARG(dtype_ok(dtype) && dp && argmax && c0 && scale && shift && g0 && sums && nshard >= 1);
+                                    const float* scale, const float* shift, void* g0, double* sums, int nshard,
+                                    const float* k1, const float* k2, const float* k3, int N, int H, int W, int C,
+                                    void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && dp && argmax && c0 && scale && shift && (g0 || sums) && nshard >= 1);
+    MSFWSI_CHECK_ARG((k1 == nullptr) == (k2 == nullptr) && (k1 == nullptr) == (k3 == nullptr));
+    MSFWSI_CHECK_ARG(k1 == nullptr || g0 != nullptr);
     MSFWSI_CHECK_ARG(N > 0 && H > 1 && W > 1 && C % vec_of(dtype) == 0 && (long)N * H * W <= 0x7fffffffL);
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     const int vec = vec_of(dtype);
     ColGrid g = make_col_grid((long)N * H * W, C, vec, 2048);
     const size_t lds = (size_t)kThreads * 2 * vec * sizeof(float);
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_kernel<T>, g.grid, dim3(kThreads), lds, ST(stream), (const T*)dp,
-                           argmax, (const T*)c0, scale, shift, (T*)g0, sums, nshard, N, H, W, C, P, Q, g.cw,
+                           argmax, (const T*)c0, scale, shift, (T*)g0, sums, nshard, k1, k2, k3, N, H, W, C, P, Q, g.cw,
                            g.nrl, g.rows_per_block));
     return msfwsi_launch_status();
 }

@@ -207,6 +207,9 @@ class Engine:
         self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
+        # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
+        # stem_pool_bwd + bn_bwd_apply (the pool-backward window logic is VALU-bound, not byte-bound): off
+        self.stem_two_pass = os.environ.get("MSFWSI_STEM_TWO_PASS", "0") != "0"
         self.fold_ds = os.environ.get("MSFWSI_FOLD_DS", "1") != "0"  # stride-1 downsample branch folded like bn3
         self.fold_ds_fwd = os.environ.get("MSFWSI_FOLD_DS_FWD", "1") != "0"  # ... and its forward: one two-source GEMM
         self.fold_ds_strided = os.environ.get("MSFWSI_FOLD_DS_STRIDED", "1") != "0"  # ... also for the stride-2 branches
@@ -631,11 +634,18 @@ class Engine:
         # stem: maxpool + relu + bn backward, then the 7x7 weight gradient
         st, u = ps.stem.st, ps.stem
         H0, W0 = u.desc.P, u.desc.Q
+        # two passes over (dy, argmax, c): sums first, then dc0 = k1*g + k2*c0 + k3 with g re-derived on the fly (the
+        # gated gradient g itself is never written: -2 passes over the largest tensor of the network)
+        sums = kn.new_stats(64, 2, u.c.device)
         g0 = torch.empty_like(u.c)
-        sums = kn.new_stats(64, 2, g0.device)
-        kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, sums, ps.N, H0, W0, 64)
-        k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
-        kn.bn_bwd_apply(g0, u.c, k[0], k[1], k[2], g0)
+        if self.stem_two_pass:
+            kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, None, sums, ps.N, H0, W0, 64)
+            k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
+            kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, None, ps.N, H0, W0, 64, k=(k[0], k[1], k[2]))
+        else:
+            kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, sums, ps.N, H0, W0, 64)
+            k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
+            kn.bn_bwd_apply(g0, u.c, k[0], k[1], k[2], g0)
         self._unit_wgrad(u, g0, grads, dtype)
 
     def _foldable(self, rec: BlockRec) -> bool:

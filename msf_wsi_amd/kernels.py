@@ -583,21 +583,30 @@ def stem_pool_fwd(c0, scale, shift, out, argmax, N, H, W, Cn):
                                         _stream()), "stem_pool_fwd")
 
 
-def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn):
+def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn, k=None):
+    """k=None: sums += {sum g, sum g*c0}, g0 (optional) = g;  k=(k1,k2,k3): g0 = k1*g + k2*c0 + k3"""
     lib = _lib.load()
     P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     _req(c0, "c0", None, N * H * W * Cn)
     _req(dp, "dp", c0.dtype, N * P * Q * Cn)
     _req(argmax, "argmax", torch.uint8, N * P * Q * Cn)
-    _req(g0, "g0", c0.dtype, N * H * W * Cn)
+    _opt(g0, "g0", c0.dtype, N * H * W * Cn)
     _req(scale, "scale", torch.float32, Cn)
     _req(shift, "shift", torch.float32, Cn)
-    _req(sums, "sums", torch.float64)
-    nsh = sums.numel() // (2 * Cn)
-    if nsh * 2 * Cn != sums.numel():
-        raise ValueError("stem_pool_bwd: sums must be [nshard,2,C]")
+    nsh = 1
+    if sums is not None:
+        _req(sums, "sums", torch.float64)
+        nsh = sums.numel() // (2 * Cn)
+        if nsh * 2 * Cn != sums.numel():
+            raise ValueError("stem_pool_bwd: sums must be [nshard,2,C]")
+    k1 = k2 = k3 = None
+    if k is not None:
+        k1, k2, k3 = k
+        for nm, t in (("k1", k1), ("k2", k2), ("k3", k3)):
+            _req(t, nm, torch.float32, Cn)
     _lib.check(lib.msfwsi_stem_pool_bwd(dt_of(c0), _p(dp), _p(argmax), _p(c0), _p(scale), _p(shift), _p(g0),
-                                        _p(sums), nsh, N, H, W, Cn, _stream()), "stem_pool_bwd")
+                                        _p(sums), nsh, _p(k1), _p(k2), _p(k3), N, H, W, Cn, _stream()),
+               "stem_pool_bwd")
 
 
 def gap_fwd(y, out, N, HW, Cn):

@@ -484,6 +484,18 @@ def test_stem_pool(hip_lib, dt, hw):
     gd = g0.double().cpu().reshape(-1, Cn)
     assert torch.allclose(s[0], gd.sum(0), rtol=1e-5, atol=1e-4)
     assert torch.allclose(s[1], (gd * c0d.double().cpu().reshape(-1, Cn)).sum(0), rtol=1e-5, atol=1e-4)
+    # sums-only pass, then the apply pass that re-derives g: dc = k1*g + k2*c0 + k3 without g in memory
+    sums2 = kn.new_stats(Cn)
+    kn.stem_pool_bwd(nhwc(dp).to(dt).cuda(), am, c0d, sc.cuda(), sh.cuda(), None, sums2, N, H, W, Cn)
+    assert torch.allclose(sums2.sum(0).cpu(), s, rtol=1e-9, atol=1e-9)
+    k1, k2, k3 = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.1, torch.randn(Cn, generator=g) * 0.1
+    dc = torch.empty_like(g0)
+    kn.stem_pool_bwd(nhwc(dp).to(dt).cuda(), am, c0d, sc.cuda(), sh.cuda(), dc, None, N, H, W, Cn,
+                     k=(k1.cuda(), k2.cuda(), k3.cuda()))
+    want = torch.empty_like(g0)
+    kn.bn_bwd_apply(g0, c0d, k1.cuda(), k2.cuda(), k3.cuda(), want)
+    torch.cuda.synchronize()
+    assert torch.equal(dc, want)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
