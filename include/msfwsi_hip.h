@@ -72,11 +72,14 @@ int msfwsi_conv_fwd_post2(const msfwsi_conv_desc* d, const void* x, const void* 
  * sums[shard][2][C] += {sum dx, sum dx*c} (what msfwsi_act_bwd_reduce would compute in a second pass).
  * mask_bits != NULL (instead of mask_c): the gate comes from the bytes msfwsi_conv_fwd_post wrote
  * ([N*H*W][C/vec]); sums slot 0 += sum dx, slot 1 is left alone.
+ * resid_stride s > 1: resid is the LOW-resolution tensor [N][(H-1)/s+1][(W-1)/s+1][C] and is added only at pixels
+ * with h % s == w % s == 0 -- the input gradient of a stride-s downsample branch without its zero-stuffed copy.
  * Replaces: autograd's convolution_backward(input) / linear backward(input) (+ threshold_backward and the
  * reduction half of batch_norm_backward) reached through scaler.scale(loss).backward(), ssl_train.py:472. */
 int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx, const void* resid,
                       const void* gapg, float gap_scale, const void* mask_c, const float* mask_scale,
-                      const float* mask_shift, const unsigned char* mask_bits, double* sums, int nshard, void* stream);
+                      const float* mask_shift, const unsigned char* mask_bits, double* sums, int nshard,
+                      int resid_stride, void* stream);
 
 /* Stem convolution (7x7 / stride 2 on 3 channels, src/models/resnet.py:174,234) on the pure-DMA kernel: x is
  * [N,H,W,CP] with the channels zero-padded to ONE 16-byte chunk (CP = 4 fp32 / 8 16-bit), w_run is

@@ -34,7 +34,7 @@ _desc = C.POINTER(ConvDesc)
 # name -> argtypes; must list every symbol declared in include/msfwsi_hip.h
 SIGNATURES = {
     "msfwsi_conv_fwd": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "msfwsi_conv_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_conv_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_conv_wgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_bn_finalize": [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "msfwsi_shard_sum": [_vp, _i, _i, _vp, _vp],

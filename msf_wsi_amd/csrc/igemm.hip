@@ -50,6 +50,8 @@ struct IgemmParams {
     const float* post_scale; // per output channel, nullable: out = [relu](round(acc)*post_scale + post_shift + resid)
     const float* post_shift;
     int post_relu;
+    int resid_stride;        // EPI 3: resid is [N][P/s][Q/s][Nout] and is added only at pixels with h % s == w % s == 0
+    FastDiv div_pq, div_q;   //   (the zero-stuffed gradient of a strided downsample branch, never materialised)
     int pix_stride;          // RUN kernels: elements between consecutive source pixels (the k range of one filter row
     int s_run;               //   is a run of s_run pixels x pix_stride channels, padded to C = a multiple of the slab)
     const void* src2;        // DGRAD 1x1 only, nullable: second source [M][C2] whose k-range follows the first
@@ -125,7 +127,7 @@ __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> 2) & 3)
 template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO, int EPI, typename Acc>
 __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, const IgemmParams& prm, char* smem,
                                                int tile_m, int m0, int n0) {
-    constexpr bool STD = EPI != 1, POST = EPI != 0;
+    constexpr bool STD = EPI != 1, POST = EPI == 1 || EPI == 2, LORES = EPI == 3;  // 3 = class 0 + strided residual
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, APRO> Cfg;
     constexpr int VEC = Cfg::VEC, TM = Cfg::TM, TN = Cfg::TN, NW = Cfg::NW, NT = 64 * Cfg::NW, LDC = Cfg::LDC;
     T* Cs = reinterpret_cast<T*>(smem);                             // [BM][LDC]
@@ -210,10 +212,27 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                     for (int e = 0; e < VEC; ++e) f[e] = fmaf(f[e], psc[e], psh[e]);
                 }
                 if (resid != nullptr) {
-                    float g[VEC];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(resid + off), g);
+                    if constexpr (LORES) {
+                        // pixel m = (n, h, w) of the [N][P][Q] output; the residual lives on the s-strided sub-grid
+                        const int sr = prm.resid_stride;
+                        const unsigned n = fast_div((unsigned)m, prm.div_pq);
+                        const unsigned rem = (unsigned)m - n * (unsigned)PQ;
+                        const unsigned h = fast_div(rem, prm.div_q);
+                        const unsigned w = rem - h * (unsigned)prm.Q;
+                        if (h % sr == 0 && w % sr == 0) {
+                            const int Pl = (prm.P - 1) / sr + 1, Ql = (prm.Q - 1) / sr + 1;
+                            const long lo = (((long)n * Pl + h / sr) * Ql + w / sr) * prm.Nout + ncol;
+                            float g[VEC];
+                            unpack16<T>(*reinterpret_cast<const uint4*>(resid + lo), g);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) f[e] += g[e];
+                            for (int e = 0; e < VEC; ++e) f[e] += g[e];
+                        }
+                    } else {
+                        float g[VEC];
+                        unpack16<T>(*reinterpret_cast<const uint4*>(resid + off), g);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) f[e] += g[e];
+                    }
                 }
                 if (gapg != nullptr) {
                     float gp[VEC];
@@ -691,8 +710,8 @@ __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds
 // with a zero weight column: the 7x7/C=3 stem becomes 7 taps x 2 slabs on this kernel instead of the generic one.
 template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, int EPI = 0, bool TWO = false, bool RUN = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams prm) {
-    static_assert(!(TWO && !DGRAD && EPI != 1) && !(DGRAD && EPI != 0),
-                  "second source: input gradient or post-epilogue forward; post epilogue: forward");
+    static_assert(!(TWO && !DGRAD && EPI != 1) && !(DGRAD && EPI != 0 && EPI != 3) && !(!DGRAD && EPI == 3),
+                  "second source: input gradient or post-epilogue forward; post epilogue: forward; strided residual: dgrad");
     static_assert(!(RUN && (DGRAD || TWO || EPI != 0)), "run mode: plain forward only");
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, false> Cfg;
     constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
@@ -972,6 +991,10 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
             if constexpr (DGRAD) {
                 kern = prm.src2 != nullptr ? igemm_dma_kernel<T, BM, BN, WM, WN, true, 0, true>
                                            : igemm_dma_kernel<T, BM, BN, WM, WN, true, 0, false>;
+                if (prm.resid_stride > 1) {
+                    if (prm.src2 != nullptr) return MSFWSI_EUNSUPPORTED;
+                    kern = igemm_dma_kernel<T, BM, BN, WM, WN, true, 3, false>;
+                }
             } else {
                 kern = prm.post_scale != nullptr ? igemm_dma_kernel<T, BM, BN, WM, WN, false, 1, false>
                                                  : igemm_dma_kernel<T, BM, BN, WM, WN, false, 0, false>;
@@ -985,7 +1008,7 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
             }
         }
     }
-    if (prm.src2 != nullptr && !dma) return MSFWSI_EUNSUPPORTED;  // only the pure-DMA kernel has the second source
+    if ((prm.src2 != nullptr || prm.resid_stride > 1) && !dma) return MSFWSI_EUNSUPPORTED;  // pure-DMA kernel features
     if (Cfg::LDS_BYTES > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
@@ -1180,10 +1203,11 @@ extern "C" int msfwsi_conv_fwd_post2(const msfwsi_conv_desc* d, const void* x, c
 extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
                                  const void* resid, const void* gapg, float gap_scale, const void* mask_c,
                                  const float* mask_scale, const float* mask_shift, const unsigned char* mask_bits,
-                                 double* sums, int nshard, void* stream) {
+                                 double* sums, int nshard, int resid_stride, void* stream) {
     int rc = check_desc(d);
     if (rc != MSFWSI_OK) return rc;
     MSFWSI_CHECK_ARG(dy != nullptr && w != nullptr && dx != nullptr);
+    MSFWSI_CHECK_ARG(resid_stride >= 0 && (resid_stride <= 1 || resid != nullptr));
     MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
     MSFWSI_CHECK_ARG(mask_c == nullptr || mask_bits == nullptr);
     MSFWSI_CHECK_ARG((mask_c == nullptr && mask_bits == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
@@ -1192,6 +1216,9 @@ extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, cons
     prm.resid = resid; prm.gapg = gapg; prm.gap_scale = gap_scale;
     prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
     prm.mask_bits = mask_bits;
+    prm.resid_stride = resid_stride > 1 ? resid_stride : 0;
+    prm.div_pq = make_fastdiv((unsigned)(d->H * d->W));
+    prm.div_q = make_fastdiv((unsigned)d->W);
     prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
     // source = dY [N,P,Q,K]; output = dX [N,H,W,C]
     prm.N = d->N; prm.H = d->P; prm.W = d->Q; prm.C = d->K;

@@ -213,6 +213,8 @@ class Engine:
         self.fold_ds = os.environ.get("MSFWSI_FOLD_DS", "1") != "0"  # stride-1 downsample branch folded like bn3
         self.fold_ds_fwd = os.environ.get("MSFWSI_FOLD_DS_FWD", "1") != "0"  # ... and its forward: one two-source GEMM
         self.fold_ds_strided = os.environ.get("MSFWSI_FOLD_DS_STRIDED", "1") != "0"  # ... also for the stride-2 branches
+        # their input gradient stays low-resolution: conv1's dgrad epilogue adds it on the strided sub-grid
+        self.lores_resid = os.environ.get("MSFWSI_LORES_RESID", "1") != "0"
         self.mat_min_rows = int(os.environ.get("MSFWSI_MAT_MIN_ROWS", "1"))  # rows from which 1x1 operands are materialised
         self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -446,15 +448,16 @@ class Engine:
             kn.add_f64_to_f32(cs, grads.get(bias), 1.0)
 
     def _unit_dgrad(self, u: Unit, dc: torch.Tensor, dtype: torch.dtype, resid=None, gapg=None, gap_scale=0.0,
-                    mask=None, sums=None, mask_bits=None):
+                    mask=None, sums=None, mask_bits=None, resid_stride: int = 1):
         d = u.desc
         dx = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dc.device)
         w = self.weights.get(u.op.weight, dtype)
-        if self.halo3x3 and gapg is None and mask_bits is None and d.K <= 64 and kn.conv3x3_supported(d):
+        if (self.halo3x3 and gapg is None and mask_bits is None and resid_stride == 1 and d.K <= 64
+                and kn.conv3x3_supported(d)):
             kn.conv3x3_dgrad(d, dc, w, dx, resid=resid, mask=mask, sums=sums)
         else:
             kn.conv_dgrad(d, dc, w, dx, resid=resid, gapg=gapg, gap_scale=gap_scale, mask=mask, sums=sums,
-                          mask_bits=mask_bits)
+                          mask_bits=mask_bits, resid_stride=resid_stride)
         return dx
 
     # ---- encoder -------------------------------------------------------------------------------
@@ -780,12 +783,15 @@ class Engine:
         """returns (gradient w.r.t. the block input, its fused-gate sums or None -- see encoder_backward)"""
         if self._foldable(rec):
             g, da, s2, kd, resid_ds = self._block_end_folded(rec, dy, gapg, grads, dtype, pre=pre)
-            resid = g
+            resid, rstride = g, 1
             if resid_ds is not None:
                 resid = resid_ds  # the skip connection IS the (folded) downsample branch
                 if rec.ds.lo is not None:  # strided branch: its input gradient lives on the subsampled pixels
-                    resid = torch.empty(rec.ds.lo[1], dtype=dtype, device=resid_ds.device)
-                    kn.pixel_stride(resid_ds, resid, rec.ds.lo[0], expand=True)
+                    if self.lores_resid:
+                        rstride = rec.ds.lo[0]  # added on that sub-grid by conv1's input-gradient epilogue
+                    else:
+                        resid = torch.empty(rec.ds.lo[1], dtype=dtype, device=resid_ds.device)
+                        kn.pixel_stride(resid_ds, resid, rec.ds.lo[0], expand=True)
             elif rec.ds is not None:
                 kn.bn_bwd_apply(g, rec.ds.c, kd[0], kd[1], kd[2], g)  # g becomes d(downsample conv output)
                 self._unit_wgrad(rec.ds, g, grads, dtype)
@@ -793,7 +799,7 @@ class Engine:
             prev = rec.units[1]
             kp = self._bn_bwd_coeffs(s2, 2, 1, prev.bn, prev.st, grads)
             kn.bn_bwd_apply(da, prev.c, kp[0], kp[1], kp[2], da)
-            return self._block_bwd_tail(rec, da, 1, resid, grads, dtype, gate=gate)
+            return self._block_bwd_tail(rec, da, 1, resid, grads, dtype, gate=gate, resid_stride=rstride)
         if pre is not None:
             raise RuntimeError("a pre-gated gradient reached a block that is not on the folded path")
         last = rec.units[-1]
@@ -833,7 +839,7 @@ class Engine:
         return self._gate_vecs[key]
 
     def _block_bwd_tail(self, rec: BlockRec, cur, top: int, resid, grads: GradStore, dtype, last_xmat=None,
-                        gate=None):
+                        gate=None, resid_stride: int = 1):
         """units[top] .. units[0]: weight gradient, input gradient with the producer's ReLU gate + BatchNorm sums
         fused into its epilogue, BatchNorm backward; the first unit adds the identity-path gradient `resid`"""
         dev = cur.device
@@ -850,17 +856,17 @@ class Engine:
         first = rec.units[0]
         self._unit_wgrad(first, cur, grads, dtype)
         if gate is None:
-            return self._unit_dgrad(first, cur, dtype, resid=resid), None
+            return self._unit_dgrad(first, cur, dtype, resid=resid, resid_stride=resid_stride), None
         y_prev, gapg_prev, hw_prev, bits_prev = gate
         Cn = y_prev.shape[-1]
         sg = kn.new_stats(Cn, 2, dev)
         if bits_prev is not None:  # 1/16 of the bytes of y_prev
             dx = self._unit_dgrad(first, cur, dtype, resid=resid, gapg=gapg_prev, gap_scale=1.0 / hw_prev,
-                                  mask_bits=bits_prev, sums=sg)
+                                  mask_bits=bits_prev, sums=sg, resid_stride=resid_stride)
         else:
             one, zero = self._unit_gate(Cn, dev)
             dx = self._unit_dgrad(first, cur, dtype, resid=resid, gapg=gapg_prev, gap_scale=1.0 / hw_prev,
-                                  mask=(y_prev, one, zero), sums=sg)
+                                  mask=(y_prev, one, zero), sums=sg, resid_stride=resid_stride)
         return dx, sg
 
     # ---- MLP heads -----------------------------------------------------------------------------

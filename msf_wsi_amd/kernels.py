@@ -343,7 +343,8 @@ def fold_matvec(W, v, out):
     _lib.check(lib.msfwsi_fold_matvec(_p(W), _p(v), _p(out), K, Cn, _stream()), "fold_matvec")
 
 
-def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mask=None, sums=None, mask_bits=None):
+def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mask=None, sums=None, mask_bits=None,
+               resid_stride=1):
     """mask = (c, scale, shift) of the activation that produced the conv input: fuses its ReLU gate and the
     BatchNorm-backward sums {sum g, sum g*c} (-> sums [nshard,2,C]) into the epilogue.  mask_bits: the gate as
     the bytes conv_fwd_post wrote (sums slot 0 only)."""
@@ -352,7 +353,10 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mas
     _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
     _req(w, "w", dt, d.K * d.R * d.S * d.C)
     _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
-    _opt(resid, "resid", dt, d.N * d.H * d.W * d.C)
+    if resid_stride > 1:  # low-resolution residual, added on the strided sub-grid only
+        _req(resid, "resid", dt, d.N * ((d.H - 1) // resid_stride + 1) * ((d.W - 1) // resid_stride + 1) * d.C)
+    else:
+        _opt(resid, "resid", dt, d.N * d.H * d.W * d.C)
     _opt(gapg, "gapg", dt, d.N * d.C)
     mc = msc = msh = None
     nsh = 1
@@ -375,9 +379,10 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mas
         raise ValueError("sums without mask")
     _timed("conv_dgrad", d, dy.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(resid), _p(gapg), float(gap_scale), _p(mc),
-                              _p(msc), _p(msh), _p(mask_bits), _p(sums), nsh, _stream()), "conv_dgrad"),
-        extra_elems=(dx.numel() if resid is not None else 0) + (dx.numel() if mask is not None else 0)
-        + (dx.numel() // 16 if mask_bits is not None else 0), dtype=dt)
+                              _p(msc), _p(msh), _p(mask_bits), _p(sums), nsh, int(resid_stride), _stream()),
+        "conv_dgrad"),
+        extra_elems=(resid.numel() if resid is not None else 0) + (dx.numel() if mask is not None else 0)
+        + (dx.numel() // 16 if mask_bits is not None else 0), dtype=dt, epi=3 if resid_stride > 1 else 0)
     return dx
 
 

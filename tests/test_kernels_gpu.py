@@ -215,6 +215,33 @@ def test_stem_conv_as_row_runs(hip_lib, dt, hw):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hw", [(8, 8), (7, 9)])
+def test_conv_dgrad_lowres_residual(hip_lib, dt, hw):
+    """resid_stride=2: the residual is the low-resolution tensor, added on the even-pixel sub-grid only"""
+    from msf_wsi_amd import kernels as kn
+
+    H, W = hw
+    N, K, Cc = 3, 64, 256
+    g = torch.Generator().manual_seed(18)
+    dy = nhwc(rnd((N, K, H, W), dt, g)).to(dt).cuda()
+    w = nhwc(rnd((K, Cc, 1, 1), dt, g, 0.2)).to(dt).cuda()
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    lo = nhwc(rnd((N, Cc, P, Q), dt, g)).to(dt).cuda()
+    full = torch.empty(N, H, W, Cc, dtype=dt, device="cuda")
+    kn.pixel_stride(lo, full, 2, expand=True)
+    d = kn.conv_desc(dt, N, H, W, Cc, K, 1, 1, 1, 0)
+    mc = nhwc(rnd((N, Cc, H, W), dt, g)).to(dt).cuda()
+    one, zero = torch.ones(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    a, b = torch.empty_like(full), torch.empty_like(full)
+    sa, sb = kn.new_stats(Cc), kn.new_stats(Cc)
+    kn.conv_dgrad(d, dy, w, a, resid=full, mask=(mc, one, zero), sums=sa)
+    kn.conv_dgrad(d, dy, w, b, resid=lo, mask=(mc, one, zero), sums=sb, resid_stride=2)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.allclose(sa.sum(0), sb.sum(0), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("hw", [(8, 8), (7, 9), (1, 1)])
 def test_pixel_stride_gather_and_expand(hip_lib, dt, hw):
     from msf_wsi_amd import kernels as kn
