@@ -112,12 +112,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the MSF-WSI hot path has no CPU fallback")
+    # rehearsal aids for a one-GPU box (RCCL refuses two ranks on one device): MSFWSI_BENCH_DEVICE pins every rank to
+    # one card, MSFWSI_BENCH_BACKEND=gloo moves the collectives to the CPU transport.  The driver uses neither.
+    if os.environ.get("MSFWSI_BENCH_DEVICE"):
+        local = int(os.environ["MSFWSI_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("MSFWSI_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from msf_wsi_amd import _lib, kernels as kn
     from msf_wsi_amd.train import PretrainStep, synthetic_batch

@@ -11,7 +11,7 @@ def timeit(fn, rep=5):
     for _ in range(rep): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / rep
-for (M, C, K) in ((256, 18432, 18432), (256, 9216, 9216), (256, 4608, 4608), (256, 2304, 2304), (4096, 2048, 2048), (4096, 1024, 1024), (256, 18432, 4608)):
+for (M, C, K) in ((256, 18432, 18432), (512, 18432, 18432), (256, 9216, 9216), (512, 9216, 9216), (256, 4608, 4608), (512, 4608, 4608), (4096, 2048, 2048), (8192, 2048, 2048), (256, 18432, 4608), (512, 18432, 4608)):
     d = kn.conv_desc(dt, M, 1, 1, C, K, 1, 1, 1, 0)
     x = torch.randn(M, 1, 1, C, device="cuda").to(dt); w = (torch.randn(K, 1, 1, C, device="cuda") * 0.01).to(dt)
     y = torch.empty(M, 1, 1, K, dtype=dt, device="cuda"); dy = torch.randn_like(y); dx = torch.empty_like(x)
