@@ -207,6 +207,7 @@ class Engine:
         self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
+        self.pair_head_wgrad = os.environ.get("MSFWSI_PAIR_HEAD_WGRAD", "1") != "0"  # one dW launch for both views
         # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
         # stem_pool_bwd + bn_bwd_apply (the pool-backward window logic is VALU-bound, not byte-bound): off
         self.stem_two_pass = os.environ.get("MSFWSI_STEM_TWO_PASS", "0") != "0"
@@ -929,6 +930,53 @@ class Engine:
                 cur = self._unit_dgrad(u, cur, dtype)
         return cur.view(cur.shape[0], -1) if need_dx else None
 
+    def chain_backward_pair(self, recs, d_outs, grads: GradStore, dtype):
+        """chain_backward for the two views of one head at once: BatchNorm backward and the input gradient per view
+        (separate BatchNorm batches, backbone.py:140-145), but ONE weight-gradient launch per layer on the stacked
+        rows -- the 18432-wide fuser layers have 256 rows per view and their weight gradient is a read-modify-write
+        of a 1.4 GB fp32 matrix: once instead of twice."""
+        curs = list(d_outs)
+        dev = curs[0].device
+        nun = len(recs[0].units)
+        for i in range(nun - 1, -1, -1):
+            us = [r.units[i] for r in recs]
+            for v, u in enumerate(us):
+                if u.bn is not None:
+                    Cn = u.c.shape[-1]
+                    s2 = kn.new_stats(Cn, 2, dev)
+                    c2 = u.c.view(-1, Cn)
+                    cur2 = curs[v].view(-1, Cn)
+                    if u.relu:
+                        kn.act_bwd_reduce(cur2, c2, u.st.scale, u.st.shift, cur2, s2)
+                    else:
+                        kn.act_bwd_reduce(cur2, c2, None, None, None, s2)
+                    k = self._bn_bwd_coeffs(s2, 2, 1, u.bn, u.st, grads)
+                    kn.bn_bwd_apply(cur2, c2, k[0], k[1], k[2], cur2)
+            u0 = us[0]
+            rows = [u.desc.N for u in us]
+            Cin, Kout = u0.desc.C, u0.desc.K
+            xcat = torch.empty(sum(rows), 1, 1, Cin, dtype=dtype, device=dev)
+            dcat = torch.empty(sum(rows), 1, 1, Kout, dtype=dtype, device=dev)
+            off = 0
+            for v, u in enumerate(us):
+                xs = xcat[off:off + rows[v]]
+                if u.x_pro is not None:
+                    kn.bn_act(u.x, u.x_pro.scale, u.x_pro.shift, xs, relu=True)
+                else:
+                    xs.view(rows[v], Cin).copy_(u.x.view(rows[v], Cin))
+                dcat[off:off + rows[v]].view(rows[v], Kout).copy_(curs[v].view(rows[v], Kout))
+                off += rows[v]
+            dpair = kn.conv_desc(dtype, sum(rows), 1, 1, Cin, Kout, 1, 1, 1, 0)
+            kn.conv_wgrad(dpair, xcat, dcat, grads.get(u0.op.weight))
+            bias = getattr(u0.op, "bias", None)
+            if bias is not None:
+                cs = torch.zeros(Kout, dtype=torch.float64, device=dev)
+                kn.colsum(dcat, cs)
+                kn.add_f64_to_f32(cs, grads.get(bias), 1.0)
+            for v, u in enumerate(us):
+                curs[v] = self._unit_dgrad(u, curs[v], dtype)
+        return [c.view(c.shape[0], -1) for c in curs]
+
     # ---- whole model -----------------------------------------------------------------------------
     def model_forward(self, model: nn.Module, x1, x2, jigsaw_idx, dtype,
                       need_backward: bool = True) -> Tuple[tuple, StepRec]:
@@ -998,11 +1046,19 @@ class Engine:
         dtf = [[None] * 4 for _ in range(2)]
         for grp in ("context", "target", "inter"):
             for s in range(4):
+                pair = None
+                if self.pair_head_wgrad:
+                    hz, hp = zip(*(rec.heads.pop((grp, s, v)) for v in range(2)))
+                    dzs = self.chain_backward_pair(hp, [dps[(grp, s, v)] for v in range(2)], grads, dtype)
+                    pair = self.chain_backward_pair(hz, [d.contiguous() for d in dzs], grads, dtype)
                 for v in range(2):
-                    zrec, prec = rec.heads.pop((grp, s, v))
-                    dp = dps[(grp, s, v)]
-                    dz = self.chain_backward(prec, dp, grads, dtype)
-                    df = self.chain_backward(zrec, dz.contiguous(), grads, dtype)
+                    if pair is not None:
+                        df = pair[v]
+                    else:
+                        zrec, prec = rec.heads.pop((grp, s, v))
+                        dp = dps[(grp, s, v)]
+                        dz = self.chain_backward(prec, dp, grads, dtype)
+                        df = self.chain_backward(zrec, dz.contiguous(), grads, dtype)
                     Cs = rec.enc[f"c{v}"].feats[s].shape[-1]
                     if grp == "context":
                         dcf[v][s] = df
