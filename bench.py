@@ -91,6 +91,23 @@ def cpu_baseline(arch, size, budget_s, threads):
                       f"{size}x{size}, after 1 warm-up step"}
 
 
+def launch_ranks(n):
+    """one child process per GPU on this node over 127.0.0.1 (the container hostname may not resolve)"""
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,29 +120,53 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group, run the collective probe and exit (launcher test)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has made no GPU call yet; it starts one fresh rank per GPU
+        # (torch.distributed.run, the reference's mp.spawn of tools/ssl_train.py:68), relays their output (rank 0
+        # prints the JSON line) and exits with their return code
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the MSF-WSI hot path has no CPU fallback")
-    # rehearsal aids for a one-GPU box (RCCL refuses two ranks on one device): MSFWSI_BENCH_DEVICE pins every rank to
-    # one card, MSFWSI_BENCH_BACKEND=gloo moves the collectives to the CPU transport.  The driver uses neither.
-    if os.environ.get("MSFWSI_BENCH_DEVICE"):
-        local = int(os.environ["MSFWSI_BENCH_DEVICE"])
-    torch.cuda.set_device(local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     import torch.distributed as dist
 
-    if world > 1:
+    # rehearsal aids for a one-GPU box (RCCL refuses two ranks on one device): MSFWSI_BENCH_DEVICE pins every rank to
+    # one card, MSFWSI_BENCH_BACKEND=gloo moves the collectives to the CPU transport.  The driver uses neither.
+    backend = os.environ.get("MSFWSI_BENCH_BACKEND", "nccl")
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not (args.rendezvous_only and backend != "nccl"):
+        raise SystemExit("bench.py needs an MI355X: the MSF-WSI hot path has no CPU fallback")
+    if os.environ.get("MSFWSI_BENCH_DEVICE"):
+        local = int(os.environ["MSFWSI_BENCH_DEVICE"])
+    if have_gpu:
+        torch.cuda.set_device(local)
+    if world > 1 or os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MSFWSI_BENCH_BACKEND", "nccl")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        from msf_wsi_amd.dist import probe_collectives
+
+        probe_collectives(None, torch.device("cuda", local) if have_gpu else torch.device("cpu"))  # fails loudly
+    if args.rendezvous_only:
+        if dist.is_initialized():
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world": world, "backend": backend if world > 1 else None}),
+                  flush=True)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     from msf_wsi_amd import _lib, kernels as kn
     from msf_wsi_amd.train import PretrainStep, synthetic_batch
@@ -219,7 +260,7 @@ def main():
                 pass
             out["cpu_baseline"] = cpu_baseline(args.arch, args.size, args.cpu_budget, threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

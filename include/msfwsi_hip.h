@@ -126,6 +126,13 @@ int msfwsi_bn_finalize(const double* sums, int nshard, int C, double count, cons
                        long* num_batches_tracked, float* scale, float* shift, float* mean, float* invstd,
                        void* stream);
 
+/* BatchNorm in eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (mean =
+ * running_mean, invstd = 1/sqrt(running_var + eps)); no batch statistics, no cross-replica exchange.
+ * Replaces: F.batch_norm(training=False) of nn.BatchNorm2d / BatchNorm1d under model.eval(),
+ * src/models/resnet.py:175 etc. (feature extraction through the pre-trained encoders). */
+int msfwsi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                          float eps, int C, float* scale, float* shift, float* mean, float* invstd, void* stream);
+
 /* out[n] = sum over nshard replicas of in[shard][n]: packs the cross-replica (SyncBatchNorm) message. */
 int msfwsi_shard_sum(const double* in, int nshard, int n, double* out, void* stream);
 
@@ -241,14 +248,24 @@ int msfwsi_scaler_update(float* scale, int* growth_tracker, const float* found, 
 
 /* One Adam step over a flat fp32 parameter group (torch.optim.Adam defaults, tools/ssl_train.py:309,473);
  * grads are divided by *loss_scale, the step is skipped when *found > 0; p_lowp != NULL also refreshes
- * the 16-bit compute copy (lowp_dtype = MSFWSI_DT_BF16 or MSFWSI_DT_F16). */
+ * the 16-bit compute copy (lowp_dtype = MSFWSI_DT_BF16 or MSFWSI_DT_F16).  step_dev != NULL: Adam's step
+ * count is read from the device (the host `step` is ignored) and the bias corrections are formed in the kernel. */
 int msfwsi_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                float eps, long step, const float* loss_scale, const float* found, void* p_lowp, int lowp_dtype,
-                void* stream);
+                float eps, long step, const int* step_dev, const float* loss_scale, const float* found, void* p_lowp,
+                int lowp_dtype, void* stream);
+
+/* *step += 1 unless *found > 0: torch's GradScaler.step (tools/ssl_train.py:473) does not call optimizer.step on an
+ * overflowed step, so Adam's per-parameter "step" (bias correction, checkpoint) does not count skipped steps. */
+int msfwsi_adam_step_advance(int* step, const float* found, void* stream);
 
 /* fp32 -> bf16 / fp16 compute copy of a flat weight buffer (dtype = MSFWSI_DT_BF16 or MSFWSI_DT_F16) */
 int msfwsi_cast_lowp(int dtype, const float* src, void* dst, long n, void* stream);
 int msfwsi_pad_cast(int dtype, const float* src, void* dst, long rows, int C, int CP, void* stream);
+/* bf16 / fp16 -> fp32 (replaces Tensor.float() on the 16-bit weight copies: the folded BatchNorm algebra of
+ * src/models/resnet.py:131-138 is evaluated on exactly the weights the MFMA multiplies) */
+int msfwsi_upcast_f32(int dtype, const void* src, float* dst, long n, void* stream);
+/* p[r*ld + c] = 0 for r < rows, c < cols (fp64): clears one slot of a sharded statistics accumulator */
+int msfwsi_zero_f64_2d(double* p, long rows, int cols, long ld, void* stream);
 int msfwsi_unpad_add(const float* src, float* dst, long rows, int C, int CP, void* stream);
 
 /* performance knobs (never change results): key 0 = minimum grid (in 256x128 tiles) from which the conv

@@ -37,6 +37,7 @@ SIGNATURES = {
     "msfwsi_conv_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_conv_wgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_bn_finalize": [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "msfwsi_bn_eval_coeffs": [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "msfwsi_shard_sum": [_vp, _i, _i, _vp, _vp],
     "msfwsi_bn_act": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _i, _vp],
     "msfwsi_block_end_bwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _vp],
@@ -64,10 +65,13 @@ SIGNATURES = {
     "msfwsi_cosine_loss": [_i, _vp, _vp, _l, _i, _f, _vp, _f, _vp, _vp, _vp],
     "msfwsi_nonfinite_check": [_vp, _l, _vp, _vp],
     "msfwsi_scaler_update": [_vp, _vp, _vp, _f, _f, _i, _vp],
-    "msfwsi_adam": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _l, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_adam": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _l, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_adam_step_advance": [_vp, _vp, _vp],
     "msfwsi_cast_lowp": [_i, _vp, _vp, _l, _vp],
     "msfwsi_pad_cast": [_i, _vp, _vp, _l, _i, _i, _vp],
     "msfwsi_unpad_add": [_vp, _vp, _l, _i, _i, _vp],
+    "msfwsi_upcast_f32": [_i, _vp, _vp, _l, _vp],
+    "msfwsi_zero_f64_2d": [_vp, _l, _i, _l, _vp],
     "msfwsi_set_tuning": [_i, _l],
     "msfwsi_conv3x3_supported": [_desc],
     "msfwsi_conv3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _i, _vp],

@@ -133,6 +133,22 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int nshard, 
     }
 }
 
+// BatchNorm in eval mode (nn.BatchNorm*.eval() with track_running_stats): the affine map comes from the running
+// statistics, nothing is reduced or exchanged: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean*scale
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift,
+                                      float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(running_var[c] + eps);
+    const float sc = (gamma != nullptr ? gamma[c] : 1.f) * invstd;
+    scale[c] = sc;
+    shift[c] = (beta != nullptr ? beta[c] : 0.f) - running_mean[c] * sc;
+    mean_out[c] = running_mean[c];
+    invstd_out[c] = invstd;
+}
+
 // sum `nshard` replicas of a length-n fp64 vector (the packed message of the cross-replica exchange)
 __global__ void shard_sum_kernel(const double* __restrict__ in, int nshard, int n, double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -858,6 +874,15 @@ extern "C" int msfwsi_bn_finalize(const double* sums, int nshard, int C, double 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), sums, nshard, C, count,
                        gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale, shift, mean,
                        invstd);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_bn_eval_coeffs(const float* running_mean, const float* running_var, const float* gamma,
+                                     const float* beta, float eps, int C, float* scale, float* shift, float* mean,
+                                     float* invstd, void* stream) {
+    MSFWSI_CHECK_ARG(running_mean && running_var && C > 0 && scale && shift && mean && invstd);
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, ST(stream), running_mean, running_var,
+                       gamma, beta, eps, C, scale, shift, mean, invstd);
     return msfwsi_launch_status();
 }
 

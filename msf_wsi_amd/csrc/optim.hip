@@ -90,11 +90,18 @@ __global__ void scaler_update_kernel(float* scale, int* growth_tracker, const fl
 
 // torch.optim.Adam (no amsgrad, no weight decay), same operation order as _single_tensor_adam:
 //   m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+// step_dev != NULL: the step count lives on the device (advanced by step_advance_kernel only on steps the
+// GradScaler does not skip, exactly like optimizer.step under scaler.step) and the bias corrections are formed here
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, float beta1, float beta2, float eps, float step_size,
-                            float bc2_sqrt, const float* __restrict__ loss_scale, const float* __restrict__ found,
-                            unsigned short* __restrict__ p_bf16, int lowp_f16) {
+                            float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps, float step_size,
+                            float bc2_sqrt, const int* __restrict__ step_dev, const float* __restrict__ loss_scale,
+                            const float* __restrict__ found, unsigned short* __restrict__ p_bf16, int lowp_f16) {
     if (found != nullptr && *found > 0.f) return;  // GradScaler.step skips the update
+    if (step_dev != nullptr) {
+        const double t = (double)*step_dev;
+        step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+    }
     const float inv_scale = loss_scale != nullptr ? 1.f / *loss_scale : 1.f;
     const long n4 = n >> 2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -140,6 +147,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Adam's "step" advances only when the update is applied (found == 0): torch's GradScaler.step does not call
+// optimizer.step on an overflowed step, so bias corrections and the checkpointed step never count skipped steps
+__global__ void step_advance_kernel(int* step, const float* found) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !(found != nullptr && *found > 0.f)) *step += 1;
+}
+
 __global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long n, int f16) {
     const long n4 = n >> 2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -158,6 +171,20 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, unsigned short* 
         const float x = src[n4 * 4 + threadIdx.x];
         dst[n4 * 4 + threadIdx.x] = f16 ? float_to_f16_bits(x) : float_to_bf16_bits(x);
     }
+}
+
+// storage type -> fp32 (the fold algebra of DESIGN.md 3.1 runs on exactly the weights the MFMA multiplies)
+template <typename T>
+__global__ void upcast_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = load_elem<T>(src, i);
+}
+
+// rows x cols fp64 block with leading dimension ld := 0 (one slot of a sharded [nshard][slots][C] accumulator)
+__global__ void zero_f64_2d_kernel(double* __restrict__ p, long rows, int cols, long ld) {
+    const long total = rows * cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        p[(i / cols) * ld + (i % cols)] = 0.0;
 }
 
 // [rows][C] fp32 -> [rows][CP] storage type, zero padded (stem weights: C=3 -> CP=8 / 4)
@@ -216,18 +243,27 @@ extern "C" int msfwsi_scaler_update(float* scale, int* growth_tracker, const flo
 }
 
 extern "C" int msfwsi_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                           float eps, long step, const float* loss_scale, const float* found, void* p_lowp,
-                           int lowp_dtype, void* stream) {
-    MSFWSI_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+                           float eps, long step, const int* step_dev, const float* loss_scale, const float* found,
+                           void* p_lowp, int lowp_dtype, void* stream) {
+    MSFWSI_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || step_dev != nullptr));
     MSFWSI_CHECK_ARG(p_lowp == nullptr || lowp_dtype == MSFWSI_DT_BF16 || lowp_dtype == MSFWSI_DT_F16);
     void* p_bf16 = p_lowp;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(adam_kernel, dim3(sgrid(n / 4 + 1, 256)), dim3(256), 0, ST(stream), p, g, m, v, n, beta1, beta2,
-                       eps, step_size, bc2_sqrt, loss_scale, found, (unsigned short*)p_bf16,
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (step_dev == nullptr) {
+        const double bc1 = 1.0 - pow((double)beta1, (double)step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)step);
+        step_size = (float)((double)lr / bc1);
+        bc2_sqrt = (float)sqrt(bc2);
+    }
+    hipLaunchKernelGGL(adam_kernel, dim3(sgrid(n / 4 + 1, 256)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1,
+                       beta2, eps, step_size, bc2_sqrt, step_dev, loss_scale, found, (unsigned short*)p_bf16,
                        lowp_dtype == MSFWSI_DT_F16 ? 1 : 0);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_adam_step_advance(int* step, const float* found, void* stream) {
+    MSFWSI_CHECK_ARG(step != nullptr);
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, ST(stream), step, found);
     return msfwsi_launch_status();
 }
 
@@ -235,6 +271,19 @@ extern "C" int msfwsi_cast_lowp(int dtype, const float* src, void* dst, long n, 
     MSFWSI_CHECK_ARG(src && dst && n > 0 && (dtype == MSFWSI_DT_BF16 || dtype == MSFWSI_DT_F16));
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(sgrid(n / 4 + 1, 256)), dim3(256), 0, ST(stream), src,
                        (unsigned short*)dst, n, dtype == MSFWSI_DT_F16 ? 1 : 0);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_upcast_f32(int dtype, const void* src, float* dst, long n, void* stream) {
+    MSFWSI_CHECK_ARG(src && dst && n > 0 && (dtype == MSFWSI_DT_BF16 || dtype == MSFWSI_DT_F16));
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(upcast_kernel<T>, dim3(sgrid(n, 256)), dim3(256), 0, ST(stream), (const T*)src,
+                           dst, n));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_zero_f64_2d(double* p, long rows, int cols, long ld, void* stream) {
+    MSFWSI_CHECK_ARG(p && rows > 0 && cols > 0 && ld >= cols);
+    hipLaunchKernelGGL(zero_f64_2d_kernel, dim3(sgrid(rows * cols, 256)), dim3(256), 0, ST(stream), p, rows, cols, ld);
     return msfwsi_launch_status();
 }
 

@@ -16,6 +16,7 @@ None of this touches the GPU directly: it is plain tensor/collective plumbing an
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -47,6 +48,39 @@ def sync_sums(packed: torch.Tensor, group=None) -> torch.Tensor:
     if world_size(group) > 1:
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return packed
+
+
+_PROBED = set()
+
+
+def probe_collectives(group=None, device=None):
+    """One-time check that the process group's backend executes every collective form this package issues:
+    fp64 SUM (packed BatchNorm statistics), fp32 AVG -- or SUM where AVG does not exist (gloo) -- on a flat gradient
+    buffer, int32 MAX (the collective recompute plan).  Raises RuntimeError naming the missing capability instead of
+    failing somewhere inside a training step.  Returns the reduce op to use for gradient averaging."""
+    backend = dist.get_backend(group)
+    key = (id(group), backend)
+    dev = device if device is not None else ("cuda" if backend == "nccl" else "cpu")
+    avg = backend == "nccl"
+    if key in _PROBED:
+        return dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    w = dist.get_world_size(group)
+    try:
+        a = torch.ones(8, dtype=torch.float64, device=dev)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group)
+        b = torch.ones(8, dtype=torch.float32, device=dev)
+        dist.all_reduce(b, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group)
+        c = torch.full((1,), dist.get_rank(group), dtype=torch.int32, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+        ok = (float(a[0]) == float(w) and float(b[0]) == (1.0 if avg else float(w)) and int(c[0]) == w - 1)
+    except Exception as e:  # noqa: BLE001 -- any backend error is the finding
+        raise RuntimeError(f"process-group backend '{backend}' cannot run a collective the MSF-WSI data-parallel path "
+                           f"needs (fp64 SUM / fp32 {'AVG' if avg else 'SUM'} / int32 MAX all-reduce): {e}") from e
+    if not ok:
+        raise RuntimeError(f"process-group backend '{backend}' returned wrong results in the collective probe "
+                           f"(fp64 SUM {float(a[0])}, fp32 {float(b[0])}, int32 MAX {int(c[0])}; world {w})")
+    _PROBED.add(key)
+    return dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
 
 
 class FlatGroups:
@@ -129,19 +163,18 @@ class GradReducer:
         self.group = group
         self.pending: List[Tuple[int, object]] = []
         self.world = world_size(group)
+        # MSFWSI_FORCE_SYNC: rehearse the collective path with a single rank (RCCL calls execute, results unchanged)
+        self.active = self.world > 1 or (os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0" and dist.is_available()
+                                         and dist.is_initialized())
+        self.op = probe_collectives(group, flats.g[0].device) if self.active else None
 
     def launch(self, group_name: str):
-        if self.world == 1:
+        if not self.active:
             return
         gi = {"context": 0, "target": 1, "inter": 2}[group_name]
         buf = self.flats.g[gi]
-        backend = dist.get_backend(self.group)
-        if backend == "nccl":
-            work = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            self.pending.append((-1, work))
-        else:
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.pending.append((gi, work))
+        work = dist.all_reduce(buf, op=self.op, group=self.group, async_op=True)
+        self.pending.append((-1 if self.op == dist.ReduceOp.AVG else gi, work))
 
     def wait(self):
         for gi, work in self.pending:

@@ -39,6 +39,7 @@ class BNState:
     mean: torch.Tensor
     invstd: torch.Tensor
     count: float  # elements per channel over ALL replicas
+    frozen: bool = False  # eval-mode BatchNorm: the map comes from the running statistics (no backward through them)
 
 
 @dataclass
@@ -219,6 +220,18 @@ class Engine:
         self.mat_min_rows = int(os.environ.get("MSFWSI_MAT_MIN_ROWS", "1"))  # rows from which 1x1 operands are materialised
         self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._plan_cache: Dict[tuple, Tuple[frozenset, bool]] = {}
+        self._msgs: Dict[tuple, torch.Tensor] = {}
+        # rehearsal switch: run the cross-replica code path (collectives included) even with one rank, so that the
+        # RCCL calls of the SyncBatchNorm exchange execute on a one-GPU box
+        self.force_sync = os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0"
+
+    def invalidate_weights(self):
+        """Every derived copy of the parameters (16-bit / channel-padded casts, the stem's filter-row runs) is keyed on
+        torch's version counter and data pointer, which an optimizer that updates the storage through raw pointers
+        (the flat Adam kernel) or `load_state_dict` into views does not move: trainers call this after every update."""
+        self.weights._cache.clear()
+        self._stem_cache.clear()
 
     # ---- configuration ---------------------------------------------------------------------
     @staticmethod
@@ -239,21 +252,46 @@ class Engine:
             return dist.get_world_size(self.group)
         return 1
 
+    def _msg_buf(self, kind: str, n: int, dev) -> torch.Tensor:
+        """pre-allocated fp64 message buffer of the cross-replica BatchNorm exchange, one per (direction, length).
+        Re-use is safe: the blocking all-reduce makes the launch stream wait for the collective, and the consumer
+        (bn_finalize / bn_bwd_finalize) precedes the next producer (shard_sum) in stream order."""
+        key = (kind, n, str(dev))
+        buf = self._msgs.get(key)
+        if buf is None:
+            buf = self._msgs[key] = torch.empty(n, dtype=torch.float64, device=dev)
+        return buf
+
     def _sync(self, bn: nn.Module) -> bool:
         if self._world() == 1:
-            return False
+            return self.force_sync and dist.is_available() and dist.is_initialized()
         if self._sync_bn is not None:
             return self._sync_bn
         return isinstance(bn, nn.SyncBatchNorm)
 
     # ---- BatchNorm helpers ---------------------------------------------------------------------
+    @staticmethod
+    def _bn_frozen(bn: nn.Module) -> bool:
+        """eval-mode BatchNorm with running statistics (model.eval(), nn.BatchNorm*: `not training and
+        track_running_stats`): normalises with running_mean / running_var, nothing is reduced or exchanged"""
+        return (not bn.training) and bn.track_running_stats and bn.running_mean is not None
+
+    def _bn_eval_state(self, bn: nn.Module, count: int) -> BNState:
+        Cn = bn.num_features
+        vecs = torch.empty(4, Cn, dtype=torch.float32, device=bn.running_mean.device)
+        kn.bn_eval_coeffs(bn.running_mean, bn.running_var, bn.weight if bn.affine else None,
+                          bn.bias if bn.affine else None, bn.eps, vecs[0], vecs[1], vecs[2], vecs[3])
+        return BNState(vecs[0], vecs[1], vecs[2], vecs[3], float(count), frozen=True)
+
     def _bn_finalize(self, stats: torch.Tensor, count: int, bn: nn.Module) -> BNState:
+        if self._bn_frozen(bn):
+            return self._bn_eval_state(bn, count)
         Cn = stats.shape[-1]
         dev = stats.device
         vecs = torch.empty(4, Cn, dtype=torch.float32, device=dev)
         total = float(count)
         if self._sync(bn):
-            packed = torch.empty(2 * Cn, dtype=torch.float64, device=dev)
+            packed = self._msg_buf("fwd", 2 * Cn, dev)
             kn.shard_sum(stats, packed)
             dist.all_reduce(packed, group=self.group)  # RCCL sum of [sum, sumsq]; equal shards per rank
             stats = packed.view(1, 2, Cn)
@@ -268,22 +306,24 @@ class Engine:
 
     def _bn_bwd_coeffs(self, sums: torch.Tensor, nslots: int, which: int, bn: nn.Module, st: BNState,
                        grads: GradStore):
+        if st.frozen:
+            raise NotImplementedError(
+                "backward through an eval-mode BatchNorm (frozen running statistics) is not implemented by the "
+                "MSF-WSI HIP engine: call model.train() for training, or run eval-mode forwards under torch.no_grad()")
         Cn = sums.shape[-1]
         dev = sums.device
         if self._sync(bn):
-            packed = torch.empty(nslots * Cn, dtype=torch.float64, device=dev)
+            packed = self._msg_buf("bwd", nslots * Cn, dev)
             kn.shard_sum(sums, packed)
-            dist.all_reduce(packed, group=self.group)
-            # parameter gradients are averaged over replicas later (DDP); keep local sums for dgamma/dbeta
-            local = torch.empty(nslots * Cn, dtype=torch.float64, device=dev)
-            kn.shard_sum(sums, local)
             k = torch.empty(3, Cn, dtype=torch.float32, device=dev)
-            scratch = torch.empty(3, Cn, dtype=torch.float32, device=dev)
+            if bn.affine:
+                # parameter gradients are averaged over replicas later (DDP): dgamma/dbeta come from the LOCAL sums,
+                # taken from the message buffer before the exchange overwrites it (k is scratch here)
+                kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count, bn.weight, st.mean, st.invstd,
+                                   grads.get(bn.weight), grads.get(bn.bias), k[0], k[1], k[2])
+            dist.all_reduce(packed, group=self.group)
             kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count,
                                bn.weight if bn.affine else None, st.mean, st.invstd, None, None, k[0], k[1], k[2])
-            if bn.affine:
-                kn.bn_bwd_finalize(local.view(1, nslots, Cn), nslots, which, st.count, bn.weight, st.mean, st.invstd,
-                                   grads.get(bn.weight), grads.get(bn.bias), scratch[0], scratch[1], scratch[2])
             return k
         k = torch.empty(3, Cn, dtype=torch.float32, device=dev)
         kn.bn_bwd_finalize(sums, nslots, which, st.count, bn.weight if bn.affine else None, st.mean, st.invstd,
@@ -333,9 +373,12 @@ class Engine:
         ver = (op.weight._version, op.weight.data_ptr())
         hit = self._stem_cache.get(key)
         if hit is None or hit[0] != ver:
-            wp = self.weights.get(op.weight, dtype, pad_to=CP)  # [K][R][S][CP]
-            w_run = torch.zeros(K, R, run, dtype=dtype, device=wp.device)
-            w_run[:, :, :S * CP] = wp.reshape(K, R, S * CP)
+            phys = WeightStore.physical(op.weight)  # fp32 [K][R][S][Cin]
+            Cin = phys.shape[-1]
+            wp = torch.empty(K * R * S, CP, dtype=torch.float32, device=phys.device)
+            kn.pad_cast(phys, wp, K * R * S, Cin, CP)          # channels -> one 16-byte chunk
+            w_run = torch.empty(K, R, run, dtype=dtype, device=phys.device)
+            kn.pad_cast(wp, w_run, K * R, S * CP, run)         # filter row -> whole k slabs, storage type
             hit = (ver, w_run)
             self._stem_cache[key] = hit
         return kn.stem_conv_fwd(x, hit[1], c, stats, R, S, op.stride[0], op.padding[0])
@@ -343,9 +386,11 @@ class Engine:
     def _gram_stats(self, w: torch.Tensor, A: torch.Tensor, sa: torch.Tensor, bn: nn.Module, count: int, dtype) -> BNState:
         """BatchNorm batch statistics of c = W a (1x1 conv) from the Gram matrix A = a^T a and the column sums of a:
         sum c = W sum(a), sum c^2 = diag(W A W^T); w = the compute-dtype weights [K][1][1][C] the MFMA multiplies"""
+        if self._bn_frozen(bn):
+            return self._bn_eval_state(bn, count)
         K, Cw = w.shape[0], w.shape[-1]
         dev = w.device
-        Wq = w if dtype == torch.float32 else w.float()
+        Wq = w if dtype == torch.float32 else kn.upcast_f32(w)
         dlin = kn.conv_desc(torch.float32, K, 1, 1, Cw, Cw, 1, 1, 1, 0)
         WA = torch.empty(K, 1, 1, Cw, dtype=torch.float32, device=dev)
         kn.conv_fwd(dlin, Wq, A, WA)  # A is symmetric
@@ -366,14 +411,19 @@ class Engine:
         d3 = kn.conv_desc(dtype, N, H, W, Cw, K, 1, 1, 1, 0)
         dd = kn.conv_desc(dtype, N, H, W, Ci, K, 1, 1, 1, 0)
         a2 = torch.empty_like(c2)
-        sa = kn.zeros((Cw,), torch.float64, dev)
-        kn.bn_act_sum(c2, pro.scale, pro.shift, a2, sa)
-        A2 = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
-        kn.conv_wgrad(kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0), a2, a2, A2)
-        Ax = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
-        kn.conv_wgrad(kn.conv_desc(dtype, N, H, W, Ci, Ci, 1, 1, 1, 0), x, x, Ax)
-        sx = kn.zeros((Ci,), torch.float64, dev)
-        kn.colsum(x, sx)
+        A2 = sa = Ax = sx = None
+        if self._bn_frozen(bn3):  # eval mode: statistics are the running ones, no Gram matrix needed
+            kn.bn_act(c2, pro.scale, pro.shift, a2, relu=True)
+        else:
+            sa = kn.zeros((Cw,), torch.float64, dev)
+            kn.bn_act_sum(c2, pro.scale, pro.shift, a2, sa)
+            A2 = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
+            kn.conv_wgrad(kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0), a2, a2, A2)
+        if not self._bn_frozen(dbn):
+            Ax = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
+            kn.conv_wgrad(kn.conv_desc(dtype, N, H, W, Ci, Ci, 1, 1, 1, 0), x, x, Ax)
+            sx = kn.zeros((Ci,), torch.float64, dev)
+            kn.colsum(x, sx)
         st3 = self._gram_stats(self.weights.get(conv3.weight, dtype), A2, sa, bn3, N * H * W, dtype)
         std = self._gram_stats(self.weights.get(dconv.weight, dtype), Ax, sx, dbn, N * H * W, dtype)
         wcat32 = torch.empty(K, Cw + Ci, dtype=torch.float32, device=dev)
@@ -386,8 +436,8 @@ class Engine:
         bits = kn.gate_bytes(N * H * W, K, dtype, dev) if want_bits else None
         if not kn.conv_fwd_post2(d3, a2, wcat, y, x, one, shift, relu=True, gate_out=bits):
             return None
-        u3 = Unit(conv3, bn3, False, d3, c2, pro, None, st3, gram=(A2, sa))
-        ud = Unit(dconv, dbn, False, dd, x, None, None, std, gram=(Ax, sx))
+        u3 = Unit(conv3, bn3, False, d3, c2, pro, None, st3, gram=(A2, sa) if A2 is not None else None)
+        ud = Unit(dconv, dbn, False, dd, x, None, None, std, gram=(Ax, sx) if Ax is not None else None)
         return u3, ud, y, bits
 
     def _conv_bn_res_fwd(self, conv: nn.Module, bn: nn.Module, c_in: torch.Tensor, pro: BNState, ident: torch.Tensor,
@@ -404,17 +454,21 @@ class Engine:
         dev = c_in.device
         d = kn.conv_desc(dtype, N, H, W, Cw, K, 1, 1, 1, 0)
         a = torch.empty_like(c_in)
-        sa = kn.zeros((Cw,), torch.float64, dev)
-        kn.bn_act_sum(c_in, pro.scale, pro.shift, a, sa)
-        dsq = kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0)
-        A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
-        kn.conv_wgrad(dsq, a, a, A)
+        A = sa = None
+        if self._bn_frozen(bn):  # eval mode: statistics are the running ones, no Gram matrix needed
+            kn.bn_act(c_in, pro.scale, pro.shift, a, relu=True)
+        else:
+            sa = kn.zeros((Cw,), torch.float64, dev)
+            kn.bn_act_sum(c_in, pro.scale, pro.shift, a, sa)
+            dsq = kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0)
+            A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
+            kn.conv_wgrad(dsq, a, a, A)
         w = self.weights.get(conv.weight, dtype)
         st = self._gram_stats(w, A, sa, bn, N * H * W, dtype)
         y = torch.empty(N, H, W, K, dtype=dtype, device=dev)
         bits = kn.gate_bytes(N * H * W, K, dtype, dev) if want_bits else None
         kn.conv_fwd_post(d, a, w, y, st.scale, st.shift, ident=ident, relu=True, gate_out=bits)
-        u = Unit(conv, bn, False, d, c_in, pro, None, st, gram=(A, sa))
+        u = Unit(conv, bn, False, d, c_in, pro, None, st, gram=(A, sa) if A is not None else None)
         return u, y, bits
 
     def _normalised_operand(self, u: Unit) -> torch.Tensor:
@@ -581,21 +635,40 @@ class Engine:
 
     def _plan_recompute(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float = 0.0) -> set:
         """which encoder passes run features-only in forward, and whether bottleneck conv3 outputs are dropped
-        (engine.recompute = off | c3 | t1 | targets | auto).  Sets self._drop_c3 for the remaining passes."""
+        (engine.recompute = off | c3 | t1 | targets | auto).  Sets self._drop_c3 for the remaining passes.
+
+        With more than one rank the decision is COLLECTIVE: a rank that recomputes a pass issues forward SyncBatchNorm
+        exchanges where its peers issue backward ones (same message sizes, so a mismatch would pair silently), and
+        'auto' depends on each rank's free memory.  Every rank therefore adopts the most conservative local plan
+        (one all-reduce(MAX) of a plan code), once per (batch, model) shape -- the result is cached."""
+        nosave, drop = self._plan_local(per_image_bytes, B, K, device, c3_fraction)
+        if self._world() > 1:
+            key = (B, K, int(per_image_bytes), self.recompute, self.fold_bn3)
+            hit = self._plan_cache.get(key)
+            if hit is None:
+                code = torch.tensor([2 * len(nosave) + int(drop)], dtype=torch.int32, device=device)
+                dist.all_reduce(code, op=dist.ReduceOp.MAX, group=self.group)
+                c = int(code.item())
+                hit = (frozenset([(), ("t1",), ("t0", "t1")][c // 2]), bool(c & 1))
+                self._plan_cache[key] = hit
+            nosave, drop = set(hit[0]), hit[1]
+        self._drop_c3 = drop
+        return nosave
+
+    def _plan_local(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float):
+        """this rank's own (features-only passes, drop conv3 outputs) choice"""
         mode = getattr(self, "recompute", "off")
-        self._drop_c3 = False
         if self.fold_bn3 and c3_fraction > 0:  # conv3 outputs are never kept on the folded path
             per_image_bytes *= 1.0 - c3_fraction
             c3_fraction = 0.0
         if mode == "off":
-            return set()
+            return set(), False
         if mode == "c3":
-            self._drop_c3 = c3_fraction > 0
-            return set()
+            return set(), c3_fraction > 0
         if mode == "t1":
-            return {"t1"}
+            return {"t1"}, False
         if mode == "targets":
-            return {"t0", "t1"}
+            return {"t0", "t1"}, False
         free, _ = torch.cuda.mem_get_info(device)
         avail = free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         budget = avail - (6 << 30)
@@ -606,16 +679,16 @@ class Engine:
         transients = 0.26 * one_target
         ctx = per_image_bytes * B  # the second context pass
         if ctx + 2 * one_target + transients < budget:
-            return set()
-        slim = 1.0
+            return set(), False
+        slim, drop = 1.0, False
         if c3_fraction > 0:
             slim = 1.0 - c3_fraction
-            self._drop_c3 = True
+            drop = True
             if ctx * slim + 2 * one_target * slim + transients < budget:
-                return set()
+                return set(), drop
         if ctx * slim + one_target * slim + transients < budget:
-            return {"t1"}
-        return {"t0", "t1"}
+            return {"t1"}, drop
+        return {"t0", "t1"}, drop
 
     def encoder_backward(self, ps: EncPass, dfeats: Sequence[Optional[torch.Tensor]], grads: GradStore,
                          dtype: torch.dtype):
@@ -692,18 +765,19 @@ class Engine:
         packed = torch.empty(ns * K, dtype=torch.float64, device=dev)
         kn.shard_sum(sums, packed)  # slot 0 = sum(g) (local)
         sd = kn.zeros((1, 2, K), torch.float64, dev)
-        sd[0, 0].copy_(packed[:K])
+        kn.shard_sum(packed[:K], sd[0, 0])  # one "shard": a device copy without a torch operator
         kn.fold_dots(Wd, Md, sd[0, 1])
         kd = self._bn_bwd_coeffs(sd, 2, 1, u.bn, u.st, grads)
         dlin = kn.conv_desc(torch.float32, K, 1, 1, Ci, Ci, 1, 1, 1, 0)
         WA = torch.empty(K, 1, 1, Ci, dtype=torch.float32, device=dev)
         kn.conv_fwd(dlin, Wd, Ax, WA)
-        Wk1, Wk2 = torch.empty_like(WA), torch.empty_like(WA)
+        # the two-source weights [k1 o W ; W^T diag(k2) W] are built in place: both parts are row blocks of one matrix
+        wcat32 = kn.zeros((K + Ci, Ci), torch.float32, dev)
+        Wk1, Gd = wcat32[:K].view(K, 1, 1, Ci), wcat32[K:].view(Ci, 1, 1, Ci)
+        Wk2 = torch.empty_like(WA)
         bvec = kn.zeros((Ci,), torch.float32, dev)
         kn.fold_weights(Wd, Md, WA, kd[0], kd[1], kd[2], sx, grads.get(u.op.weight), Wk1, Wk2, bvec)
-        Gd = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
         kn.conv_wgrad(dlin, Wd, Wk2, Gd)
-        wcat32 = torch.cat([Wk1.view(K, Ci), Gd.view(Ci, Ci)], 0)
         wcat = wcat32 if dtype == torch.float32 else kn.cast_lowp(wcat32, torch.empty_like(wcat32, dtype=dtype))
         dx = torch.empty_like(x)
         if self.fuse_two_source and kn.conv_dgrad2(d, g, wcat, dx, x, bias=bvec):
@@ -730,7 +804,7 @@ class Engine:
             # dy is already the gated gradient (ReLU gate + pooled-feature gradient applied by its producer);
             # pre = [nshard][2][K] with slot 0 = sum(g); slot 1 is overwritten by fold_dots below
             g, sums, ns = dy, pre, 2
-            sums[:, 1].zero_()
+            kn.zero_slot(sums, 1)
         else:
             g, ns = torch.empty_like(rec.y_out), 3
             sums = kn.new_stats(K, 3, dev)
@@ -759,17 +833,17 @@ class Engine:
         dlin = kn.conv_desc(torch.float32, K, 1, 1, Cw, Cw, 1, 1, 1, 0)
         WA = torch.empty(K, 1, 1, Cw, dtype=torch.float32, device=dev)
         kn.conv_fwd(dlin, W, A, WA)  # A is symmetric: [out][in] == [in][out]
-        Wk1 = torch.empty_like(WA)
+        # [k1 o W ; G] are the two row blocks of ONE matrix (the two-source launch's weights), built in place
+        wcat32 = kn.zeros((K + Cw, Cw), torch.float32, dev)
+        Wk1, G = wcat32[:K].view(K, 1, 1, Cw), wcat32[K:].view(Cw, 1, 1, Cw)
         Wk2 = torch.empty_like(WA)
         bvec = kn.zeros((Cw,), torch.float32, dev)
         kn.fold_weights(W, Mm, WA, k[0], k[1], k[2], sa, grads.get(last.op.weight), Wk1, Wk2, bvec)
-        G = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
         kn.conv_wgrad(dlin, W, Wk2, G)  # G[i][j] = sum_k k2[k] W[k][i] W[k][j]
         s2 = kn.new_stats(Cw, 2, dev)
         da = torch.empty_like(a2)
         gate = (prev.c, prev.st.scale, prev.st.shift)
         # one launch: da2 = gate([g | a2] . [k1 o W ; G] + W^T k3), the k range of a2 follows the one of g
-        wcat32 = torch.cat([Wk1.view(K, Cw), G.view(Cw, Cw)], 0)
         wcat = wcat32 if dtype == torch.float32 else kn.cast_lowp(wcat32, torch.empty_like(wcat32, dtype=dtype))
         if self.fuse_two_source and kn.conv_dgrad2(d, g, wcat, da, a2, bias=bvec, mask=gate, sums=s2):
             return g, da, s2, kd, resid_ds
@@ -940,7 +1014,14 @@ class Engine:
         nun = len(recs[0].units)
         for i in range(nun - 1, -1, -1):
             us = [r.units[i] for r in recs]
+            u0 = us[0]
+            rows = [u.desc.N for u in us]
+            Cin, Kout = u0.desc.C, u0.desc.K
+            xcat = torch.empty(sum(rows), 1, 1, Cin, dtype=dtype, device=dev)
+            dcat = torch.empty(sum(rows), 1, 1, Kout, dtype=dtype, device=dev)
+            off = 0
             for v, u in enumerate(us):
+                dslot = dcat[off:off + rows[v]].view(rows[v], Kout)
                 if u.bn is not None:
                     Cn = u.c.shape[-1]
                     s2 = kn.new_stats(Cn, 2, dev)
@@ -951,20 +1032,15 @@ class Engine:
                     else:
                         kn.act_bwd_reduce(cur2, c2, None, None, None, s2)
                     k = self._bn_bwd_coeffs(s2, 2, 1, u.bn, u.st, grads)
-                    kn.bn_bwd_apply(cur2, c2, k[0], k[1], k[2], cur2)
-            u0 = us[0]
-            rows = [u.desc.N for u in us]
-            Cin, Kout = u0.desc.C, u0.desc.K
-            xcat = torch.empty(sum(rows), 1, 1, Cin, dtype=dtype, device=dev)
-            dcat = torch.empty(sum(rows), 1, 1, Kout, dtype=dtype, device=dev)
-            off = 0
-            for v, u in enumerate(us):
+                    kn.bn_bwd_apply(cur2, c2, k[0], k[1], k[2], dslot)  # lands in its rows of the stacked gradient
+                else:
+                    kn.copy2d(curs[v], 0, Kout, dcat, off * Kout, Kout, rows[v], Kout)
+                curs[v] = dslot
                 xs = xcat[off:off + rows[v]]
                 if u.x_pro is not None:
                     kn.bn_act(u.x, u.x_pro.scale, u.x_pro.shift, xs, relu=True)
                 else:
-                    xs.view(rows[v], Cin).copy_(u.x.view(rows[v], Cin))
-                dcat[off:off + rows[v]].view(rows[v], Kout).copy_(curs[v].view(rows[v], Kout))
+                    kn.copy2d(u.x, 0, Cin, xcat, off * Cin, Cin, rows[v], Cin)
                 off += rows[v]
             dpair = kn.conv_desc(dtype, sum(rows), 1, 1, Cin, Kout, 1, 1, 1, 0)
             kn.conv_wgrad(dpair, xcat, dcat, grads.get(u0.op.weight))

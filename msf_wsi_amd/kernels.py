@@ -455,6 +455,19 @@ def bn_finalize(sums, count, gamma, beta, eps, momentum, running_mean, running_v
                                       _p(shift), _p(mean), _p(invstd), _stream()), "bn_finalize")
 
 
+def bn_eval_coeffs(running_mean, running_var, gamma, beta, eps, scale, shift, mean, invstd):
+    """eval-mode BatchNorm: the affine map from the running statistics (no reduction, no exchange)"""
+    lib = _lib.load()
+    Cn = scale.numel()
+    for n, t in (("running_mean", running_mean), ("running_var", running_var), ("scale", scale), ("shift", shift),
+                 ("mean", mean), ("invstd", invstd)):
+        _req(t, n, torch.float32, Cn)
+    _opt(gamma, "gamma", torch.float32, Cn)
+    _opt(beta, "beta", torch.float32, Cn)
+    _lib.check(lib.msfwsi_bn_eval_coeffs(_p(running_mean), _p(running_var), _p(gamma), _p(beta), float(eps), Cn,
+                                         _p(scale), _p(shift), _p(mean), _p(invstd), _stream()), "bn_eval_coeffs")
+
+
 def shard_sum(sums, out):
     lib = _lib.load()
     _req(sums, "sums", torch.float64)
@@ -726,7 +739,8 @@ def scaler_update(scale, tracker, found, growth_factor, backoff_factor, growth_i
 
 
 def adam(p, g, m, v, lr, beta1, beta2, eps, step, loss_scale=None, found=None, p_lowp=None):
-    """p_lowp: bf16 / fp16 compute copy of p refreshed in the same pass"""
+    """p_lowp: bf16 / fp16 compute copy of p refreshed in the same pass; step: host int, or a device int32[1]
+    tensor (advanced by adam_step_advance) from which the kernel forms the bias corrections itself"""
     lib = _lib.load()
     n = p.numel()
     for nm, t in (("p", p), ("g", g), ("m", m), ("v", v)):
@@ -737,8 +751,20 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, step, loss_scale=None, found=None, p
     if p_lowp is not None:
         _req(p_lowp, "p_lowp", None, n)
         code = LOWP[p_lowp.dtype]
+    step_dev = None
+    if isinstance(step, torch.Tensor):
+        _req(step, "step", torch.int32, 1)
+        step_dev, step = step, 0
     _lib.check(lib.msfwsi_adam(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps),
-                               int(step), _p(loss_scale), _p(found), _p(p_lowp), code, _stream()), "adam")
+                               int(step), _p(step_dev), _p(loss_scale), _p(found), _p(p_lowp), code, _stream()), "adam")
+
+
+def adam_step_advance(step, found=None):
+    """step[0] += 1 unless found[0] > 0 (a step the GradScaler skips does not advance Adam's step count)"""
+    lib = _lib.load()
+    _req(step, "step", torch.int32, 1)
+    _opt(found, "found", torch.float32, 1)
+    _lib.check(lib.msfwsi_adam_step_advance(_p(step), _p(found), _stream()), "adam_step_advance")
 
 
 def cast_lowp(src, dst):
@@ -748,6 +774,25 @@ def cast_lowp(src, dst):
     _req(dst, "dst", None, src.numel())
     _lib.check(lib.msfwsi_cast_lowp(LOWP[dst.dtype], _p(src), _p(dst), src.numel(), _stream()), "cast_lowp")
     return dst
+
+
+def upcast_f32(src, dst=None):
+    """bf16 / fp16 -> fp32"""
+    lib = _lib.load()
+    _req(src, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    _req(dst, "dst", torch.float32, src.numel())
+    _lib.check(lib.msfwsi_upcast_f32(LOWP[src.dtype], _p(src), _p(dst), src.numel(), _stream()), "upcast_f32")
+    return dst
+
+
+def zero_slot(sums, slot: int):
+    """sums[:, slot, :] = 0 for a sharded fp64 accumulator [nshard][slots][C]"""
+    lib = _lib.load()
+    _req(sums, "sums", torch.float64)
+    nsh, nslots, Cn = sums.shape
+    _lib.check(lib.msfwsi_zero_f64_2d(sums.data_ptr() + slot * Cn * 8, nsh, Cn, nslots * Cn, _stream()), "zero_slot")
 
 
 def pad_cast(src, dst, rows, Cn, CP):

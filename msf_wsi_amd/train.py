@@ -65,7 +65,9 @@ class PretrainStep:
         self.lrs = [self.init_lr * float(m) for m in ms_lr]
         self.betas = (0.9, 0.999)
         self.eps = [1e-8, 1e-8, 1e-8]
-        self.t = 0
+        # Adam's step count lives on the device: it advances only on steps the GradScaler does not skip
+        # (scaler.step(optimizer), ssl_train.py:473), and the kernel forms the bias corrections from it
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.flats = FlatGroups(model, lowp_dtype=None if dtype == torch.float32 else dtype)
         self.engine = Engine(process_group=process_group, sync_bn=sync_bn)
         model._engine = self.engine
@@ -80,8 +82,14 @@ class PretrainStep:
         # gradients travel on their OWN communicator: the multi-GB all-reduce of the head group must not sit in
         # front of the latency-bound SyncBN exchanges of the encoder backward that is still running
         grad_group = process_group
-        if world_size(process_group) > 1 and process_group is None:
+        import os
+
+        force = os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0"
+        if process_group is None and (world_size(process_group) > 1 or force):
             import torch.distributed as dist
+
+            if not (dist.is_available() and dist.is_initialized()):
+                raise _lib.MsfwsiHipError("MSFWSI_FORCE_SYNC needs an initialised process group")
 
             grad_group = dist.new_group(backend=dist.get_backend())
         self.reducer = GradReducer(self.flats, grad_group)
@@ -134,8 +142,12 @@ class PretrainStep:
         self.epoch_meter[1] += bs
         return loss
 
+    @property
+    def t(self) -> int:
+        """Adam's step count (host read-back: synchronises; used by checkpointing and tests only)"""
+        return int(self.step_dev.item())
+
     def optimizer_step(self):
-        self.t += 1
         found = None
         ls = None
         if self.use_scaler:
@@ -143,15 +155,17 @@ class PretrainStep:
             for g in self.flats.g:
                 kn.nonfinite_check(g, self.found_inf)
             found, ls = self.found_inf, self.scale
+        kn.adam_step_advance(self.step_dev, found)
         for gi in range(3):
             kn.adam(self.flats.w[gi], self.flats.g[gi], self.flats.m[gi], self.flats.v[gi], self.lrs[gi],
-                    self.betas[0], self.betas[1], self.eps[gi], self.t, loss_scale=ls, found=found,
+                    self.betas[0], self.betas[1], self.eps[gi], self.step_dev, loss_scale=ls, found=found,
                     p_lowp=self.flats.w16[gi])
         if self.use_scaler:
             kn.scaler_update(self.scale, self.growth_tracker, self.found_inf, self.growth_factor,
                              self.backoff_factor, self.growth_interval)
-        # padded / cast copies keyed on torch's version counter do not see raw-pointer updates
-        self.engine.weights._cache.clear()
+        # padded / cast copies (and the stem's filter-row runs) keyed on torch's version counter do not see
+        # raw-pointer updates
+        self.engine.invalidate_weights()
 
     def epoch_loss(self) -> float:
         """sample-weighted mean loss over ranks (ssl_train.py:483-486); syncs once per epoch"""
@@ -172,11 +186,12 @@ class PretrainStep:
 
     def optimizer_state_dict(self) -> dict:
         opt = self._torch_adam()
-        if self.t > 0:
+        t = self.t
+        if t > 0:
             for gi, plist in enumerate(self.flats.params):
                 for pi, p in enumerate(plist):
                     m, v = self.flats.state_views(gi, pi)
-                    opt.state[p] = {"step": torch.tensor(float(self.t)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+                    opt.state[p] = {"step": torch.tensor(float(t)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
         return opt.state_dict()
 
     def load_optimizer_state_dict(self, sd: dict):
@@ -196,7 +211,7 @@ class PretrainStep:
                 steps.add(int(float(st["step"])))
         if len(steps) > 1:
             raise ValueError("per-parameter Adam step counts differ; not a checkpoint of this training loop")
-        self.t = steps.pop() if steps else 0
+        self.step_dev.fill_(steps.pop() if steps else 0)
 
     def scaler_state_dict(self) -> dict:
         if not self.use_scaler:
@@ -232,7 +247,7 @@ class PretrainStep:
         if self.dtype != torch.float32:
             for gi in range(3):
                 kn.cast_lowp(self.flats.w[gi], self.flats.w16[gi])
-        self.engine.weights._cache.clear()
+        self.engine.invalidate_weights()
         return int(ckpt["epoch"])
 
 

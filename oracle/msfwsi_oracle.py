@@ -63,8 +63,18 @@ def _bn(sd: StateDict, key: str, x: Tensor, train: bool = True) -> Tensor:
     return out
 
 
-def encoder_forward(sd: StateDict, prefix: str, x: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """resnet.py:232-256 with return_features=True and fc = Identity (backbone.py:64-65)"""
+def encoder_forward(sd: StateDict, prefix: str, x: Tensor, train: bool = True) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """resnet.py:232-256 with return_features=True and fc = Identity (backbone.py:64-65); train=False is the module
+    under .eval(): every BatchNorm normalises with its running statistics"""
+    bn = _bn
+    if not train:
+        def _bn_eval(sd_, key, x_):
+            return bn(sd_, key, x_, train=False)
+        return _encoder_forward(sd, prefix, x, _bn_eval)
+    return _encoder_forward(sd, prefix, x, _bn)
+
+
+def _encoder_forward(sd: StateDict, prefix: str, x: Tensor, _bn) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     y = F.conv2d(x, sd[prefix + "conv1.weight"], None, stride=2, padding=3)
     y = F.relu(_bn(sd, prefix + "bn1", y))
     y = F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
@@ -221,7 +231,7 @@ def train_step(sd: StateDict, batch, opt: Adam, scale: int = 4, mask_ratio: floa
     grads = {}
     for k, v in params.items():
         v.requires_grad_(False)
-        grads[k] = None if v.grad is None else v.grad / loss_scale
+        grads[k] = None if v.grad is None else (v.grad if loss_scale == 1.0 else v.grad / loss_scale)
         v.grad = None
     finite = all(torch.isfinite(g).all() for g in grads.values() if g is not None)
     if finite:

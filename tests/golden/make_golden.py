@@ -33,9 +33,19 @@ CASES = {
     # name: (arch, B, image size, run adam?, run fp64?)
     "r18_b2_s64": ("resnet18", 2, 64, True, True),
     "r18_b8_s64": ("resnet18", 8, 64, True, True),
-    "r18_b8_s224": ("resnet18", 8, 224, True, False),
+    "r18_b8_s224": ("resnet18", 8, 224, True, True),   # BASELINE config 1 (fp64 reference: the noise floor at 224x224)
+    # ResNet-50-derived model (1.665 B parameters): forward + loss + backward, no Adam (host RAM)
     "r50_b2_s64": ("resnet50", 2, 64, False, False),
+    "r50_b8_s64": ("resnet50", 8, 64, False, True),
 }
+
+
+class _NoOpt:
+    """stand-in for oracle.Adam when a case does not step (the real one allocates two moments per parameter)"""
+
+    def step(self, *a, **k):
+        pass
+
 
 
 def hub_stub(resnet_mod):
@@ -115,9 +125,12 @@ def reference_step(model, batch, B, do_adam):
             loss = loss + t * WEIGHTS[i]
     opt.zero_grad()
     loss.backward()
-    grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in named}
     if do_adam:
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in named}
         opt.step()
+    else:  # nothing overwrites .grad afterwards: no second copy of 1.665 B gradients
+        grads = {n: (p.grad.detach() if p.grad is not None else None) for n, p in named}
+    out = tuple(tuple(tuple(t.detach() for t in tup) for tup in grp) for grp in out)  # drop the autograd graph
     return loss.detach(), torch.stack(terms), out, grads
 
 
@@ -157,15 +170,14 @@ def run_case(name):
 
     # ---- fp32 reference run
     loss32, terms32, out32, grads32 = reference_step(ref, batch, B, do_adam)
-    sd1 = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    sd1 = {k: (v.detach().clone() if do_adam or not orc.is_param(k) else v.detach())
+           for k, v in ref.state_dict().items()}
     print(f"[{name}] fp32 reference step done ({time.time() - t0:.1f}s) loss={loss32.item():.9f}")
 
     # ---- (3) oracle vs reference, fp32, same initial state
     osd = {k: v.clone() for k, v in sd0.items()}
     lr = orc.init_lr(LR, B)
-    opt = orc.Adam(osd, [lr, lr, lr])
-    if not do_adam:
-        opt.step = lambda *a, **k: None
+    opt = orc.Adam(osd, [lr, lr, lr]) if do_adam else _NoOpt()
     oloss, oterms, oout, ograds = orc.train_step(osd, batch, opt, 4, 0.5, WEIGHTS)
     assert abs(oloss.item() - loss32.item()) < 1e-6, (oloss.item(), loss32.item())
     flat_o = [t for grp in oout for tup in grp for t in tup]
@@ -185,6 +197,10 @@ def run_case(name):
         else:
             assert torch.equal(osd[k], sd1[k]), k
     print(f"[{name}] oracle == reference (worst grad rel {worst:.2e})")
+    del osd, ograds, oout, opt
+    bn_keys = ("running_mean", "running_var", "num_batches_tracked")
+    if not do_adam:  # only the BatchNorm buffers of the post-step state are written out below
+        sd1 = {k: v for k, v in sd1.items() if k.endswith(bn_keys)}
 
     gold_loss, gold_terms, gold_out, gold_grads, gold_sd1 = loss32, terms32, out32, grads32, sd1
     if do_f64:
@@ -192,13 +208,18 @@ def run_case(name):
         ref64 = build_reference(arch).double()
         b64 = orc.synthetic_batch(B, size, 16, DATA_SEED, torch.float64)
         loss64, terms64, out64, grads64 = reference_step(ref64, b64, B, do_adam)
-        sd1_64 = {k: v.detach().clone() for k, v in ref64.state_dict().items()}
+        sd1_64 = {k: v.detach().clone() for k, v in ref64.state_dict().items() if do_adam or k.endswith(bn_keys)}
         gold_loss, gold_terms, gold_out, gold_grads, gold_sd1 = loss64, terms64, out64, grads64, sd1_64
         print(f"[{name}] fp64 reference loss={loss64.item():.12f}")
         # the reference's own fp32<->fp64 spread: the parity noise floor per tensor
         vec["spread_grad"] = np.array([rel(grads32[k], grads64[k]) if grads64[k] is not None else 0.0
                                        for k in grads64])
         vec["spread_terms"] = (terms32.double() - terms64).abs().numpy()
+        if do_adam:  # ... and of the updated weights after one Adam step (the north star's third parity object)
+            vec["spread_step"] = np.array([rel(sd1[k], sd1_64[k]) for k in grads64])
+        flat32 = [t for grp in out32 for tup in grp for t in tup]
+        flat64 = [t for grp in out64 for tup in grp for t in tup]
+        vec["spread_out"] = np.array([rel(a, b) for a, b in zip(flat32, flat64)])
 
     vec["loss"] = np.array([float(gold_loss)])
     vec["loss_fp32"] = np.array([float(loss32)])

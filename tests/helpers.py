@@ -71,3 +71,125 @@ def reference_loop_loss(outputs, weights=WEIGHTS):
             terms.append(t.detach())
             loss = loss + t * weights[i]
     return loss, torch.stack(terms)
+
+
+# --------------------------------------------------------------------------------------------------
+# parity gates (north_star: 1e-3 relative fp32 on loss, embeddings, gradients, updated weights)
+# --------------------------------------------------------------------------------------------------
+FLOOR = 1e-3  # north_star tolerance
+
+
+def spread_gate(rels, names, spreads, what, envelope=()):
+    """Per-tensor gate of SURVEY.md 8(d): rel-L2 against the fp64 oracle <= max(1e-3, 2 x the reference's OWN
+    fp32<->fp64 spread of that tensor).
+
+    rels     per-tensor rel-L2 of the product against the fp64 oracle
+    spreads  samples of the reference's own per-tensor noise, same tensor order: the committed fixture
+             (`spread_grad` / `spread_step`, real reference fp32 vs fp64, build container) and the oracle's fp32 vs
+             fp64 run on THIS machine.  Per tensor the allowance uses the largest sample.
+    envelope further samples of the same noise on other inputs (other fixture cases), used only for the size bound
+             of rule 2.
+
+    Rule 1 (per tensor): rel <= max(1e-3, 2 * spread).  The tensors that needed the spread allowance are printed.
+    Rule 2 (outliers): the noise is a ReLU-gate flip process -- one pre-activation inside the forward rounding noise
+             flips, and every gradient below it moves by 1e-3 .. 1e-2; each fp32 run of the REFERENCE shows these jumps
+             on different tensors (compare the samples).  A product tensor beyond rule 1 is accepted only while the
+             product shows no more such tensors than the worst reference sample does (count of tensors above 1e-3),
+             none of them further out than 2 x the largest spread any reference sample shows.  Nothing here is a free
+             constant: every bound is read from the fixtures / the same-machine reference run.
+    """
+    rels = np.asarray(rels, dtype=np.float64)
+    samples = [np.asarray(s, dtype=np.float64) for s in spreads]
+    env = np.max(np.stack(samples), axis=0)
+    allow = np.maximum(FLOOR, 2.0 * env)
+    over = rels > allow
+    needed = (rels > FLOOR) & ~over
+    if needed.any():
+        print(f"[{what}] {int(needed.sum())}/{len(rels)} tensors above 1e-3 but within 2x the reference's own "
+              f"fp32<->fp64 spread:")
+        for i in np.flatnonzero(needed)[:40]:
+            print(f"    {names[i]}: rel {rels[i]:.2e}  (reference spread {env[i]:.2e})")
+    n_ref = max(int((s > FLOOR).sum()) for s in samples + [np.asarray(e) for e in envelope])
+    worst_ref = max(float(np.max(s)) for s in samples + [np.asarray(e) for e in envelope])
+    if over.any():
+        print(f"[{what}] {int(over.sum())} tensors beyond their own spread allowance (gate flips that the reference "
+              f"samples show on OTHER tensors; the reference's worst sample has {n_ref} tensors above 1e-3, "
+              f"largest spread {worst_ref:.2e}):")
+        for i in np.flatnonzero(over)[:40]:
+            print(f"    {names[i]}: rel {rels[i]:.2e}  (allowance {allow[i]:.2e})")
+    print(f"[{what}] median {np.median(rels):.2e}  p90 {np.quantile(rels, 0.9):.2e}  max {rels.max():.2e} "
+          f"({names[int(rels.argmax())]}); reference noise: median {np.median(env):.2e} max {env.max():.2e}")
+    assert np.median(rels) <= max(FLOOR, 2.0 * float(np.median(env))), (what, "median", float(np.median(rels)))
+    assert int(over.sum()) <= n_ref, (what, "tensors beyond their allowance", int(over.sum()), "reference", n_ref)
+    if over.any():
+        assert float(rels[over].max()) <= max(FLOOR, 2.0 * worst_ref), (what, names[int(rels.argmax())],
+                                                                        float(rels[over].max()), worst_ref)
+    return rels
+
+
+def grad_rels(named_grads, ref):
+    return np.array([rel(g, ref[n]) for n, g in named_grads])
+
+
+def step_rels(named_params, ref_sd1):
+    """per-tensor rel-L2 of the UPDATED weights (north_star: 'updated weights match ... within 1e-3')"""
+    return np.array([rel(p, ref_sd1[n]) for n, p in named_params])
+
+
+_ORACLE_CACHE = {}
+
+
+def oracle_case(case):
+    """One fp64 and one fp32 oracle step (forward, loss, backward, Adam) of a golden case on THIS machine, shared by
+    the tests of a session: {B, size, batch, sd0, lr, loss64, terms64, outs64, grads64, sd64 (updated weights),
+    loss32, grads32, sd32, names, box_grad, box_step (the oracle's own fp32<->fp64 spread per tensor here)}"""
+    if case in _ORACLE_CACHE:
+        return _ORACLE_CACHE[case]
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden(case)
+    B, size = man["B"], man["size"]
+    model = build_product(man["arch"])
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, _ in model.named_parameters()]
+    del model
+    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
+    lr = orc.init_lr(LR, B)
+    out = {"B": B, "size": size, "batch": batch, "sd0": sd0, "lr": lr, "names": names, "vec": vec, "man": man}
+    for tag, dt in (("64", torch.float64), ("32", torch.float32)):
+        sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        (c1, c2), (t1, t2), idx = batch
+        b = ((c1.to(dt), c2.to(dt)), (t1.to(dt), t2.to(dt)), idx)
+        loss, terms, outs, grads = orc.train_step(sd, b, orc.Adam(sd, [lr, lr, lr]), 4, 0.5, WEIGHTS)
+        out["loss" + tag] = float(loss)
+        out["terms" + tag] = torch.stack([t for row in terms for t in row])
+        out["outs" + tag] = tuple(tuple(tuple(t.detach() for t in tup) for tup in grp) for grp in outs)
+        out["grads" + tag] = grads
+        out["sd" + tag] = sd
+    # pinned: this machine's fp64 oracle reproduces the real reference's golden loss terms
+    assert torch.allclose(out["terms64"], torch.as_tensor(vec["terms"]), rtol=0, atol=1e-7)
+    out["box_grad"] = np.array([rel(out["grads32"][n], out["grads64"][n]) for n in names])
+    out["box_step"] = np.array([rel(out["sd32"][n], out["sd64"][n]) for n in names])
+    _ORACLE_CACHE[case] = out
+    return out
+
+
+def other_spreads(key, skip):
+    """the same reference noise measured on the other fixture cases (size bound of spread_gate's rule 2)"""
+    res = []
+    for case in ("r18_b8_s64", "r18_b8_s224"):
+        if case != skip:
+            vec, _ = load_golden(case)
+            if key in vec:
+                res.append(vec[key])
+    return res
+
+
+def gate_updated_weights(named_params, case, what):
+    """updated weights of `case` after one Adam step against the fp64 oracle, allowance from the fixture's
+    spread_step and this machine's oracle spread"""
+    oc = oracle_case(case)
+    names = [n for n, _ in named_params]
+    assert names == oc["names"]
+    return spread_gate(step_rels(named_params, oc["sd64"]), names, [oc["vec"]["spread_step"], oc["box_step"]], what,
+                       envelope=other_spreads("spread_step", case))

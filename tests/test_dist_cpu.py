@@ -161,3 +161,28 @@ def test_shard_range_and_layout():
     sd = {k: torch.zeros_like(v) for k, v in model.state_dict().items()}
     model.load_state_dict(sd)
     assert all(float(w.abs().sum()) == 0 for w in flats.w)
+
+
+def test_bench_self_launcher_rendezvous():
+    """`python bench.py --gpus 2` as the driver may call it (no WORLD_SIZE in the environment): the parent starts one
+    rank per GPU through torch.distributed.run over 127.0.0.1, the ranks form the process group, pass the collective
+    capability probe and a barrier, rank 0 prints one JSON line and the parent returns the ranks' exit code
+    (gloo here: there is no GPU in this container; the compute part needs an MI355X)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MSFWSI_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"rendezvous": "ok", "world": 2, "backend": "gloo"}
+    # without a GPU the compute path refuses loudly (no CPU fallback), and the launcher passes the failure on
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    if not __import__("torch").cuda.is_available():
+        assert r.returncode != 0

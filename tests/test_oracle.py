@@ -86,3 +86,21 @@ def test_param_groups_and_lr():
     assert [len(g) for g in groups] == [108, 108, 48]
     assert sum(sd[k].numel() for g in groups for k in g) == 123551584
     assert abs(orc.init_lr(1e-3, 8) - 1e-3 * 8 ** 0.5 / 32 ** 0.5) < 1e-15
+
+
+@pytest.mark.parametrize("case_name", ["r50_b8_s64", "r50_b2_s64"])
+def test_resnet50_derived_fixture_manifest(case_name):
+    """the ResNet-50-DERIVED model (reference trunk + reference head factories + reference forward, width
+    list x block expansion) that BASELINE configs 2-4 run: the fixture written by make_golden.py after it asserted
+    oracle == reference and product init == reference init (the 1.665 B-parameter model is not rebuilt here)"""
+    vec, man = load_golden(case_name)
+    assert man["arch"] == "resnet50" and "derived oracle" in man["provenance"]
+    assert len(man["keys"]) == 924 and len(man["param_keys"]) == 462
+    n_param = sum(int(np.prod(shape)) for k, shape, _ in man["keys"] if k in set(man["param_keys"]))
+    assert abs(n_param - 1.665e9) < 1e6
+    assert vec["terms"].shape == (12,) and np.isfinite(vec["terms"]).all()
+    w = np.tile(np.array(WEIGHTS), 3)
+    assert abs(float((vec["terms"] * w).sum()) - float(vec["loss"][0])) < 1e-7  # fp32 case: terms summed in fp32
+    assert vec["grad_norm"].shape == (462,) and (vec["grad_norm"] >= 0).all()
+    if "spread_grad" in vec:  # the reference's own fp32<->fp64 noise floor on this model: ~2e-2 on most tensors
+        assert vec["spread_grad"].shape == (462,) and np.median(vec["spread_grad"]) > 1e-3

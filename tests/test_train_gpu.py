@@ -6,17 +6,17 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import LR, WEIGHTS, build_product, load_golden, rel
+from helpers import LR, WEIGHTS, build_product, load_golden, rel, spread_gate, step_rels
 
 pytestmark = pytest.mark.gpu
 
 
-def _oracle(sd0, batch, B, steps=1):
+def _oracle(sd0, batch, B, steps=1, dt=torch.float64):
     from oracle import msfwsi_oracle as orc
 
-    osd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    osd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
     (c1, c2), (t1, t2), idx = batch
-    b64 = ((c1.double(), c2.double()), (t1.double(), t2.double()), idx)
+    b64 = ((c1.to(dt), c2.to(dt)), (t1.to(dt), t2.to(dt)), idx)
     lr = orc.init_lr(LR, B)
     opt = orc.Adam(osd, [lr, lr, lr])
     losses = []
@@ -48,9 +48,14 @@ def test_fused_step_fp32_matches_oracle(hip_lib):
     l2 = ts.step(gb)
     torch.cuda.synchronize()
     assert abs(float(l1) - olosses[0]) <= 1e-3 * max(abs(olosses[0]), 1e-2)
-    assert abs(float(l1) - float(vec["loss"][0])) <= 2e-3 * max(abs(float(vec["loss"][0])), 1e-2)
-    # second step sees the updated weights: loose bound (Adam's first steps are sign-like, noise amplifies)
-    assert abs(float(l2) - olosses[1]) <= 5e-2 * max(abs(olosses[1]), 1e-1)
+    assert abs(float(l1) - float(vec["loss"][0])) <= 1e-3 * max(abs(float(vec["loss"][0])), 1e-2)
+    # second step sees the updated weights.  Adam's first step is lr*sign(g), so elements whose gradient lies inside
+    # the fp32 noise move the other way; the reference's own fp32 second-step loss shows how far that carries:
+    # allow 2x its distance from the fp64 run (floor: the 1e-3 of the first step)
+    o32, _ = _oracle(sd0, batch, B, steps=2, dt=torch.float32)
+    ref_spread = abs(o32[1] - olosses[1])
+    print(f"second-step loss: product {float(l2):.6f} fp64 oracle {olosses[1]:.6f} fp32 oracle {o32[1]:.6f}")
+    assert abs(float(l2) - olosses[1]) <= max(1e-3 * max(abs(olosses[1]), 1e-2), 2 * ref_spread)
     assert ts.scale.item() == 1024.0 and ts.found_inf.item() == 0
     now = model.state_dict()
     for k, v in osd.items():
@@ -64,18 +69,23 @@ def test_fused_single_step_weights_fp32(hip_lib):
 
     vec, man = load_golden("r18_b8_s64")
     B, size = man["B"], man["size"]
-    spread = dict(zip(man["param_keys"], vec["spread_grad"]))
     model = build_product("resnet18")
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
     _, osd = _oracle(sd0, batch, B, steps=1)
+    _, osd32 = _oracle(sd0, batch, B, steps=1, dt=torch.float32)
     model = model.cuda().train()
     ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False)
     ts.step(_gpu_batch(batch))
     torch.cuda.synchronize()
-    from test_parity_gpu import update_gate
+    from helpers import other_spreads
 
-    update_gate(list(model.named_parameters()), sd0, osd, LR * (B ** 0.5) / (32 ** 0.5))
+    named = list(model.named_parameters())
+    names = [n for n, _ in named]
+    assert names == man["param_keys"]
+    box_step = np.array([rel(osd32[n], osd[n]) for n in names])
+    spread_gate(step_rels(named, osd), names, [vec["spread_step"], box_step], "fused step: updated weights vs fp64",
+                envelope=other_spreads("spread_step", "r18_b8_s64"))
     for k, v in osd.items():
         if k.endswith("running_var"):
             assert torch.allclose(model.state_dict()[k].cpu().double(), v, rtol=1e-4, atol=1e-6), k
