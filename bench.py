@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--layer-report", default=None,
+                    help="write a per-layer-shape table (time, TFLOP/s, GB/s of every dense and streaming launch of the "
+                         "event-timed steps) to this file")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, form the process group, run the collective probe and exit (launcher test)")
     args = ap.parse_args()
@@ -186,7 +189,7 @@ def main():
 
     for _ in range(args.warmup):
         ts.step(batch)
-    timer = None if args.no_kernel_timer else kn.KernelTimer()
+    timer = None if args.no_kernel_timer else kn.KernelTimer(streams=args.layer_report is not None)
     sync()
     # the per-launch HIP events cost ~1 % of the step: bracket the launches of the LAST two timed steps only
     timed_from = max(0, args.steps - 2)
@@ -220,6 +223,15 @@ def main():
                        "peak_mem_GiB": round(peak_mem, 1), "peak_reserved_GiB": round(peak_reserved, 1),
                        "step_TFLOPs_algorithmic": round(FLOP_PER_PAIR.get(args.arch, 0) * pairs / dt / 1e12, 1)},
         }
+        if timer is not None and args.layer_report:
+            rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1][1])
+            nst = args.steps - timed_from
+            with open(args.layer_report, "w") as f:
+                f.write(f"# per event-timed step ({nst} steps averaged); ms, TFLOP/s, GB/s are algorithmic\n")
+                f.write("kind\tms_per_step\tlaunches_per_step\tTFLOP/s\tGB/s\tshape\tsymbol\n")
+                for (kind, shape, sym), (n, sec, fl, by) in rows:
+                    f.write(f"{kind}\t{1e3 * sec / nst:.3f}\t{n / nst:.1f}\t{fl / sec / 1e12:.1f}\t{by / sec / 1e9:.0f}\t"
+                            f"{shape}\t{sym if kind != 'stream' else ''}\n")
         if timer is not None:
             fam = timer.summary()
             summ = timer.summary(by_symbol=True)

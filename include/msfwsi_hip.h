@@ -215,6 +215,11 @@ int msfwsi_fold_weights(const float* W, const float* M, const float* WA, const f
 /* column sums of x[M][C] added into sums[shard][C] (fp64, nshard replicas against same-address atomic contention)
  * -- bias gradient of backbone.py:30's Linear; column sums of a folded BatchNorm's operand. */
 int msfwsi_colsum(int dtype, const void* x, double* sums, int nshard, long M, int C, void* stream);
+
+/* sums[nshard][2][C] += {sum_m x, sum_m x^2} of x[M][C], accumulated in fp64 throughout: the statistics of the heads'
+ * BatchNorm1d (src/models/backbone.py:15,18,21,28), whose inputs have a batch mean far larger than their batch
+ * deviation (E[x^2] - mean^2 cancels 3-4 digits; the GEMM epilogue's fp32 partial sums are not enough there). */
+int msfwsi_colstats(int dtype, const void* x, double* sums, int nshard, long M, int C, void* stream);
 int msfwsi_add_f64_to_f32(const double* in, float* out, int n, float alpha, void* stream);
 
 /* scatter == 0: out[b*K+k] = in[b*K+idx[b][k]] (jigsaw un-shuffle, src/models/backbone.py:147-158);

@@ -623,6 +623,56 @@ __global__ void colsum_kernel(const T* __restrict__ x, double* sums, int nshard,
     col_commit<1, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
 }
 
+// Column statistics {sum x, sum x^2} of [M][C] accumulated in fp64 from the first add on.  The heads' BatchNorm1d
+// (backbone.py:15,18,21,28) sees Linear outputs whose batch mean is 10..100x their batch deviation (pooled features of
+// different tiles are nearly equal), so var = E[x^2] - mean^2 cancels 3-4 digits: fp32 partial sums (the GEMM
+// epilogue's) would leave invstd with 1e-4 relative error there; fp64 sums make the cancellation harmless.
+template <typename T>
+__global__ void colstats_kernel(const T* __restrict__ x, double* sums, int nshard, long M, int C, int cw, int nrl,
+                                int rows_per_block) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    extern __shared__ double smem_d[];
+    const int tid = threadIdx.x;
+    const int cc = tid % cw, rl = tid / cw;
+    const int chunk = blockIdx.x * cw + cc;
+    const bool active = rl < nrl && chunk * VEC < C;
+    const int ch = chunk * VEC;
+    double s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.0;
+    if (active) {
+        const long rbeg = (long)blockIdx.y * rows_per_block;
+        const long rend = rbeg + rows_per_block < M ? rbeg + rows_per_block : M;
+        for (long m = rbeg + rl; m < rend; m += nrl) {
+            float f[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(x + m * C + ch), f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const double d = (double)f[e];
+                s1[e] += d;
+                s2[e] = fma(d, d, s2[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        smem_d[(0 * VEC + e) * kThreads + tid] = active ? s1[e] : 0.0;
+        smem_d[(1 * VEC + e) * kThreads + tid] = active ? s2[e] : 0.0;
+    }
+    __syncthreads();
+    if (active && rl == 0) {
+        double* dst = sums + (long)(blockIdx.y % nshard) * 2 * C;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double t = 0.0;
+                for (int r = 0; r < nrl; ++r) t += smem_d[(w * VEC + e) * kThreads + r * cw + cc];
+                atomicAdd(dst + (long)w * C + ch + e, t);
+            }
+    }
+}
+
 // bn_act with the column sums of its OUTPUT: out = relu(scale*c+shift), sums[c] += sum_m out  (the folded bn3
 // backward needs sum_p a2, see fold_weights_kernel; one pass instead of bn_act + colsum)
 template <typename T>
@@ -1015,6 +1065,16 @@ extern "C" int msfwsi_colsum(int dtype, const void* x, double* sums, int nshard,
     ColGrid cg = make_col_grid(M, C, vec, 1024);
     const size_t lds = (size_t)kThreads * vec * sizeof(float);
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)x, sums,
+                           nshard, M, C, cg.cw, cg.nrl, cg.rows_per_block));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_colstats(int dtype, const void* x, double* sums, int nshard, long M, int C, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && x && sums && nshard >= 1 && M > 0 && C % vec_of(dtype) == 0);
+    const int vec = vec_of(dtype);
+    ColGrid cg = make_col_grid(M, C, vec, 512);
+    const size_t lds = (size_t)kThreads * 2 * vec * sizeof(double);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(colstats_kernel<T>, cg.grid, dim3(kThreads), lds, ST(stream), (const T*)x, sums,
                            nshard, M, C, cg.cw, cg.nrl, cg.rows_per_block));
     return msfwsi_launch_status();
 }

@@ -344,6 +344,10 @@ class Engine:
         w = self.weights.get(op.weight, dtype, pad_to=pad_c)
         c = torch.empty(N, d.P, d.Q, K, dtype=dtype, device=x.device)
         stats = kn.new_stats(K, 2, x.device) if bn is not None else None
+        # BatchNorm1d of the heads: pooled features of different tiles are nearly equal, so a Linear output's batch mean
+        # is 10-100x its batch deviation and E[c^2] - mean^2 cancels 3-4 digits; the GEMM epilogue's fp32 partial sums
+        # are not enough there (1e-4 on invstd) -> statistics by a separate fp64 pass over the (small) output
+        epi_stats = stats if not isinstance(op, nn.Linear) else None
         bias = getattr(op, "bias", None)
         xin, pro = x, (x_pro.scale, x_pro.shift) if x_pro is not None else None
         if pro is not None and self.materialize_3x3 and (R * S > 1 or (self.materialize_1x1 and N * H * W >= self.mat_min_rows)):
@@ -357,7 +361,9 @@ class Engine:
         elif self.halo3x3_fwd and pro is None and bias is None and not pad_c and kn.conv3x3_supported(d):
             kn.conv3x3_fwd(d, xin, w, c, stats=stats)  # input patch staged once per channel slab, 9 taps reuse it
         else:
-            kn.conv_fwd(d, xin, w, c, pro=pro, bias=bias.data if bias is not None else None, stats=stats)
+            kn.conv_fwd(d, xin, w, c, pro=pro, bias=bias.data if bias is not None else None, stats=epi_stats)
+            if stats is not None and epi_stats is None:
+                kn.colstats(c, stats)
         u = Unit(op, bn, relu, d, x, x_pro, c)
         if bn is not None:
             u.st = self._bn_finalize(stats, N * d.P * d.Q, bn)

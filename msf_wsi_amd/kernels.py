@@ -123,15 +123,33 @@ class KernelTimer:
     (bench.py's roofline leg).  For every launch it keeps the algorithmic FLOPs and the algorithmic HBM
     bytes (each operand / result tensor counted once) next to the event pair."""
 
-    def __init__(self):
-        self.records = []  # (kind, symbol, flops, bytes, ev0, ev1)
+    def __init__(self, streams: bool = False):
+        self.records = []  # (kind, symbol, flops, bytes, ev0, ev1, shape)
+        self.stream_records = [] if streams else None  # (name, bytes, ev0, ev1): the HBM-bound elementwise kernels
+
+    def by_shape(self):
+        """per (kernel family, layer shape): launches, seconds, algorithmic FLOPs and bytes -- the layer report"""
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, sym, fl, by, e0, e1, shape in self.records:
+            a = agg.setdefault((kind, shape, sym), [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += fl
+            a[3] += by
+        for name, by, e0, e1 in self.stream_records or []:
+            a = agg.setdefault(("stream", name, name), [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[3] += by
+        return agg
 
     def summary(self, by_symbol: bool = False):
         """per kernel family (conv_fwd / conv_dgrad / conv_wgrad) or, by_symbol, per kernel symbol (the template
         instance the C side dispatches to -- the name rocprofv3 --kernel-trace --stats reports)"""
         torch.cuda.synchronize()
         agg = {}
-        for kind, sym, fl, by, e0, e1 in self.records:
+        for kind, sym, fl, by, e0, e1, _shape in self.records:
             a = agg.setdefault(sym if by_symbol else kind, [0, 0.0, 0.0, 0.0, kind])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
@@ -196,7 +214,22 @@ def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = 
     e0.record()
     r = fn()
     e1.record()
-    TIMER.records.append((kind, symbol_override or _symbol(kind, d, tcode, pro, halo, epi, two), flops, nbytes, e0, e1))
+    shape = f"N{d.N} {d.H}x{d.W} C{d.C}->K{d.K} {d.R}x{d.S}/s{d.stride}" + (" +src2" if two else "") + (
+        f" epi{epi}" if epi else "") + (f" +{extra_elems * esize >> 20}MiB epilogue" if extra_elems else "")
+    TIMER.records.append((kind, symbol_override or _symbol(kind, d, tcode, pro, halo, epi, two), flops, nbytes, e0, e1,
+                          shape))
+    return r
+
+
+def _stream_timed(name: str, nbytes: float, fn):
+    """the HBM-bound elementwise kernels, timed only for the layer report (KernelTimer(streams=True))"""
+    if TIMER is None or TIMER.stream_records is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    TIMER.stream_records.append((name, float(nbytes), e0, e1))
     return r
 
 
@@ -327,8 +360,9 @@ def pixel_stride(x, out, stride: int, expand: bool):
     _req(out, "out", x.dtype)
     if tuple(lo.shape) != (N, P, Q, Cn):
         raise ValueError(f"pixel_stride: low-resolution tensor must be {(N, P, Q, Cn)}, got {tuple(lo.shape)}")
-    _lib.check(lib.msfwsi_pixel_stride(dt_of(x), _p(x), _p(out), N, H, W, Cn, int(stride), int(bool(expand)), _stream()),
-               "pixel_stride")
+    _stream_timed("pixel_stride", x.element_size() * (x.numel() if expand else out.numel()) * 2, lambda: _lib.check(
+        lib.msfwsi_pixel_stride(dt_of(x), _p(x), _p(out), N, H, W, Cn, int(stride), int(bool(expand)), _stream()),
+        "pixel_stride"))
     return out
 
 
@@ -491,8 +525,9 @@ def bn_act(c, scale, shift, out, ident=None, id_scale=None, id_shift=None, relu=
     _opt(ident, "ident", c.dtype, M * Cn)
     _opt(id_scale, "id_scale", torch.float32, Cn)
     _opt(id_shift, "id_shift", torch.float32, Cn)
-    _lib.check(lib.msfwsi_bn_act(dt_of(c), _p(c), _p(scale), _p(shift), _p(ident), _p(id_scale), _p(id_shift),
-                                 int(bool(relu)), _p(out), M, Cn, _stream()), "bn_act")
+    _stream_timed("bn_act", c.element_size() * M * Cn * (2 + (ident is not None)), lambda: _lib.check(
+        lib.msfwsi_bn_act(dt_of(c), _p(c), _p(scale), _p(shift), _p(ident), _p(id_scale), _p(id_shift),
+                          int(bool(relu)), _p(out), M, Cn, _stream()), "bn_act"))
     return out
 
 
@@ -508,8 +543,9 @@ def bn_act_sum(c, scale, shift, out, sums):
     _req(sums, "sums", torch.float64, Cn)
     # sharded accumulation (one replica would serialise ~2000 workgroups on C addresses), then one tiny reduction
     part = ARENA.zeros((NSHARD, 1, Cn), torch.float64, c.device)
-    _lib.check(lib.msfwsi_bn_act_sum(dt_of(c), _p(c), _p(scale), _p(shift), _p(out), _p(part), NSHARD, M, Cn,
-                                     _stream()), "bn_act_sum")
+    _stream_timed("bn_act_sum", c.element_size() * M * Cn * 2, lambda: _lib.check(
+        lib.msfwsi_bn_act_sum(dt_of(c), _p(c), _p(scale), _p(shift), _p(out), _p(part), NSHARD, M, Cn, _stream()),
+        "bn_act_sum"))
     shard_sum(part, sums)
     return out
 
@@ -528,8 +564,10 @@ def block_end_bwd(dy, y, gapg, gap_scale, c_main, c_ds, g, sums, HW):
     nsh = sums.numel() // (3 * Cn)
     if nsh * 3 * Cn != sums.numel() or M % HW != 0:
         raise ValueError("block_end_bwd: bad sums / HW")
-    _lib.check(lib.msfwsi_block_end_bwd(dt_of(y), _p(dy), _p(y), _p(gapg), float(gap_scale), _p(c_main), _p(c_ds),
-                                        _p(g), _p(sums), nsh, M, HW, Cn, _stream()), "block_end_bwd")
+    _stream_timed("block_end_bwd", y.element_size() * M * Cn * (3 + (c_main is not None) + (c_ds is not None)),
+                  lambda: _lib.check(lib.msfwsi_block_end_bwd(dt_of(y), _p(dy), _p(y), _p(gapg), float(gap_scale),
+                                                              _p(c_main), _p(c_ds), _p(g), _p(sums), nsh, M, HW, Cn,
+                                                              _stream()), "block_end_bwd"))
 
 
 def act_bwd_reduce(da, c, scale, shift, g, sums):
@@ -545,8 +583,9 @@ def act_bwd_reduce(da, c, scale, shift, g, sums):
     nsh = sums.numel() // (2 * Cn)
     if nsh * 2 * Cn != sums.numel():
         raise ValueError("act_bwd_reduce: sums must be [nshard,2,C]")
-    _lib.check(lib.msfwsi_act_bwd_reduce(dt_of(c), _p(da), _p(c), _p(scale), _p(shift), _p(g), _p(sums), nsh, M, Cn,
-                                         _stream()), "act_bwd_reduce")
+    _stream_timed("act_bwd_reduce", c.element_size() * M * Cn * (2 + (g is not None)), lambda: _lib.check(
+        lib.msfwsi_act_bwd_reduce(dt_of(c), _p(da), _p(c), _p(scale), _p(shift), _p(g), _p(sums), nsh, M, Cn, _stream()),
+        "act_bwd_reduce"))
 
 
 def bn_bwd_finalize(sums, nslots, which, count, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3):
@@ -574,8 +613,9 @@ def bn_bwd_apply(g, c, k1, k2, k3, dc):
     _req(dc, "dc", c.dtype, M * Cn)
     for n, t in (("k1", k1), ("k2", k2), ("k3", k3)):
         _req(t, n, torch.float32, Cn)
-    _lib.check(lib.msfwsi_bn_bwd_apply(dt_of(c), _p(g), _p(c), _p(k1), _p(k2), _p(k3), _p(dc), M, Cn, _stream()),
-               "bn_bwd_apply")
+    _stream_timed("bn_bwd_apply", c.element_size() * M * Cn * 3, lambda: _lib.check(
+        lib.msfwsi_bn_bwd_apply(dt_of(c), _p(g), _p(c), _p(k1), _p(k2), _p(k3), _p(dc), M, Cn, _stream()),
+        "bn_bwd_apply"))
     return dc
 
 
@@ -585,7 +625,8 @@ def nchw_to_nhwc(x, y, CP):
     N, Cc, H, W = x.shape
     _req(x, "x", torch.float32)
     _req(y, "y", None, N * H * W * CP)
-    _lib.check(lib.msfwsi_nchw_to_nhwc(dt_of(y), _p(x), _p(y), N, Cc, H, W, CP, _stream()), "nchw_to_nhwc")
+    _stream_timed("nchw_to_nhwc", 4 * x.numel() + y.element_size() * y.numel(), lambda: _lib.check(
+        lib.msfwsi_nchw_to_nhwc(dt_of(y), _p(x), _p(y), N, Cc, H, W, CP, _stream()), "nchw_to_nhwc"))
     return y
 
 
@@ -597,8 +638,9 @@ def stem_pool_fwd(c0, scale, shift, out, argmax, N, H, W, Cn):
     _req(argmax, "argmax", torch.uint8, N * P * Q * Cn)
     _req(scale, "scale", torch.float32, Cn)
     _req(shift, "shift", torch.float32, Cn)
-    _lib.check(lib.msfwsi_stem_pool_fwd(dt_of(c0), _p(c0), _p(scale), _p(shift), _p(out), _p(argmax), N, H, W, Cn,
-                                        _stream()), "stem_pool_fwd")
+    _stream_timed("stem_pool_fwd", c0.element_size() * (N * H * W * Cn + N * P * Q * Cn) + N * P * Q * Cn,
+                  lambda: _lib.check(lib.msfwsi_stem_pool_fwd(dt_of(c0), _p(c0), _p(scale), _p(shift), _p(out),
+                                                              _p(argmax), N, H, W, Cn, _stream()), "stem_pool_fwd"))
 
 
 def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn, k=None):
@@ -622,16 +664,18 @@ def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn, k=None):
         k1, k2, k3 = k
         for nm, t in (("k1", k1), ("k2", k2), ("k3", k3)):
             _req(t, nm, torch.float32, Cn)
-    _lib.check(lib.msfwsi_stem_pool_bwd(dt_of(c0), _p(dp), _p(argmax), _p(c0), _p(scale), _p(shift), _p(g0),
-                                        _p(sums), nsh, _p(k1), _p(k2), _p(k3), N, H, W, Cn, _stream()),
-               "stem_pool_bwd")
+    _stream_timed("stem_pool_bwd", c0.element_size() * (N * H * W * Cn * (1 + (g0 is not None)) + N * P * Q * Cn)
+                  + N * P * Q * Cn, lambda: _lib.check(
+        lib.msfwsi_stem_pool_bwd(dt_of(c0), _p(dp), _p(argmax), _p(c0), _p(scale), _p(shift), _p(g0), _p(sums), nsh,
+                                 _p(k1), _p(k2), _p(k3), N, H, W, Cn, _stream()), "stem_pool_bwd"))
 
 
 def gap_fwd(y, out, N, HW, Cn):
     lib = _lib.load()
     _req(y, "y", None, N * HW * Cn)
     _req(out, "out", y.dtype, N * Cn)
-    _lib.check(lib.msfwsi_gap_fwd(dt_of(y), _p(y), _p(out), N, HW, Cn, _stream()), "gap_fwd")
+    _stream_timed("gap_fwd", y.element_size() * N * HW * Cn, lambda: _lib.check(
+        lib.msfwsi_gap_fwd(dt_of(y), _p(y), _p(out), N, HW, Cn, _stream()), "gap_fwd"))
     return out
 
 
@@ -675,6 +719,19 @@ def colsum(x, sums):
     tot = torch.empty(Cn, dtype=torch.float64, device=x.device)
     shard_sum(part, tot)
     sums.add_(tot)
+
+
+def colstats(x, stats):
+    """stats[nshard][2][C] += {column sums, column sums of squares} of x [M][C], fp64 from the first add on"""
+    lib = _lib.load()
+    _req(stats, "stats", torch.float64)
+    nsh = stats.shape[0]
+    Cn = stats.shape[-1]
+    M = x.numel() // Cn
+    _req(x, "x", None, M * Cn)
+    if stats.numel() != nsh * 2 * Cn:
+        raise ValueError("stats must be [nshard,2,C]")
+    _lib.check(lib.msfwsi_colstats(dt_of(x), _p(x), _p(stats), nsh, M, Cn, _stream()), "colstats")
 
 
 def add_f64_to_f32(src, dst, alpha=1.0):
@@ -755,8 +812,9 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, step, loss_scale=None, found=None, p
     if isinstance(step, torch.Tensor):
         _req(step, "step", torch.int32, 1)
         step_dev, step = step, 0
-    _lib.check(lib.msfwsi_adam(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps),
-                               int(step), _p(step_dev), _p(loss_scale), _p(found), _p(p_lowp), code, _stream()), "adam")
+    _stream_timed("adam", n * (28 + (2 if p_lowp is not None else 0)), lambda: _lib.check(
+        lib.msfwsi_adam(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps), int(step),
+                        _p(step_dev), _p(loss_scale), _p(found), _p(p_lowp), code, _stream()), "adam"))
 
 
 def adam_step_advance(step, found=None):

@@ -77,7 +77,7 @@ def test_two_ranks_match_single_process(hip_lib):
     assert abs(ret["loss"] - loss) <= 1e-5 * max(1.0, abs(loss)), (ret["loss"], loss)
     for k, v in model.state_dict().items():
         if "running_" in k:
-            assert torch.allclose(sd2[k].double(), v.detach().cpu().double(), rtol=1e-4, atol=1e-6), k
+            assert torch.allclose(sd2[k].double(), v.detach().cpu().double(), rtol=1e-3, atol=1e-5), k
     gate_updated_weights(list(model.named_parameters()), CASE, "1 rank: updated weights")
 
 

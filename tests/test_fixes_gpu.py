@@ -138,3 +138,24 @@ def test_rccl_path_executes_single_rank():
     b = json.loads(plain.stdout.strip().splitlines()[-1])
     assert np.isfinite(a["config"]["loss"])
     assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-4 * max(1.0, abs(b["config"]["loss"]))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 64), (4096, 512), (130, 2304)])
+def test_colstats_survives_cancellation(hip_lib, dt, shape):
+    """BatchNorm1d statistics of the heads: a batch mean 55x the batch deviation (measured on config 1's layer-1
+    features) makes E[x^2] - mean^2 cancel 3-4 digits; the fp64 column-statistics kernel must keep the variance exact"""
+    from msf_wsi_amd import kernels as kn
+
+    M, Cn = shape
+    g = torch.Generator().manual_seed(41)
+    x = (55.0 + torch.randn(M, Cn, generator=g)).to(dt)
+    stats = kn.new_stats(Cn)
+    kn.colstats(x.cuda(), stats)
+    torch.cuda.synchronize()
+    s = stats.sum(0).cpu()
+    xd = x.double()
+    assert torch.allclose(s[0], xd.sum(0), rtol=1e-13, atol=0)
+    assert torch.allclose(s[1], (xd * xd).sum(0), rtol=1e-13, atol=0)
+    var = s[1] / M - (s[0] / M) ** 2
+    assert torch.allclose(var, xd.var(0, unbiased=False), rtol=1e-9, atol=0)

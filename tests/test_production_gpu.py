@@ -290,6 +290,54 @@ def test_over_2gib_dgrad_gated_and_two_source(hip_lib, freed):
     assert rel(torch.where(clear, got3, want3), want3) < tol(dt)
 
 
+def test_gram_statistics_at_production_row_count(hip_lib, freed):
+    """bn3's batch statistics from the Gram matrix of conv3's operand (engine._gram_stats: sum c = W sum(a),
+    sum c^2 = diag(W (a^T a) W^T), fp32 Gram accumulated over 12.8 M pixels, variance as E[c^2] - mean^2) against the
+    statistics accumulated from the conv output itself, at the row count of config 2's layer 1 (N = 4096, 56x56)"""
+    from msf_wsi_amd import kernels as kn
+    from msf_wsi_amd.engine import Engine
+
+    dt = torch.bfloat16
+    N, H, Cw, Cx = 4096, 56, 64, 256
+    a = _rand_nhwc((N, H, H, Cw), dt, 21)
+    a.add_(0.5).clamp_(min=0)                                   # relu-like operand with a non-zero mean
+    g = torch.Generator().manual_seed(22)
+    w = rnd((Cx, Cw, 1, 1), dt, g, 1 / 8.0)
+    wd = nhwc(w).to(dt).cuda()
+    M = N * H * H
+    # explicit: the conv with its statistics epilogue (sums over the bf16-rounded outputs)
+    d = kn.conv_desc(dt, N, H, H, Cw, Cx, 1, 1, 1, 0)
+    c = torch.empty(N, H, H, Cx, dtype=dt, device="cuda")
+    stats = kn.new_stats(Cx)
+    kn.conv_fwd(d, a, wd, c, stats=stats)
+    bn_a, bn_b = torch.nn.BatchNorm2d(Cx).cuda().train(), torch.nn.BatchNorm2d(Cx).cuda().train()
+    eng = Engine()
+    st_explicit = eng._bn_finalize(stats, M, bn_a)
+    del c
+    # folded: Gram matrix + column sums of the operand
+    A = torch.zeros(Cw, 1, 1, Cw, device="cuda")
+    kn.conv_wgrad(kn.conv_desc(dt, N, H, H, Cw, Cw, 1, 1, 1, 0), a, a, A)
+    sa = torch.zeros(Cw, dtype=torch.float64, device="cuda")
+    kn.colsum(a, sa)
+    st_fold = eng._gram_stats(wd, A, sa, bn_b, M, dt)
+    torch.cuda.synchronize()
+    # exact statistics of c = W a in fp64 from the exact Gram matrix (a is exact in bf16)
+    a64 = torch.zeros(Cw, Cw, dtype=torch.float64, device="cuda")
+    for i in range(0, N, 128):
+        blk = a[i:i + 128].reshape(-1, Cw).double()
+        a64 += blk.t() @ blk
+    W64 = wd.view(Cx, Cw).double()
+    mean = (W64 @ sa) / M
+    var = ((W64 @ a64) * W64).sum(1) / M - mean * mean
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    for name, st in (("explicit", st_explicit), ("Gram", st_fold)):
+        em = float((st.mean.double() - mean).abs().max() / mean.abs().max())
+        ei = float(((st.invstd.double() - invstd) / invstd).abs().max())
+        print(f"   {name} statistics at M = {M}: mean err {em:.1e}, invstd err {ei:.1e}")
+        assert em < 1e-4 and ei < 1e-3, (name, em, ei)
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=2e-3)
+
+
 # ------------------------------------------------------------------------------------------------
 # full-size config 2
 # ------------------------------------------------------------------------------------------------
@@ -318,15 +366,15 @@ def test_config2_full_size_properties(hip_lib, freed):
         eng.update_running = False
         try:
             with torch.no_grad():
-                outs, _ = eng.model_forward(model, (batch[0][0], batch[1][0]), (batch[0][1], batch[1][1]), batch[2],
-                                            torch.bfloat16, need_backward=False)
+                outs, rec = eng.model_forward(model, (batch[0][0], batch[1][0]), (batch[0][1], batch[1][1]), batch[2],
+                                              torch.bfloat16, need_backward=False)
         finally:
             eng.fold_bn3_fwd, eng.fold_ds_fwd, eng.update_running = keep
         from helpers import reference_loop_loss
 
         loss, terms = reference_loop_loss(outs)
-        zs = [z.float() for grp in outs for z in grp[2]]
-        return float(loss), terms.cpu(), zs
+        feats = [f.float() for name in ("c0", "t0") for f in rec.enc[name].feats]
+        return float(loss), terms.cpu(), feats
 
     l_fold, t_fold, z_fold = forward_only(True)
     l_expl, t_expl, z_expl = forward_only(False)
@@ -336,8 +384,15 @@ def test_config2_full_size_properties(hip_lib, freed):
     # against statistics accumulated from the conv output itself: same network up to bf16 rounding of different tensors
     print("   per-term |difference|:", [f"{float(v):.1e}" for v in (t_fold - t_expl).abs()])
     assert float((t_fold - t_expl).abs().max()) <= 5e-3, (t_fold, t_expl)
-    for a, b in zip(z_fold, z_expl):
-        assert float((a - b).norm() / b.norm()) < 5e-2
+    # pooled encoder features (the heads' BatchNorm1d then amplifies the bf16 noise of these nearly sample-independent
+    # features of N(0,1) images by orders of magnitude -- the reference's own fp32 run is 2e-2 from its fp64 run on this
+    # model, fixture r50_b8_s64 -- so the embeddings themselves are not comparable between two bf16 evaluation orders)
+    fr = [float((a - b).norm() / b.norm()) for a, b in zip(z_fold, z_expl)]
+    print("   pooled-feature rel-L2, folded vs explicit:", [f"{v:.1e}" for v in fr])
+    # two bf16 evaluation orders of a 50-layer network: rounding-level after layers 1-2, a few per cent at layer 3 and
+    # ~1e-1 at layer 4 (each BatchNorm re-normalises, i.e. amplifies, the accumulated bf16 noise); a wrong statistic
+    # would be O(1) from the first folded block on (the statistics themselves: test_gram_statistics_... above)
+    assert max(fr[0], fr[1], fr[4], fr[5]) < 1e-2 and max(fr) < 0.25
     del z_fold, z_expl
     torch.cuda.empty_cache()
     loss = float(ts.step(batch))
