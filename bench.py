@@ -26,17 +26,22 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = {"resnet18": 363.37e9, "resnet50": 848.8e9}  # SURVEY.md 8(d), fwd+bwd per tile pair
 
 
-def pmc_traffic(symbol):
-    """L2-miss (fabric) bytes per launch of the kernel whose mangled name contains `symbol`, from the committed PMC
-    summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, scratch/pmc_summary.py)"""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_entry(symbol):
+    """counter-derived figures of the kernel whose mangled name contains `symbol`, from the newest committed PMC summary
+    (profiles/r*_pmc.json: separate rocprofv3 --pmc passes of this same command, tools/profile_step.sh +
+    tools/pmc_summary.py): L2-miss (fabric) bytes per launch and MFMA utilisation"""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not paths:
+        return {}
     try:
-        with open(path) as f:
+        with open(paths[-1]) as f:
             tab = json.load(f).get("kernels", {})
-        hit = [v for k, v in tab.items() if symbol in k]
-        return round(hit[0]["hbm_bytes_per_launch"]) if hit else None
+        hit = [v for k, v in tab.items() if k in symbol or symbol in k]
+        return dict(hit[0], source=os.path.basename(paths[-1])) if hit else {}
     except (OSError, ValueError, KeyError):
-        return None
+        return {}
 
 
 def hub_stub():
@@ -61,34 +66,58 @@ def build(arch, device):
     return model.train()
 
 
-def cpu_baseline(arch, size, budget_s, threads):
-    """the oracle's train_step on B=2 tile pairs of the same architecture, timed on the host cores"""
-    from oracle import msfwsi_oracle as orc
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
-    torch.set_num_threads(threads)
-    hub_stub()
-    torch.manual_seed(3407)
+
+def _oracle_steps(arch, B, size, n_timed, budget_s):
+    """1 warm-up + up to n_timed timed steps of the oracle's train_step (fp32) on B tile pairs; returns (pairs/s, n)"""
+    from oracle import msfwsi_oracle as orc
     from msf_wsi_amd.models import resnet as R
     from msf_wsi_amd.models.backbone import MSFWSI
 
+    hub_stub()
+    torch.manual_seed(3407)
     model = MSFWSI(R.__dict__[arch], 4)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     del model
-    B = 2
     batch = orc.synthetic_batch(B, size, 16, 0)
     lr = orc.init_lr(1e-3, B)
     opt = orc.Adam(sd, [lr, lr, lr])
     orc.train_step(sd, batch, opt)  # warm-up (allocator, oneDNN primitive caches)
     n, t0 = 0, time.time()
-    while True:
+    while n < n_timed:
         orc.train_step(sd, batch, opt)
         n += 1
-        if time.time() - t0 > budget_s or n >= 5:
+        if time.time() - t0 > budget_s:
             break
-    dt = time.time() - t0
-    return {"value": round(B * n / dt, 4), "unit": "tile-pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{n} step(s) of the oracle (port of the reference step) on {B} tile pairs, {arch}, fp32, "
-                      f"{size}x{size}, after 1 warm-up step"}
+    return B * n / (time.time() - t0), n
+
+
+def cpu_baseline(arch, size, budget_s, threads):
+    """SURVEY.md 8(d) / BASELINE.md 3: the oracle (a port of the reference step, verified against the real reference)
+    on BASELINE config 1 EXACTLY -- ResNet-18 dual-stream, 8 tile pairs of 224x224, fp32 -- 1 warm-up + 3 timed steps
+    on the host's physical cores.  `extra` carries one step of the bench's own architecture at 2 tile pairs, labelled."""
+    torch.set_num_threads(threads)
+    val, n = _oracle_steps("resnet18", 8, 224, 3, max(budget_s, 60.0))
+    out = {"value": round(val, 4), "unit": "tile-pairs/s", "cores": threads, "kind": "port",
+           "sample": f"{n} timed step(s) after 1 warm-up of the oracle (port of the reference step) on BASELINE config 1: "
+                     f"resnet18, 8 tile pairs of 224x224, fp32",
+           "cpu_model": _cpu_model(), "torch": torch.__version__,
+           "blas": "mkl" if torch.backends.mkl.is_available() else "other"}
+    if arch != "resnet18":
+        v2, n2 = _oracle_steps(arch, 2, size, 1, budget_s)
+        out["extra"] = {"value": round(v2, 4), "unit": "tile-pairs/s",
+                        "sample": f"{n2} step of the oracle on 2 tile pairs of {arch} ({size}x{size}, fp32): the bench "
+                                  f"architecture at a CPU-sized batch, not the metric's configuration"}
+    return out
 
 
 def launch_ranks(n):
@@ -241,12 +270,16 @@ def main():
             gbs = s["bytes"] / s["seconds"] / 1e9
             frac_m, frac_h = tf / PEAK_TFLOPS[args.dtype], gbs / PEAK_HBM_GBS
             bound = "mfma" if frac_m >= frac_h else "hbm"
+            pmc = pmc_entry(dom)
             out["roofline"] = {
                 "kernel": dom, "family": s["family"], "bound": bound,
                 "achieved": round(tf if bound == "mfma" else gbs, 2),
                 "peak": PEAK_TFLOPS[args.dtype] if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                "frac": round(max(frac_m, frac_h), 4), "traffic": pmc_traffic(dom),
+                "frac": round(max(frac_m, frac_h), 4),
+                "traffic": round(pmc.get("hbm_bytes_per_launch")) if pmc.get("hbm_bytes_per_launch") else None,
+                "mfma_util": round(pmc["mfma_util"], 4) if pmc.get("mfma_util") is not None else None,
+                "pmc_source": pmc.get("source"),
                 "launches": s["launches"], "avg_launch_ms": round(1e3 * s["seconds"] / s["launches"], 4),
                 "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                 "alt": {"TFLOP/s": round(tf, 2), "frac_mfma": round(frac_m, 4), "GB/s": round(gbs, 1),
