@@ -541,8 +541,9 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int nsha
     }
     const double mu = mean[c], is = invstd[c];
     const double dot = is * (s2 - mu * s1);  // sum g * xhat
-    if (dgamma != nullptr) dgamma[c] += (float)dot;
-    if (dbeta != nullptr) dbeta[c] += (float)s1;
+    // atomics: the two views of an encoder run their backward passes on two streams and share these accumulators
+    if (dgamma != nullptr) atomicAdd(dgamma + c, (float)dot);
+    if (dbeta != nullptr) atomicAdd(dbeta + c, (float)s1);
     const double a = (gamma != nullptr ? (double)gamma[c] : 1.0) * is;
     const double m1 = s1 / count, m2 = dot / count;
     k1[c] = (float)a;
@@ -786,7 +787,7 @@ __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __
     for (int k = kb; k < ke; ++k) {
         const long o = (long)k * C + c;
         const float w = W[o], a = k1[k], b = k2[k], d = k3[k];
-        dW[o] += fmaf(a, Mm[o], fmaf(b, WA[o], d * s));
+        atomicAdd(dW + o, fmaf(a, Mm[o], fmaf(b, WA[o], d * s)));  // shared with the other view's stream
         Wk1[o] = a * w;
         Wk2[o] = b * w;
         bacc = fmaf(d, w, bacc);
@@ -796,7 +797,7 @@ __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __
 
 __global__ void add_f64_to_f32_kernel(const double* __restrict__ in, float* out, int n, float alpha) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] += alpha * (float)in[i];
+    if (i < n) atomicAdd(out + i, alpha * (float)in[i]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -159,7 +159,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
             }
         }
     }
-    __syncthreads();
+    // (the barrier that completes the tile follows the operand prefetch below)
 
     // ---------------- row-chunk pass: coalesced 16-byte stores + per-channel statistics ----------------
     constexpr int CPR = BN / VEC;        // chunks per tile row
@@ -196,8 +196,56 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
         }
     }
 
-#pragma unroll 2
-    for (int pass = 0; pass < BM / RPP; ++pass) {
+    // Every epilogue operand that comes from global memory (residual / identity, the gate's activation, gate bits) is
+    // requested for ALL row passes up front: a short-k 1x1 tile (4-8 slabs) otherwise spends more time in its NP
+    // serialised load latencies here than in its k loop (measured 3.0-3.5 TB/s on those layers).  The accumulators are
+    // dead by now, so the registers are free -- up to the 128 that four waves per SIMD allow: the class that can carry
+    // two operands per pass (residual AND gate activation) prefetches in groups of four passes.
+    constexpr int NP = BM / RPP;
+    constexpr int GP = !STD ? NP : (NW == 4 && BN == 128 ? 2 : (NP > 4 ? 4 : NP));  // 128x128 / 4 waves: 64 AGPRs stay allocated
+    static_assert(NP % GP == 0, "row passes must split into whole prefetch groups");
+    const int Pl = LORES ? (prm.P - 1) / prm.resid_stride + 1 : 0, Ql = LORES ? (prm.Q - 1) / prm.resid_stride + 1 : 0;
+#pragma unroll 1  // a real loop: unrolled, the scheduler hoists every group's loads to the top (130 VGPRs, 3 waves/SIMD)
+    for (int grp = 0; grp < NP / GP; ++grp) {
+    uint4 r_res[GP], r_msk[GP];
+    unsigned r_bits[GP];
+    bool r_has[GP];
+#pragma unroll
+    for (int pi = 0; pi < GP; ++pi) {
+        const int pass = grp * GP + pi;
+        const int m = m0 + rr + pass * RPP;
+        const bool ok = m < prm.M && col_ok;
+        r_has[pi] = false;
+        r_bits[pi] = 0;
+        if (ok) {
+            const long off = (long)m * prm.Nout + ncol;
+            if (resid != nullptr) {
+                if constexpr (LORES) {
+                    // pixel m = (n, h, w) of the [N][P][Q] output; the residual lives on the s-strided sub-grid
+                    const int sr = prm.resid_stride;
+                    const unsigned n = fast_div((unsigned)m, prm.div_pq);
+                    const unsigned rem = (unsigned)m - n * (unsigned)PQ;
+                    const unsigned h = fast_div(rem, prm.div_q);
+                    const unsigned w = rem - h * (unsigned)prm.Q;
+                    if (h % sr == 0 && w % sr == 0) {
+                        const long lo = (((long)n * Pl + h / sr) * Ql + w / sr) * prm.Nout + ncol;
+                        r_res[pi] = *reinterpret_cast<const uint4*>(resid + lo);
+                        r_has[pi] = true;
+                    }
+                } else {
+                    r_res[pi] = *reinterpret_cast<const uint4*>(resid + off);
+                    r_has[pi] = true;
+                }
+            }
+            if (mask_c != nullptr) r_msk[pi] = *reinterpret_cast<const uint4*>(mask_c + off);
+            else if (mask_bits != nullptr) r_bits[pi] = mask_bits[(long)m * (prm.Nout / VEC) + (ncol / VEC)];
+        }
+    }
+    if (grp == 0) __syncthreads();  // the transposed tile is complete in LDS
+
+#pragma unroll
+    for (int pi = 0; pi < GP; ++pi) {
+        const int pass = grp * GP + pi;
         const int row = rr + pass * RPP;
         const int m = m0 + row;
         if (m < prm.M && col_ok) {
@@ -211,28 +259,11 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] = fmaf(f[e], psc[e], psh[e]);
                 }
-                if (resid != nullptr) {
-                    if constexpr (LORES) {
-                        // pixel m = (n, h, w) of the [N][P][Q] output; the residual lives on the s-strided sub-grid
-                        const int sr = prm.resid_stride;
-                        const unsigned n = fast_div((unsigned)m, prm.div_pq);
-                        const unsigned rem = (unsigned)m - n * (unsigned)PQ;
-                        const unsigned h = fast_div(rem, prm.div_q);
-                        const unsigned w = rem - h * (unsigned)prm.Q;
-                        if (h % sr == 0 && w % sr == 0) {
-                            const int Pl = (prm.P - 1) / sr + 1, Ql = (prm.Q - 1) / sr + 1;
-                            const long lo = (((long)n * Pl + h / sr) * Ql + w / sr) * prm.Nout + ncol;
-                            float g[VEC];
-                            unpack16<T>(*reinterpret_cast<const uint4*>(resid + lo), g);
+                if (r_has[pi]) {
+                    float g[VEC];
+                    unpack16<T>(r_res[pi], g);
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) f[e] += g[e];
-                        }
-                    } else {
-                        float g[VEC];
-                        unpack16<T>(*reinterpret_cast<const uint4*>(resid + off), g);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) f[e] += g[e];
-                    }
+                    for (int e = 0; e < VEC; ++e) f[e] += g[e];
                 }
                 if (gapg != nullptr) {
                     float gp[VEC];
@@ -258,7 +289,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 // fused backward of the producer's relu(bn(c)): gate, then accumulate {sum g, sum g*c}
                 float f[VEC], cv[VEC];
                 unpack16<T>(v, f);
-                unpack16<T>(*reinterpret_cast<const uint4*>(mask_c + off), cv);
+                unpack16<T>(r_msk[pi], cv);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     if (!(fmaf(cv[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
@@ -270,7 +301,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
             } else if (mask_bits != nullptr) {
                 float f[VEC];
                 unpack16<T>(v, f);
-                const unsigned b = mask_bits[(long)m * (prm.Nout / VEC) + (ncol / VEC)];
+                const unsigned b = r_bits[pi];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     if (!((b >> e) & 1u)) f[e] = 0.f;
@@ -292,6 +323,8 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
             }
         }
     }
+
+    }  // prefetch group
 
     if (stats != nullptr) {
 #pragma unroll

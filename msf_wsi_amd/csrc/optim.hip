@@ -203,7 +203,7 @@ __global__ void unpad_add_kernel(const float* __restrict__ src, float* __restric
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / C;
         const int c = (int)(i - r * C);
-        dst[i] += src[r * CP + c];
+        atomicAdd(dst + i, src[r * CP + c]);  // the other view's stream adds into the same gradient
     }
 }
 

@@ -99,6 +99,7 @@ class StepRec:
     heads: Dict[Tuple[str, int, int], Tuple[ChainRec, ChainRec]] = field(default_factory=dict)
     tgt_sorted: Dict[Tuple[int, int], torch.Tensor] = field(default_factory=dict)
     nosave: set = field(default_factory=set)
+    dual: bool = False  # view-1 passes ran on the side stream (their activations live in that stream's pool)
 
 
 def chan_pad(dtype: torch.dtype) -> int:
@@ -225,6 +226,14 @@ class Engine:
         # rehearsal switch: run the cross-replica code path (collectives included) even with one rank, so that the
         # RCCL calls of the SyncBatchNorm exchange execute on a one-GPU box
         self.force_sync = os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0"
+        # The two views of an encoder are independent passes (separate BatchNorm batches, backbone.py:140-145): view 1
+        # runs on a second HIP stream beside view 0, forward and backward.  The passes are offset in time, so the
+        # chip usually holds an MFMA-bound kernel of one beside an HBM-bound kernel of the other, and tails / launch
+        # gaps of one are filled by the other.  Per BatchNorm module the running-statistics update of view 1 waits for
+        # the one of view 0 (an event), which keeps the reference's update order.
+        self.dual_stream = os.environ.get("MSFWSI_DUAL_STREAM", "0") != "0"
+        self._side: Dict[str, torch.cuda.Stream] = {}
+        self._bn_order: Optional[Tuple[str, dict]] = None
 
     def invalidate_weights(self):
         """Every derived copy of the parameters (16-bit / channel-padded casts, the stem's filter-row runs) is keyed on
@@ -252,11 +261,33 @@ class Engine:
             return dist.get_world_size(self.group)
         return 1
 
+    def _side_stream(self, dev) -> "torch.cuda.Stream":
+        key = str(dev)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
+    def _prewarm(self, encoders, dtype, dev):
+        """derived weight copies and small constants that passes on BOTH streams read are made here, on the calling
+        stream, before the second stream is released (a lazily filled cache would be written by one stream while the
+        other already reads it)"""
+        for enc in encoders:
+            for m in enc.modules():
+                if isinstance(m, (nn.Conv2d, nn.Linear)):
+                    if m is getattr(enc, "conv1", None):
+                        CP = chan_pad(dtype)
+                        if self.stem_run:
+                            self._stem_run_weights(m, dtype, CP)
+                        self.weights.get(m.weight, dtype, pad_to=CP)
+                    else:
+                        self.weights.get(m.weight, dtype)
+                        self._unit_gate(m.weight.shape[0], dev)
+
     def _msg_buf(self, kind: str, n: int, dev) -> torch.Tensor:
         """pre-allocated fp64 message buffer of the cross-replica BatchNorm exchange, one per (direction, length).
         Re-use is safe: the blocking all-reduce makes the launch stream wait for the collective, and the consumer
         (bn_finalize / bn_bwd_finalize) precedes the next producer (shard_sum) in stream order."""
-        key = (kind, n, str(dev))
+        key = (kind, n, str(dev), torch.cuda.current_stream(dev).cuda_stream)
         buf = self._msgs.get(key)
         if buf is None:
             buf = self._msgs[key] = torch.empty(n, dtype=torch.float64, device=dev)
@@ -299,9 +330,18 @@ class Engine:
         if bn.momentum is None:
             raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not used by MSF-WSI")
         track = self.update_running and bn.track_running_stats and bn.training
+        order = self._bn_order if track else None
+        if order is not None and order[0] == "follow":
+            ev = order[1].get(id(bn))
+            if ev is not None:  # view 0's update of this module's running statistics comes first (reference order)
+                torch.cuda.current_stream(dev).wait_event(ev)
         kn.bn_finalize(stats, total, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
                        bn.momentum, bn.running_mean if track else None, bn.running_var if track else None,
                        bn.num_batches_tracked if track else None, vecs[0], vecs[1], vecs[2], vecs[3])
+        if order is not None and order[0] == "lead":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            order[1][id(bn)] = ev
         return BNState(vecs[0], vecs[1], vecs[2], vecs[3], total)
 
     def _bn_bwd_coeffs(self, sums: torch.Tensor, nslots: int, which: int, bn: nn.Module, st: BNState,
@@ -370,8 +410,13 @@ class Engine:
         return u
 
     def _stem_run_fwd(self, op: nn.Module, x: torch.Tensor, c: torch.Tensor, stats, dtype, CP: int) -> bool:
+        """the stem conv as filter-row runs; False when the library has no run kernel for the shape"""
+        R, S = op.kernel_size
+        return kn.stem_conv_fwd(x, self._stem_run_weights(op, dtype, CP), c, stats, R, S, op.stride[0], op.padding[0])
+
+    def _stem_run_weights(self, op: nn.Module, dtype, CP: int) -> torch.Tensor:
         """stem weights [K][R][S][CP] -> [K][R][run] (zero columns pad the S*CP run to whole k slabs), cached per
-        parameter version; False when the library has no run kernel for the shape"""
+        parameter version"""
         K, R, S = op.out_channels, op.kernel_size[0], op.kernel_size[1]
         bk = 16 if dtype == torch.float32 else 32
         run = (S * CP + bk - 1) // bk * bk
@@ -387,7 +432,7 @@ class Engine:
             kn.pad_cast(wp, w_run, K * R, S * CP, run)         # filter row -> whole k slabs, storage type
             hit = (ver, w_run)
             self._stem_cache[key] = hit
-        return kn.stem_conv_fwd(x, hit[1], c, stats, R, S, op.stride[0], op.padding[0])
+        return hit[1]
 
     def _gram_stats(self, w: torch.Tensor, A: torch.Tensor, sa: torch.Tensor, bn: nn.Module, count: int, dtype) -> BNState:
         """BatchNorm batch statistics of c = W a (1x1 conv) from the Gram matrix A = a^T a and the column sums of a:
@@ -917,6 +962,7 @@ class Engine:
         if key not in self._gate_vecs:
             self._gate_vecs[key] = (torch.ones(Cn, dtype=torch.float32, device=dev),
                                     torch.zeros(Cn, dtype=torch.float32, device=dev))
+            torch.cuda.current_stream(dev).synchronize()  # first use only: both streams may read them from now on
         return self._gate_vecs[key]
 
     def _block_bwd_tail(self, rec: BlockRec, cur, top: int, resid, grads: GradStore, dtype, last_xmat=None,
@@ -1076,7 +1122,15 @@ class Engine:
             rec.idx.append(idx.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous())
         # reference call order (backbone.py:140-145): separate BatchNorm batches per call
         self._drop_c3 = False  # the first (small) context pass keeps everything and calibrates the planner
+        dual = self.dual_stream
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if dual else None
+        ev_c, ev_t = {}, {}
+        if dual:
+            self._prewarm((model.context_encoder, model.target_encoder), dtype, dev)
+            side.wait_stream(main)  # inputs, weights, the zero arena: everything enqueued so far
         m0 = torch.cuda.memory_allocated(dev)
+        self._bn_order = ("lead", ev_c) if dual else None
         rec.enc["c0"] = self.encoder_forward(model.context_encoder, x1[0], dtype)
         per_image = (torch.cuda.memory_allocated(dev) - m0) / max(1, B)
         c3_bytes = sum(b.units[-1].c.numel() * b.units[-1].c.element_size() for b in rec.enc["c0"].blocks
@@ -1086,9 +1140,29 @@ class Engine:
         if not need_backward:
             rec.enc["c0"] = EncPass(model.context_encoder, B, 0, 0, None, None, None, None, [], rec.enc["c0"].feats,
                                     saved=False)
-        rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
-        rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
-        rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype, save="t1" not in nosave)
+        if not dual:
+            rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
+            rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
+            rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype, save="t1" not in nosave)
+        else:
+            try:
+                for t in (x2[0], x2[1]):
+                    t.record_stream(side)
+                with torch.cuda.stream(side):
+                    self._bn_order = ("follow", ev_c)
+                    rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
+                self._bn_order = ("lead", ev_t)
+                rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
+                with torch.cuda.stream(side):
+                    self._bn_order = ("follow", ev_t)
+                    rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype, save="t1" not in nosave)
+            finally:
+                self._bn_order = None
+            main.wait_stream(side)
+            for name in ("c1", "t1"):  # allocated in the side stream's pool, read by the heads on this one
+                for f in rec.enc[name].feats:
+                    f.record_stream(main)
+        rec.dual = dual
         rec.nosave = nosave
         outs = {}
         for grp in ("context", "target", "inter"):
@@ -1156,12 +1230,35 @@ class Engine:
                 on_group_done("inter")
         # saved passes first (frees their activations), then the features-only ones are re-materialised
         order = sorted((("t0", dtf[0]), ("t1", dtf[1])), key=lambda nd: not rec.enc[nd[0]].saved)
+        # view 1 on the side stream again (its activations live in that stream's pool); both views add into the same
+        # gradient accumulators -- every such add is an atomic -- which must exist before either stream starts
+        dual = rec.dual and getattr(grads, "preallocated", False)
+        dev = dtf[0][0].device
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if dual else None
+
+        def run(name, df):
+            if dual and name.endswith("1"):
+                for d in df:
+                    if d is not None:
+                        d.record_stream(side)
+                with torch.cuda.stream(side):
+                    self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
+            else:
+                self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
+
+        if dual:
+            side.wait_stream(main)  # the heads' backward produced the feature gradients
         for name, df in order:
-            self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
+            run(name, df)
+        if dual:
+            main.wait_stream(side)
         if on_group_done is not None:
             on_group_done("target")
         for name, df in (("c1", dcf[1]), ("c0", dcf[0])):
-            self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
+            run(name, df)
+        if dual:
+            main.wait_stream(side)
         if on_group_done is not None:
             on_group_done("context")
 

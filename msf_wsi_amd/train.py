@@ -32,6 +32,8 @@ FUSER_WEIGHTS = (0.1, 0.4, 0.7, 1.0)  # tools/ssl_train.py:623-625
 class _FlatGradStore(GradStore):
     """gradient accumulators that live inside the flat per-group buffers"""
 
+    preallocated = True  # every accumulator exists (and is zeroed) before the backward starts: two streams may add
+
     def __init__(self, flats: FlatGroups):
         super().__init__()
         self.flats = flats

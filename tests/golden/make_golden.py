@@ -310,6 +310,19 @@ def run_encoder_case(name="r50enc_b4_s64", arch="resnet50", B=4, size=64):
     for n, gr in grads.items():
         assert rel(osd["e." + n].grad, gr) < 1e-9, n
     vec = {"loss": np.array([float(loss)])}
+    # the reference's own fp32 run of the same trunk: its distance from the fp64 run is the parity noise floor
+    torch.manual_seed(MODEL_SEED)
+    ref32 = ref_resnet.__dict__[arch](zero_init_residual=False, return_features=True)
+    ref32.fc = torch.nn.Identity()
+    ref32.load_state_dict({k: v for k, v in sd0.items()}, strict=False)
+    ref32.train()
+    f32 = ref32(x)
+    sum((f * r).sum() for f, r in zip(f32, Rs)).backward()
+    g32 = {n: p.grad.detach() for n, p in ref32.named_parameters() if not n.startswith("fc.")}
+    vec["spread_grad"] = np.array([rel(g32[n], grads[n]) for n in grads])
+    vec["spread_feat"] = np.array([rel(a, b) for a, b in zip(f32, feats)])
+    print(f"[{name}] reference fp32<->fp64: features {vec['spread_feat'].max():.2e}, gradients median "
+          f"{np.median(vec['spread_grad']):.2e} max {vec['spread_grad'].max():.2e}")
     for s, f in enumerate(feats):
         vec[f"feat/{s}"] = f.detach().float().numpy()
     vec["grad_norm"] = np.array([float(g_.norm()) for g_ in grads.values()])

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import MODEL_SEED, load_golden, rel
+from helpers import MODEL_SEED, load_golden, rel, spread_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -32,12 +32,13 @@ def test_resnet50_trunk_matches_reference(hip_lib):
     named = dict(enc.named_parameters())
     norms = np.array([float(named[k].grad.double().norm()) for k in man["param_keys"]])
     rn = np.abs(norms - vec["grad_norm"]) / (vec["grad_norm"] + 1e-30)
-    # same statistical gate as the whole-step test (ReLU gate flips at the fp32 noise floor)
-    assert np.median(rn) < 1e-3 and rn.max() < 5e-2, (float(np.median(rn)), float(rn.max()))
+    # the gate of the whole-step tests (helpers.spread_gate): per tensor max(1e-3, 2 x the REFERENCE's own fp32<->fp64
+    # spread), here on the gradient norms (a norm moves at most as much as the tensor, so the tensor spread bounds it)
+    spread_gate(rn, man["param_keys"], [vec["spread_grad"]], "resnet50 trunk: gradient norms vs the fp64 reference")
+    idx = {k: i for i, k in enumerate(man["param_keys"])}
     for k in ("conv1.weight", "layer1.0.downsample.1.weight", "layer2.0.bn2.bias", "layer4.2.bn3.weight"):
         if f"grad/{k}" in vec:
-            # B=4 at 64x64 (BatchNorm over 16..1024 samples) sits at 1.6e-2..1.9e-2 from gate flips alone
-            assert rel(named[k].grad, vec[f"grad/{k}"]) < 5e-2, k
+            assert rel(named[k].grad, vec[f"grad/{k}"]) <= max(1e-3, 2 * float(vec["spread_grad"].max())), k
     rv = enc.state_dict()["layer3.0.downsample.1.running_var"].cpu().numpy()
     assert np.allclose(rv, vec["bn/layer3.0.downsample.1/running_var"], rtol=1e-3, atol=1e-6)
 
