@@ -273,6 +273,23 @@ int msfwsi_upcast_f32(int dtype, const void* src, float* dst, long n, void* stre
 int msfwsi_zero_f64_2d(double* p, long rows, int cols, long ld, void* stream);
 int msfwsi_unpad_add(const float* src, float* dst, long rows, int C, int CP, void* stream);
 
+/* ---- validation metrics (row f4 of SURVEY.md 8f) -------------------------------------------------------------------
+ * Per-image, per-class confusion counts of a multiclass segmentation, and the scores the reference logs.
+ * Replaces: torch.argmax(preds, dim=1) + smp.metrics.get_stats(pred - 1, target - 1, mode="multiclass",
+ * ignore_index=-1, num_classes=C) (tools/ssl_finetune.py:526-533, tools/evaluate.py:285-305) and smp.metrics.f1_score /
+ * iou_score / accuracy with reduction "micro" and None (:535-551).  segmentation_models_pytorch (>= 0.3.2) is a
+ * third-party dependency outside the reference tree: its published algorithm is restated, parity unpinned.
+ * Either `logits` [N][nch][L] (storage dtype; pred = argmax over nch, first maximum) or `pred` [N][L] int64 is given;
+ * pred_shift / target_shift are added first (the reference's "- 1"); counts [N][4][C] uint64 scratch, ZEROED by the
+ * caller; tp/fp/fn/tn [N][C] int64 outputs.  Classes <= 64. */
+int msfwsi_seg_stats(int logits_dtype, const void* logits, int nch, const long* pred, const long* target, int N, long L,
+                     int C, long pred_shift, long target_shift, long ignore_index, int has_ignore,
+                     unsigned long long* counts, long* tp, long* fp, long* fn, long* tn, void* stream);
+/* scores[0..2] = micro F1, IoU, accuracy over all images and classes; scores[3+c], [3+C+c], [3+2C+c] = per-class F1, IoU,
+ * accuracy on the counts summed over images; 0/0 -> zero_division (smp default 1.0).  scores: 3 + 3*C doubles. */
+int msfwsi_seg_scores(const long* tp, const long* fp, const long* fn, const long* tn, int N, int C, double zero_division,
+                      double* scores, void* stream);
+
 /* performance knobs (never change results): key 0 = minimum grid (in 256x128 tiles) from which the conv
  * kernels switch from the 128x128 / 4-wave tile to the 256x128 / 8-wave tile; key 1 = 0 disables the pure-DMA
  * (buffer_load ... lds) conv kernel, key 2 = 0 the linear-addressing weight-gradient path, key 4 = grid size (in

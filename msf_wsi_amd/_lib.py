@@ -73,6 +73,8 @@ SIGNATURES = {
     "msfwsi_unpad_add": [_vp, _vp, _l, _i, _i, _vp],
     "msfwsi_upcast_f32": [_i, _vp, _vp, _l, _vp],
     "msfwsi_zero_f64_2d": [_vp, _l, _i, _l, _vp],
+    "msfwsi_seg_stats": [_i, _vp, _i, _vp, _vp, _i, _l, _i, _l, _l, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "msfwsi_seg_scores": [_vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp],
     "msfwsi_set_tuning": [_i, _l],
     "msfwsi_conv3x3_supported": [_desc],
     "msfwsi_conv3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _i, _vp],

@@ -1115,6 +1115,8 @@ class Engine:
         if jigsaw_idx is None or len(jigsaw_idx) != 2:
             raise ValueError("jigsaw_idx must be the two [B,K] index tensors")
         dev = x1[0].device
+        if dev.type != "cuda":
+            raise _lib.MsfwsiHipError("the MSF-WSI model runs only on a HIP device (no CPU path)")
         rec = StepRec(B)
         for v, idx in enumerate(jigsaw_idx):
             # the only in-path assertion of the reference (backbone.py:152)

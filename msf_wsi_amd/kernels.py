@@ -919,3 +919,43 @@ def conv3x3_dgrad(d: ConvDesc, dy, w, dx, resid=None, mask=None, sums=None):
         extra_elems=(dx.numel() if resid is not None else 0) + (dx.numel() if mask is not None else 0), halo=True,
         dtype=dy.dtype)
     return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# validation metrics (csrc/metrics.hip)
+# ------------------------------------------------------------------------------------------------
+def seg_stats(logits, pred, target, num_classes: int, pred_shift: int, target_shift: int, ignore_index):
+    """tp, fp, fn, tn [N, C] int64 of a multiclass segmentation; `logits` [N, nch, ...] (argmax inside) or `pred` [N, ...]"""
+    lib = _lib.load()
+    N = target.shape[0]
+    L = target.numel() // N
+    _req(target, "target", torch.int64)
+    nch, ldt = 0, 0
+    if logits is not None:
+        _req(logits, "logits")
+        nch = logits.shape[1]
+        ldt = dt_of(logits)
+        if logits.shape[0] != N or logits.numel() != N * nch * L:
+            raise ValueError(f"logits {tuple(logits.shape)} do not match target {tuple(target.shape)}")
+    else:
+        _req(pred, "pred", torch.int64, N * L)
+    dev = target.device
+    counts = torch.zeros(N, 4, num_classes, dtype=torch.int64, device=dev)
+    outs = [torch.empty(N, num_classes, dtype=torch.int64, device=dev) for _ in range(4)]
+    _lib.check(lib.msfwsi_seg_stats(ldt, _p(logits), nch, _p(pred), _p(target), N, L, int(num_classes), int(pred_shift),
+                                    int(target_shift), int(ignore_index) if ignore_index is not None else 0,
+                                    int(ignore_index is not None), _p(counts), *[_p(o) for o in outs], _stream()),
+               "seg_stats")
+    return tuple(outs)
+
+
+def seg_scores(tp, fp, fn, tn, zero_division: float = 1.0):
+    """fp64 [3 + 3C]: micro F1 / IoU / accuracy, then per-class F1, IoU, accuracy on the counts summed over images"""
+    lib = _lib.load()
+    N, Cn = tp.shape
+    for nm, t in (("tp", tp), ("fp", fp), ("fn", fn), ("tn", tn)):
+        _req(t, nm, torch.int64, N * Cn)
+    out = torch.empty(3 + 3 * Cn, dtype=torch.float64, device=tp.device)
+    _lib.check(lib.msfwsi_seg_scores(_p(tp), _p(fp), _p(fn), _p(tn), N, Cn, float(zero_division), _p(out), _stream()),
+               "seg_scores")
+    return out
