@@ -290,6 +290,21 @@ int msfwsi_seg_stats(int logits_dtype, const void* logits, int nch, const long* 
 int msfwsi_seg_scores(const long* tp, const long* fp, const long* fn, const long* tn, int N, int C, double zero_division,
                       double* scores, void* stream);
 
+/* ---- tiling / normalising front end (row f3 of SURVEY.md 8f) --------------------------------------------------------
+ * out[b][k] (fp32 [3][S][S]) = Normalize(HFlip?(resize_bilinear(crop(block perm[b][k] of img[b], box[b][k]), S x S)))
+ * for the grid x grid blocks of an H x W x 3 uint8 tile; grid = 1 treats the whole tile as one block (context view).
+ * Replaces the per-sample CPU work of BcssPretrainDataset.__getitem__ after the colour augmentations:
+ * blockshaped (src/utils/data/bcss.py:203-216), target_grid[jigsaw_idx] (:176), RandomResizedCrop + HorizontalFlip +
+ * Normalize + ToTensorV2 (tools/ssl_train.py:176-214) with the random decisions (boxes [B][K][4] = x0,y0,w,h inside the
+ * block; flips [B][K]; perm [B][K]) supplied by the caller.  Bilinear resize in fp32 with cv2's half-pixel convention,
+ * rounded to uint8 levels (cv2's fixed-point arithmetic is not reproduced: resize parity unpinned; a box of exactly
+ * S x S is an exact copy).  perm / flips may be NULL. */
+int msfwsi_tile_views(const unsigned char* img, int B, int H, int W, int grid, const long* perm, const int* boxes,
+                      const unsigned char* flips, const float* mean, const float* std_, float max_pixel, int S,
+                      float* out, void* stream);
+/* inv[r][perm[r][k]] = k: jigsaw_reverse_idx = argsort(jigsaw_idx) (src/utils/data/bcss.py:172) */
+int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* stream);
+
 /* performance knobs (never change results): key 0 = minimum grid (in 256x128 tiles) from which the conv
  * kernels switch from the 128x128 / 4-wave tile to the 256x128 / 8-wave tile; key 1 = 0 disables the pure-DMA
  * (buffer_load ... lds) conv kernel, key 2 = 0 the linear-addressing weight-gradient path, key 4 = grid size (in

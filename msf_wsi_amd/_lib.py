@@ -75,6 +75,8 @@ SIGNATURES = {
     "msfwsi_zero_f64_2d": [_vp, _l, _i, _l, _vp],
     "msfwsi_seg_stats": [_i, _vp, _i, _vp, _vp, _i, _l, _i, _l, _l, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "msfwsi_seg_scores": [_vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp],
+    "msfwsi_tile_views": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp],
+    "msfwsi_inverse_perm": [_vp, _vp, _l, _i, _vp],
     "msfwsi_set_tuning": [_i, _l],
     "msfwsi_conv3x3_supported": [_desc],
     "msfwsi_conv3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _i, _vp],

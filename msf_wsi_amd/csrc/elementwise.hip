@@ -29,7 +29,9 @@ inline ColGrid make_col_grid(long M, int C, int vec, int target_blocks) {
     long rowblocks = target_blocks / colblocks;
     if (rowblocks < 1) rowblocks = 1;
     long rpb = (M + rowblocks - 1) / rowblocks;
-    if (rpb < g.nrl) rpb = g.nrl;
+    // every row lane sums at least 16 rows before its block's fp64 atomics: the heads' tensors (256 .. 4096 rows, up
+    // to 18432 columns) were cut into 2-row blocks whose 8 M atomics took 100 us per launch (95 GB/s)
+    if (rpb < 16L * g.nrl) rpb = 16L * g.nrl;
     rowblocks = (M + rpb - 1) / rpb;
     if (rowblocks > 65535) {
         rowblocks = 65535;

@@ -222,6 +222,7 @@ class Engine:
         self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
         self._plan_cache: Dict[tuple, Tuple[frozenset, bool]] = {}
+        self._mode_override: Optional[str] = None  # "targets" while a model built with use_checkpoint=True runs
         self._msgs: Dict[tuple, torch.Tensor] = {}
         # rehearsal switch: run the cross-replica code path (collectives included) even with one rank, so that the
         # RCCL calls of the SyncBatchNorm exchange execute on a one-GPU box
@@ -694,7 +695,7 @@ class Engine:
         (one all-reduce(MAX) of a plan code), once per (batch, model) shape -- the result is cached."""
         nosave, drop = self._plan_local(per_image_bytes, B, K, device, c3_fraction)
         if self._world() > 1:
-            key = (B, K, int(per_image_bytes), self.recompute, self.fold_bn3)
+            key = (B, K, int(per_image_bytes), self._mode_override or self.recompute, self.fold_bn3)
             hit = self._plan_cache.get(key)
             if hit is None:
                 code = torch.tensor([2 * len(nosave) + int(drop)], dtype=torch.int32, device=device)
@@ -708,7 +709,7 @@ class Engine:
 
     def _plan_local(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float):
         """this rank's own (features-only passes, drop conv3 outputs) choice"""
-        mode = getattr(self, "recompute", "off")
+        mode = self._mode_override or getattr(self, "recompute", "off")
         if self.fold_bn3 and c3_fraction > 0:  # conv3 outputs are never kept on the folded path
             per_image_bytes *= 1.0 - c3_fraction
             c3_fraction = 0.0
@@ -1138,6 +1139,9 @@ class Engine:
         c3_bytes = sum(b.units[-1].c.numel() * b.units[-1].c.element_size() for b in rec.enc["c0"].blocks
                        if len(b.units) == 3 and b.units[-1].c is not None)
         c3_frac = (c3_bytes / max(1, B)) / per_image if per_image > 0 else 0.0
+        # MSFWSI(..., use_checkpoint=True) (the reference's --use-ac, backbone.py:103-127): trade compute for activation
+        # memory -- here: both target passes (16/17 of the images) run features-only and are re-run before their backward
+        self._mode_override = "targets" if getattr(model, "use_checkpoint", False) else None
         nosave = self._plan_recompute(per_image, B, K, dev, c3_frac) if need_backward else {"c1", "t0", "t1"}
         if not need_backward:
             rec.enc["c0"] = EncPass(model.context_encoder, B, 0, 0, None, None, None, None, [], rec.enc["c0"].feats,

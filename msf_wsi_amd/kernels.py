@@ -959,3 +959,42 @@ def seg_scores(tp, fp, fn, tn, zero_division: float = 1.0):
     _lib.check(lib.msfwsi_seg_scores(_p(tp), _p(fp), _p(fn), _p(tn), N, Cn, float(zero_division), _p(out), _stream()),
                "seg_scores")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# tiling / normalising front end (csrc/tiler.hip)
+# ------------------------------------------------------------------------------------------------
+def tile_views(img, grid: int, perm, boxes, flips, mean, std, size: int = 224, max_pixel: float = 255.0):
+    """img uint8 [B,H,W,3] -> fp32 [B, grid*grid, 3, size, size]; perm int64 [B,K] / flips uint8 [B,K] optional,
+    boxes int32 [B,K,4] = x0, y0, w, h inside each block"""
+    lib = _lib.load()
+    B, H, W, ch = img.shape
+    K = grid * grid
+    _req(img, "img", torch.uint8, B * H * W * 3)
+    if ch != 3 or H % grid or W % grid:
+        raise ValueError(f"expected [B,H,W,3] with H, W divisible by {grid}, got {tuple(img.shape)}")
+    _req(boxes, "boxes", torch.int32, B * K * 4)
+    _opt(perm, "perm", torch.int64, B * K)
+    _opt(flips, "flips", torch.uint8, B * K)
+    # the boxes are validated where they are drawn, on the host (data.DeviceTiler.view): here it would be a read-back
+    mean_t = torch.tensor(list(mean), dtype=torch.float32)
+    std_t = torch.tensor(list(std), dtype=torch.float32)
+    out = torch.empty(B, K, 3, size, size, dtype=torch.float32, device=img.device)
+    import ctypes as C_
+
+    m = (C_.c_float * 3)(*mean_t.tolist())
+    s = (C_.c_float * 3)(*std_t.tolist())
+    _lib.check(lib.msfwsi_tile_views(_p(img), B, H, W, int(grid), _p(perm), _p(boxes), _p(flips),
+                                     C_.cast(m, C_.c_void_p), C_.cast(s, C_.c_void_p), float(max_pixel), int(size),
+                                     _p(out), _stream()), "tile_views")
+    return out
+
+
+def inverse_perm(perm):
+    """argsort of each row of a permutation matrix int64 [rows, K]"""
+    lib = _lib.load()
+    rows, K = perm.shape
+    _req(perm, "perm", torch.int64)
+    inv = torch.empty_like(perm)
+    _lib.check(lib.msfwsi_inverse_perm(_p(perm), _p(inv), rows, K, _stream()), "inverse_perm")
+    return inv

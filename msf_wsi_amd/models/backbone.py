@@ -58,9 +58,10 @@ class MSFWSI(nn.Module):
                     nn.ModuleList([make_predictor(d, torch.div(d, 4, rounding_mode="floor")) for d in dims]))
 
         # The reference's --use-ac wraps every Conv2d/Linear in torch activation checkpointing
-        # (backbone.py:106-127).  Here activation memory is handled inside the engine (only raw conv outputs
-        # are kept; BatchNorm+ReLU are recomputed in the consumers), so the flag only selects the engine's
-        # pass-level recompute mode; the reference's side effect of re-initialising both stem convs is kept.
+        # (backbone.py:106-127).  Here the engine reads this flag (Engine.model_forward): with it set, both target
+        # passes run features-only in the forward and are re-run right before their backward ("targets" recompute
+        # mode: 16/17 of the activation memory against one extra forward of the target stream); results are
+        # identical.  The reference's side effect of re-initialising both stem convs is kept.
         self.use_checkpoint = bool(use_checkpoint)
         if use_checkpoint:
             for enc in (self.context_encoder, self.target_encoder):

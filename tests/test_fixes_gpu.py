@@ -159,3 +159,40 @@ def test_colstats_survives_cancellation(hip_lib, dt, shape):
     assert torch.allclose(s[1], (xd * xd).sum(0), rtol=1e-13, atol=0)
     var = s[1] / M - (s[0] / M) ** 2
     assert torch.allclose(var, xd.var(0, unbiased=False), rtol=1e-9, atol=0)
+
+
+def test_use_checkpoint_selects_recompute_and_keeps_results(hip_lib):
+    """MSFWSI(..., use_checkpoint=True) (reference --use-ac, backbone.py:103-127): both stem convs are re-initialised
+    like the reference does, the engine runs the target passes features-only and re-runs them before their backward;
+    on equal weights loss, gradients and BatchNorm updates equal the keep-everything mode"""
+    from helpers import install_hub_stub, reference_loop_loss
+    from msf_wsi_amd.models import resnet as R
+    from msf_wsi_amd.models.backbone import MSFWSI
+
+    install_hub_stub()
+    torch.manual_seed(MODEL_SEED)
+    ref_model = MSFWSI(R.resnet18, 4)
+    torch.manual_seed(MODEL_SEED)
+    ac = MSFWSI(R.resnet18, 4, use_checkpoint=True)
+    assert ac.use_checkpoint and not torch.equal(ac.context_encoder.conv1.weight, ref_model.context_encoder.conv1.weight)
+    ref_model.load_state_dict(ac.state_dict())
+    ac, ref_model = ac.cuda().train(), ref_model.cuda().train()
+    (c1, c2), (t1, t2), idx = _gpu_batch(B=4)
+    outs = {}
+    for name, m in (("ac", ac), ("ref", ref_model)):
+        o = m((c1, t1), (c2, t2), idx)
+        loss, _ = reference_loop_loss(o)
+        loss.backward()
+        outs[name] = (float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+                      {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "tracked" in k})
+    torch.cuda.synchronize()
+    from msf_wsi_amd.engine import default_engine
+
+    assert default_engine()._mode_override is None  # the second model (use_checkpoint=False) reset it
+    assert abs(outs["ac"][0] - outs["ref"][0]) <= 1e-6 * max(1.0, abs(outs["ref"][0]))
+    worst = max(rel(outs["ac"][1][n], g) for n, g in outs["ref"][1].items())
+    assert worst < 1e-4, worst  # same kernels on the same numbers; only fp32 atomics' order differs
+    for k, v in outs["ref"][2].items():
+        assert torch.allclose(outs["ac"][2][k].double(), v.double(), rtol=1e-5, atol=1e-7), k
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 2
