@@ -10,7 +10,8 @@
 // gathered from the uint8 HWC tile, writes are coalesced fp32 CHW planes.  HBM-bound: 3 B in (per bilinear tap) + 12 B
 // out per pixel.
 // Arithmetic: crop + bilinear resize with the half-pixel convention of cv2.resize(INTER_LINEAR)
-// (src = (dst + 0.5) * scale - 0.5, clamped), in fp32, result rounded to the nearest uint8 level (the reference's
+// (src = (dst + 0.5) * scale - 0.5, clamped) evaluated EXACTLY in integers -- coordinate split and the 4-tap blend --
+// and rounded half-to-even to the uint8 level (the reference's
 // intermediate image is uint8) -- cv2's fixed-point coefficients are NOT reproduced (cv2 / albumentations are absent:
 // resize parity unpinned; a box of exactly 224x224 is an exact copy); then albumentations' Normalize in its own fp32
 // operation order: img = float(img); img -= mean*255; img *= 1/(std*255).
@@ -43,27 +44,34 @@ __global__ void tiler_kernel(const TilerParams p) {
         const int x0 = box[0], y0 = box[1], cw = box[2], ch = box[3];
         const int xo = (p.flips != nullptr && p.flips[bk]) ? p.S - 1 - x : x;  // HorizontalFlip AFTER the resize
         // cv2 half-pixel mapping into the crop, clamped to its edge
-        const float sx = (float)cw / (float)p.S, sy = (float)ch / (float)p.S;
-        float fx = ((float)xo + 0.5f) * sx - 0.5f, fy = ((float)y + 0.5f) * sy - 0.5f;
-        int ix = (int)floorf(fx), iy = (int)floorf(fy);
-        float ax = fx - (float)ix, ay = fy - (float)iy;
-        if (ix < 0) { ix = 0; ax = 0.f; }
-        if (iy < 0) { iy = 0; ay = 0.f; }
+        // Source coordinate of cv2's half-pixel convention, src = (dst + 0.5) * c / S - 0.5 = ((2 dst + 1) c - S) / (2 S),
+        // split EXACTLY with integers into its floor and a remainder in [0, 2S); the interpolation weight is
+        // remainder / 2S (kept as the integer remainder: the blend below is integer arithmetic, bit-identical everywhere)
+        const int twoS = 2 * p.S;
+        const int nx = (2 * xo + 1) * cw - p.S, ny = (2 * y + 1) * ch - p.S;
+        int ix = nx >= 0 ? nx / twoS : -((-nx + twoS - 1) / twoS);
+        int iy = ny >= 0 ? ny / twoS : -((-ny + twoS - 1) / twoS);
+        int rx = nx - ix * twoS, ry = ny - iy * twoS;  // weights rx / 2S, ry / 2S
+        if (ix < 0) { ix = 0; rx = 0; }
+        if (iy < 0) { iy = 0; ry = 0; }
         int ix1 = ix + 1, iy1 = iy + 1;
-        if (ix1 >= cw) { ix1 = cw - 1; if (ix >= cw - 1) { ix = cw - 1; ax = 0.f; } }
-        if (iy1 >= ch) { iy1 = ch - 1; if (iy >= ch - 1) { iy = ch - 1; ay = 0.f; } }
+        if (ix1 >= cw) { ix1 = cw - 1; if (ix >= cw - 1) { ix = cw - 1; rx = 0; } }
+        if (iy1 >= ch) { iy1 = ch - 1; if (iy >= ch - 1) { iy = ch - 1; ry = 0; } }
         const unsigned char* r0 = p.img + (((long)b * p.H + by + y0 + iy) * p.W + bx + x0) * 3;
         const unsigned char* r1 = p.img + (((long)b * p.H + by + y0 + iy1) * p.W + bx + x0) * 3;
         float* o = p.out + bk * 3 * p.S * p.S + (long)y * p.S + x;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v00 = (float)r0[ix * 3 + c], v01 = (float)r0[ix1 * 3 + c];
-            const float v10 = (float)r1[ix * 3 + c], v11 = (float)r1[ix1 * 3 + c];
-            const float top = __fadd_rn(v00, __fmul_rn(ax, __fsub_rn(v01, v00)));
-            const float bot = __fadd_rn(v10, __fmul_rn(ax, __fsub_rn(v11, v10)));
-            float v = __fadd_rn(top, __fmul_rn(ay, __fsub_rn(bot, top)));
-            v = rintf(v);  // the uint8 intermediate image (round half to even)
-            v = fminf(fmaxf(v, 0.f), 255.f);
+            // the blend in exact integers (like cv2's 8-bit path, which is fixed-point too):
+            //   v = [(v00 (2S-rx) + v01 rx) (2S-ry) + (v10 (2S-rx) + v11 rx) ry] / (2S)^2, rounded half to even
+            const int top = (int)r0[ix * 3 + c] * (twoS - rx) + (int)r0[ix1 * 3 + c] * rx;
+            const int bot = (int)r1[ix * 3 + c] * (twoS - rx) + (int)r1[ix1 * 3 + c] * rx;
+            const long num = (long)top * (twoS - ry) + (long)bot * ry;
+            const long den = (long)twoS * twoS;
+            long q = num / den;
+            const long rem2 = 2 * (num - q * den);
+            if (rem2 > den || (rem2 == den && (q & 1))) ++q;
+            const float v = (float)q;  // 0 .. 255: the reference's uint8 intermediate image
             o[(long)c * p.S * p.S] = __fmul_rn(__fsub_rn(v, p.mean255[c]), p.denom[c]);
         }
     }
@@ -90,7 +98,7 @@ extern "C" int msfwsi_tile_views(const unsigned char* img, int B, int H, int W, 
     for (int c = 0; c < 3; ++c) {
         // albumentations.functional.normalize: mean32 * max_pixel, reciprocal(std32 * max_pixel) -- all fp32
         p.mean255[c] = mean[c] * max_pixel;
-        p.denom[c] = 1.0f / (std_[c] * max_pixel);
+        p.denom[c] = 1.0f / (std_[c] * max_pixel);  // host code: IEEE fp32 division, as np.reciprocal(float32)
     }
     p.B = B; p.H = H; p.W = W; p.K = grid * grid; p.grid = grid; p.bh = H / grid; p.bw = W / grid; p.S = S;
     const long total = (long)B * p.K * S * S;

@@ -7,8 +7,9 @@ numpy restatement of the geometric part of the reference's per-sample batch cons
 PINNED: blockshaped / shuffle / flip / layout (plain numpy, checked here against the reference's own assertion
 `target_grid.shape == (16, 256, 256, 3)` and its block order) and Normalize (albumentations.functional.normalize's
 published fp32 operation order).  UNPINNED: the bilinear resize -- albumentations delegates to cv2.resize(INTER_LINEAR),
-whose 8-bit path uses fixed-point coefficients; cv2 and albumentations are absent from this image, so the resize is
-restated as fp32 bilinear interpolation with cv2's half-pixel convention, rounded to uint8 levels.  A crop box of exactly
+whose 8-bit path uses fixed-point coefficients (11-bit weights, two rounded passes); cv2 and albumentations are absent
+from this image, so the resize is restated as EXACT bilinear interpolation with cv2's half-pixel convention (integer
+arithmetic, one rounding half-to-even to the uint8 level): it can differ from cv2 by one level on a fraction of pixels.  A crop box of exactly
 224x224 makes the resize an exact copy: that case is fully pinned."""
 import numpy as np
 
@@ -20,30 +21,35 @@ def blockshaped(arr, nrows, ncols):
 
 
 def resize_bilinear_u8(img, size):
-    """[h,w,3] uint8 -> [size,size,3] uint8-valued float32; cv2 half-pixel convention, fp32 lerps, round half to even"""
+    """[h,w,3] uint8 -> [size,size,3] uint8-valued float32.  cv2 half-pixel convention src = (dst + 0.5) n_src / n_dst - 0.5
+    = ((2 dst + 1) n_src - n_dst) / (2 n_dst), split exactly into floor and remainder r in [0, 2 n_dst); the 4-tap blend
+    with weights r / (2 n_dst) is evaluated in exact integers and rounded half to even"""
     h, w, _ = img.shape
-    f32 = np.float32
+    two = 2 * size
 
-    def coords(n_src, n_dst):
-        sc = f32(n_src) / f32(n_dst)
-        f = (np.arange(n_dst, dtype=f32) + f32(0.5)) * sc - f32(0.5)
-        i0 = np.floor(f).astype(np.int64)
-        a = (f - i0.astype(f32)).astype(f32)
+    def coords(n_src):
+        num = (2 * np.arange(size, dtype=np.int64) + 1) * n_src - size
+        i0 = np.floor_divide(num, two)
+        r = num - i0 * two
         lo = i0 < 0
-        i0[lo], a[lo] = 0, 0
+        i0[lo], r[lo] = 0, 0
         hi = i0 >= n_src - 1
-        i0[hi], a[hi] = n_src - 1, 0
+        i0[hi], r[hi] = n_src - 1, 0
         i1 = np.minimum(i0 + 1, n_src - 1)
-        return i0, i1, a
+        return i0, i1, r
 
-    y0, y1, ay = coords(h, size)
-    x0, x1, ax = coords(w, size)
-    im = img.astype(f32)
-    ax_, ay_ = ax[None, :, None], ay[:, None, None]
-    top = im[y0][:, x0] + ax_ * (im[y0][:, x1] - im[y0][:, x0])
-    bot = im[y1][:, x0] + ax_ * (im[y1][:, x1] - im[y1][:, x0])
-    v = top + ay_ * (bot - top)
-    return np.clip(np.rint(v), 0, 255).astype(f32)
+    y0, y1, ry = coords(h)
+    x0, x1, rx = coords(w)
+    im = img.astype(np.int64)
+    rx_, ry_ = rx[None, :, None], ry[:, None, None]
+    top = im[y0][:, x0] * (two - rx_) + im[y0][:, x1] * rx_
+    bot = im[y1][:, x0] * (two - rx_) + im[y1][:, x1] * rx_
+    num = top * (two - ry_) + bot * ry_
+    den = two * two
+    q = num // den
+    rem2 = 2 * (num - q * den)
+    q = q + ((rem2 > den) | ((rem2 == den) & (q % 2 == 1)))
+    return q.astype(np.float32)
 
 
 def normalize(img_f32, mean, std, max_pixel=255.0):
