@@ -185,10 +185,12 @@ int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scale, const fl
 /* Backward of relu + maxpool at the stem (resnet.py:235-237), g = relu'(.) * maxpool_backward(dp), in the two passes
  * BatchNorm's backward forces (all of sum g, sum g*c0 before any dc0):
  *   k1 == NULL: sums[shard][2][C] += {sum g, sum g*c0}; g0 (nullable) = g
- *   k1 != NULL: g0 = k1*g + k2*c0 + k3 (g re-derived from dp / argmax instead of written and re-read); sums nullable */
+ *   k1 != NULL: g0 = k1*g + k2*c0 + k3 (g re-derived from dp / argmax instead of written and re-read); sums nullable
+ * dact (nullable, [N][H][W][C]): a gradient of the stem activation itself, added before the gate (the U-Net skip taken
+ * before the max-pool: smp's ResNetEncoder stage 1, used by reference src/models/hooknet.py through smp.Unet). */
 int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax, const void* c0,
                          const float* scale, const float* shift, void* g0, double* sums, int nshard, const float* k1,
-                         const float* k2, const float* k3, int N, int H, int W, int C, void* stream);
+                         const float* k2, const float* k3, const void* dact, int N, int H, int W, int C, void* stream);
 
 /* out[n][c] = mean over HW of y[n][hw][c].  Replaces: AdaptiveAvgPool2d((1,1)) + flatten on the four
  * stage outputs, src/models/resnet.py:244-250. */
@@ -289,6 +291,29 @@ int msfwsi_seg_stats(int logits_dtype, const void* logits, int nch, const long* 
  * accuracy on the counts summed over images; 0/0 -> zero_division (smp default 1.0).  scores: 3 + 3*C doubles. */
 int msfwsi_seg_scores(const long* tp, const long* fp, const long* fn, const long* tn, int N, int C, double zero_division,
                       double* scores, void* stream);
+
+/* ---- fine-tune model: U-Net decoder pieces (row f2 of SURVEY.md 8f, BASELINE config 5) --------------------------------
+ * The arithmetic of HookNet's decoders lives in segmentation_models_pytorch (third party, outside the reference tree,
+ * absent here): its published algorithm is restated, parity unpinned; call sites: src/models/hooknet.py:15-35,84-100.
+ * out[n][2h][2w][Cx+Cs] = [nearest-x2(x) | skip]: DecoderBlock's F.interpolate(scale_factor=2, "nearest") + torch.cat. */
+int msfwsi_upcat_fwd(int dtype, const void* x, const void* skip, void* out, int N, int h, int w, int Cx, int Cs,
+                     void* stream);
+/* adjoint: dx = 2x2 window sums of dout[..., :Cx]; dskip (nullable when Cs == 0) = dout[..., Cx:] */
+int msfwsi_upcat_bwd(int dtype, const void* dout, void* dx, void* dskip, int N, int h, int w, int Cx, int Cs,
+                     void* stream);
+/* backward == 0: out[N][ch][cw][C] = x[:, y0:y0+ch, x0:x0+cw, :] (the hook x[:, :, 12:20, 12:20], hooknet.py:29-32);
+ * backward != 0: x[window] += out (its adjoint, accumulated into the gradient that also comes from the next block) */
+int msfwsi_crop(int dtype, void* x, void* out, int N, int H, int W, int C, int y0, int x0, int ch, int cw, int backward,
+                void* stream);
+/* y[N][C][HW] fp32 = x[N][HW][CP][:C] (the logits handed back to the caller in the reference's NCHW layout) */
+int msfwsi_nhwc_to_nchw(int dtype, const void* x, float* y, int N, int C, long HW, int CP, void* stream);
+/* smp.losses.DiceLoss(MULTICLASS_MODE, classes, from_logits=True) (tools/ssl_finetune.py:287-288) forward + backward on
+ * NHWC logits [M][CP] (C1 real channels) and int64 targets [M]: *loss += weight * mean_{c in class_mask}
+ * (1 - 2 sum p_c t_c / max(sum p_c + t_c, eps)) [sum t_c > 0]; dlogits (nullable) = *grad_scale * weight * dLoss/dlogits.
+ * sums [3][C1] fp64 ZEROED by the caller; coef [2][C1] fp32 scratch.  C1 <= 32. */
+int msfwsi_dice_loss(int dtype, const void* logits, const long* target, long M, int C1, int CP, unsigned class_mask,
+                     double eps, double smooth, double weight, double* sums, double* loss, float* coef,
+                     const float* grad_scale, void* dlogits, void* stream);
 
 /* ---- tiling / normalising front end (row f3 of SURVEY.md 8f) --------------------------------------------------------
  * out[b][k] (fp32 [3][S][S]) = Normalize(HFlip?(resize_bilinear(crop(block perm[b][k] of img[b], box[b][k]), S x S)))

@@ -268,8 +268,10 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
                                      const T* __restrict__ c0, const float* __restrict__ scale,
                                      const float* __restrict__ shift, T* __restrict__ g0, double* sums, int nshard,
                                      const float* __restrict__ k1, const float* __restrict__ k2,
-                                     const float* __restrict__ k3, int N, int H, int W, int C, int P, int Q, int cw,
-                                     int nrl, int rows_per_block) {
+                                     const float* __restrict__ k3, const T* __restrict__ dact, int N, int H, int W, int C,
+                                     int P, int Q, int cw, int nrl, int rows_per_block) {
+    // dact (nullable): a second gradient of the stem ACTIVATION relu(bn1(c0)) itself, added before the gate -- the
+    // U-Net skip connection taken before the max-pool (smp ResNetEncoder stage 1)
     // two modes (BatchNorm's backward needs the sums of ALL of g before any dc can be formed):
     //   k1 == null: g = gated pool gradient, sums += {sum g, sum g*c}; g0 (if given) = g
     //   k1 != null: g0 = k1*g + k2*c + k3  (g re-derived on the fly instead of being written and re-read)
@@ -328,6 +330,12 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
             }
             float x[VEC];
             unpack16<T>(*reinterpret_cast<const uint4*>(c0 + m * C + ch), x);
+            if (dact != nullptr) {
+                float da[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(dact + m * C + ch), da);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] += da[e];
+            }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 if (!(fmaf(x[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
@@ -983,8 +991,8 @@ extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scal
 
 extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax, const void* c0,
                                     const float* scale, const float* shift, void* g0, double* sums, int nshard,
-                                    const float* k1, const float* k2, const float* k3, int N, int H, int W, int C,
-                                    void* stream) {
+                                    const float* k1, const float* k2, const float* k3, const void* dact, int N, int H,
+                                    int W, int C, void* stream) {
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && dp && argmax && c0 && scale && shift && (g0 || sums) && nshard >= 1);
     MSFWSI_CHECK_ARG((k1 == nullptr) == (k2 == nullptr) && (k1 == nullptr) == (k3 == nullptr));
     MSFWSI_CHECK_ARG(k1 == nullptr || g0 != nullptr);
@@ -994,8 +1002,8 @@ extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned ch
     ColGrid g = make_col_grid((long)N * H * W, C, vec, 2048);
     const size_t lds = (size_t)kThreads * 2 * vec * sizeof(float);
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_kernel<T>, g.grid, dim3(kThreads), lds, ST(stream), (const T*)dp,
-                           argmax, (const T*)c0, scale, shift, (T*)g0, sums, nshard, k1, k2, k3, N, H, W, C, P, Q, g.cw,
-                           g.nrl, g.rows_per_block));
+                           argmax, (const T*)c0, scale, shift, (T*)g0, sums, nshard, k1, k2, k3, (const T*)dact, N, H, W, C,
+                           P, Q, g.cw, g.nrl, g.rows_per_block));
     return msfwsi_launch_status();
 }
 

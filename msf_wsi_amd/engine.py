@@ -743,15 +743,27 @@ class Engine:
         return {"t0", "t1"}, drop
 
     def encoder_backward(self, ps: EncPass, dfeats: Sequence[Optional[torch.Tensor]], grads: GradStore,
-                         dtype: torch.dtype):
+                         dtype: torch.dtype, dmaps: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                         dstem: Optional[torch.Tensor] = None):
+        """dfeats: gradients of the four pooled features.  dmaps / dstem (U-Net skip connections, unet_engine): dense
+        gradients of the four stage OUTPUT maps [N,H,W,C] and of the stem activation relu(bn1(conv1)) [N,H/2,W/2,64]."""
         dy, pre = None, None
         for i in range(len(ps.blocks) - 1, -1, -1):
             rec = ps.blocks[i]
             gapg = dfeats[rec.stage] if rec.stage_end else None
+            if dmaps is not None and rec.stage_end and dmaps[rec.stage] is not None:
+                dm = dmaps[rec.stage]
+                if dy is None:
+                    dy = dm
+                else:  # dy + dm through the BatchNorm-apply kernel with the unit map (one rounding)
+                    one, zero = self._unit_gate(dm.shape[-1], dm.device)
+                    tot = torch.empty_like(dy)
+                    kn.bn_act(dy, one, zero, tot, ident=dm, relu=False)
+                    dy = tot
             if dy is None and gapg is None:
                 raise RuntimeError("encoder_backward: no gradient reaches the last block")
             gate = None
-            if i > 0 and self.fuse_gate:
+            if i > 0 and self.fuse_gate and dmaps is None:
                 pr = ps.blocks[i - 1]
                 if self._foldable(pr) and (pr.ds is None or self._ds_foldable(pr.ds)):
                     # the producer of pr's output gradient (this block's first conv) applies pr's closing ReLU gate,
@@ -767,12 +779,12 @@ class Engine:
         # gated gradient g itself is never written: -2 passes over the largest tensor of the network)
         sums = kn.new_stats(64, 2, u.c.device)
         g0 = torch.empty_like(u.c)
-        if self.stem_two_pass:
+        if self.stem_two_pass and dstem is None:
             kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, None, sums, ps.N, H0, W0, 64)
             k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
             kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, None, ps.N, H0, W0, 64, k=(k[0], k[1], k[2]))
         else:
-            kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, sums, ps.N, H0, W0, 64)
+            kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, sums, ps.N, H0, W0, 64, dact=dstem)
             k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
             kn.bn_bwd_apply(g0, u.c, k[0], k[1], k[2], g0)
         self._unit_wgrad(u, g0, grads, dtype)

@@ -643,8 +643,9 @@ def stem_pool_fwd(c0, scale, shift, out, argmax, N, H, W, Cn):
                                                               _p(argmax), N, H, W, Cn, _stream()), "stem_pool_fwd"))
 
 
-def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn, k=None):
-    """k=None: sums += {sum g, sum g*c0}, g0 (optional) = g;  k=(k1,k2,k3): g0 = k1*g + k2*c0 + k3"""
+def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn, k=None, dact=None):
+    """k=None: sums += {sum g, sum g*c0}, g0 (optional) = g;  k=(k1,k2,k3): g0 = k1*g + k2*c0 + k3;
+    dact: gradient of the stem activation itself (U-Net skip), added before the gate"""
     lib = _lib.load()
     P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     _req(c0, "c0", None, N * H * W * Cn)
@@ -659,6 +660,7 @@ def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn, k=None):
         nsh = sums.numel() // (2 * Cn)
         if nsh * 2 * Cn != sums.numel():
             raise ValueError("stem_pool_bwd: sums must be [nshard,2,C]")
+    _opt(dact, "dact", c0.dtype, N * H * W * Cn)
     k1 = k2 = k3 = None
     if k is not None:
         k1, k2, k3 = k
@@ -667,7 +669,7 @@ def stem_pool_bwd(dp, argmax, c0, scale, shift, g0, sums, N, H, W, Cn, k=None):
     _stream_timed("stem_pool_bwd", c0.element_size() * (N * H * W * Cn * (1 + (g0 is not None)) + N * P * Q * Cn)
                   + N * P * Q * Cn, lambda: _lib.check(
         lib.msfwsi_stem_pool_bwd(dt_of(c0), _p(dp), _p(argmax), _p(c0), _p(scale), _p(shift), _p(g0), _p(sums), nsh,
-                                 _p(k1), _p(k2), _p(k3), N, H, W, Cn, _stream()), "stem_pool_bwd"))
+                                 _p(k1), _p(k2), _p(k3), _p(dact), N, H, W, Cn, _stream()), "stem_pool_bwd"))
 
 
 def gap_fwd(y, out, N, HW, Cn):
@@ -998,3 +1000,73 @@ def inverse_perm(perm):
     inv = torch.empty_like(perm)
     _lib.check(lib.msfwsi_inverse_perm(_p(perm), _p(inv), rows, K, _stream()), "inverse_perm")
     return inv
+
+
+# ------------------------------------------------------------------------------------------------
+# U-Net decoder pieces / Dice loss (csrc/unet.hip)
+# ------------------------------------------------------------------------------------------------
+def upcat_fwd(x, skip, out):
+    """out [N,2h,2w,Cx+Cs] = [nearest-x2(x) | skip]"""
+    lib = _lib.load()
+    N, h, w, Cx = x.shape
+    Cs = skip.shape[-1] if skip is not None else 0
+    _req(x, "x")
+    _opt(skip, "skip", x.dtype, N * 4 * h * w * Cs)
+    _req(out, "out", x.dtype, N * 4 * h * w * (Cx + Cs))
+    _lib.check(lib.msfwsi_upcat_fwd(dt_of(x), _p(x), _p(skip), _p(out), N, h, w, Cx, Cs, _stream()), "upcat_fwd")
+    return out
+
+
+def upcat_bwd(dout, dx, dskip):
+    lib = _lib.load()
+    N, h, w, Cx = dx.shape
+    Cs = dout.shape[-1] - Cx
+    _req(dout, "dout", None, N * 4 * h * w * (Cx + Cs))
+    _req(dx, "dx", dout.dtype)
+    _opt(dskip, "dskip", dout.dtype, N * 4 * h * w * Cs)
+    _lib.check(lib.msfwsi_upcat_bwd(dt_of(dout), _p(dout), _p(dx), _p(dskip), N, h, w, Cx, Cs, _stream()), "upcat_bwd")
+
+
+def crop(x, out, y0: int, x0: int, backward: bool = False):
+    """out = x[:, y0:y0+ch, x0:x0+cw, :]; backward: x[window] += out"""
+    lib = _lib.load()
+    N, H, W, Cn = x.shape
+    _, ch, cw, _ = out.shape
+    _req(x, "x")
+    _req(out, "out", x.dtype, N * ch * cw * Cn)
+    _lib.check(lib.msfwsi_crop(dt_of(x), _p(x), _p(out), N, H, W, Cn, int(y0), int(x0), ch, cw, int(bool(backward)),
+                               _stream()), "crop")
+    return out
+
+
+def nhwc_to_nchw(x, C1: int):
+    """fp32 NCHW copy of the first C1 channels of an NHWC storage tensor"""
+    lib = _lib.load()
+    N, H, W, CP = x.shape
+    _req(x, "x")
+    y = torch.empty(N, C1, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(lib.msfwsi_nhwc_to_nchw(dt_of(x), _p(x), _p(y), N, int(C1), H * W, CP, _stream()), "nhwc_to_nchw")
+    return y
+
+
+def dice_loss(logits, target, C1: int, classes, weight: float, loss_accum, dlogits=None, grad_scale=None,
+              eps: float = 1e-7, smooth: float = 0.0):
+    """multiclass soft Dice from NHWC logits [N,H,W,CP] (C1 real channels), target int64 [N,H,W]; loss_accum fp64[1] +="""
+    lib = _lib.load()
+    N, H, W, CP = logits.shape
+    M = N * H * W
+    _req(logits, "logits")
+    _req(target, "target", torch.int64, M)
+    _req(loss_accum, "loss_accum", torch.float64, 1)
+    _opt(dlogits, "dlogits", logits.dtype, M * CP)
+    _opt(grad_scale, "grad_scale", torch.float32, 1)
+    mask = 0
+    for c in classes:
+        if not 0 <= int(c) < C1:
+            raise ValueError(f"class {c} outside the {C1} logit channels")
+        mask |= 1 << int(c)
+    sums = zeros((3, C1), torch.float64, logits.device)
+    coef = torch.empty(2, C1, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.msfwsi_dice_loss(dt_of(logits), _p(logits), _p(target), M, int(C1), CP, mask, float(eps),
+                                    float(smooth), float(weight), _p(sums), _p(loss_accum), _p(coef), _p(grad_scale),
+                                    _p(dlogits), _stream()), "dice_loss")
