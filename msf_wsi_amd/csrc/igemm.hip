@@ -64,6 +64,14 @@ struct IgemmParams {
     int M, Ktot;
     int nshard;
     int ntile_n;
+    // Stride-2 3x3 input gradient by OUTPUT-PIXEL PARITY (pure-DMA kernel, DGRAD): launch (par_a, par_b) computes the dX
+    // pixels (2i + par_a, 2j + par_b).  For them only the taps r = wr0 + 2 r', s = ws0 + 2 s' (r' < R, s' < S) meet a
+    // dY pixel, so the launch is a stride-1 gradient of an R x S (1x1, 1x2, 2x1, 2x2) kernel over the [N][P][Q] grid of
+    // dY with paddings (pad, pad_w) -- 9 tap-passes over M/4 rows each instead of 9 over M (3/4 of them on zeros) --
+    // whose weights are read in place from the 3x3 tensor (w_S = 3 taps per row, w_RS = 9 per channel) and whose
+    // rows are written to / read from the interleaved full-resolution pixels (epilogue: pix_of_row).
+    int par_mode, par_a, par_b, pad_w, wr0, ws0, w_S, w_RS;
+    FastDiv par_div_pq, par_div_q;
 };
 
 template <typename T>
@@ -138,6 +146,16 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
     const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, lh = lane >> 5;
     const int PQ = prm.P * prm.Q;
+    // row m of this launch -> pixel index of the output tensor (identity except in parity mode: row (n, i, j) of the
+    // [N][P][Q] sub-grid is pixel (n, 2i + a, 2j + b) of the [N][2P][2Q] tensor)
+    auto pix_of_row = [&](int m) -> long {
+        if (!DGRAD || !prm.par_mode) return (long)m;
+        const unsigned n = fast_div((unsigned)m, prm.par_div_pq);
+        const unsigned rem = (unsigned)m - n * (unsigned)PQ;
+        const unsigned i = fast_div(rem, prm.par_div_q);
+        const unsigned j = rem - i * (unsigned)prm.Q;
+        return ((long)n * (2 * prm.P) + 2 * i + prm.par_a) * (2 * prm.Q) + 2 * j + prm.par_b;
+    };
     // ---------------- epilogue: accumulators -> LDS tile (storage type) ----------------
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -218,7 +236,8 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
         r_has[pi] = false;
         r_bits[pi] = 0;
         if (ok) {
-            const long off = (long)m * prm.Nout + ncol;
+            const long pixm = pix_of_row(m);
+            const long off = pixm * prm.Nout + ncol;
             if (resid != nullptr) {
                 if constexpr (LORES) {
                     // pixel m = (n, h, w) of the [N][P][Q] output; the residual lives on the s-strided sub-grid
@@ -238,7 +257,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 }
             }
             if (mask_c != nullptr) r_msk[pi] = *reinterpret_cast<const uint4*>(mask_c + off);
-            else if (mask_bits != nullptr) r_bits[pi] = mask_bits[(long)m * (prm.Nout / VEC) + (ncol / VEC)];
+            else if (mask_bits != nullptr) r_bits[pi] = mask_bits[pixm * (prm.Nout / VEC) + (ncol / VEC)];
         }
     }
     if (grp == 0) __syncthreads();  // the transposed tile is complete in LDS
@@ -250,7 +269,8 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
         const int m = m0 + row;
         if (m < prm.M && col_ok) {
             uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
-            const long off = (long)m * prm.Nout + ncol;
+            const long pixm = pix_of_row(m);
+            const long off = pixm * prm.Nout + ncol;
             if (resid != nullptr || gapg != nullptr || post_scale != nullptr) {
                 float f[VEC];
                 unpack16<T>(v, f);
@@ -267,7 +287,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 }
                 if (gapg != nullptr) {
                     float gp[VEC];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(gapg + (long)(m / PQ) * prm.Nout + ncol), gp);
+                    unpack16<T>(*reinterpret_cast<const uint4*>(gapg + (long)(m / PQ) * prm.Nout + ncol), gp);  // m / PQ = image, also in parity mode
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
                 }
@@ -282,7 +302,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                     unsigned b = 0;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
-                    gate_out[(long)m * (prm.Nout / VEC) + (ncol / VEC)] = (unsigned char)b;
+                    gate_out[pixm * (prm.Nout / VEC) + (ncol / VEC)] = (unsigned char)b;
                 }
             }
             if (mask_c != nullptr) {
@@ -789,7 +809,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         const int q = rem - p * prm.Q;
         if (DGRAD) {
             hb = p + prm.pad;
-            wb = q + prm.pad;
+            wb = q + (prm.par_mode ? prm.pad_w : prm.pad);
         } else {
             hb = p * prm.stride - prm.pad;
             wb = q * prm.stride - prm.pad;
@@ -804,7 +824,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     const int pitch = RUN ? prm.pix_stride : prm.C;  // elements per source pixel
     const __amdgpu_buffer_rsrc_t srd_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T*>(reinterpret_cast<const T*>(prm.src)) + ref_pix * pitch, 0, 0x7fffffff, 0x00020000);
-    const long wbytes = (long)prm.Nout * prm.Ktot * ES;
+    // (parity mode reads its taps in place from the whole 3x3 tensor: the descriptor must span all w_RS taps)
+    const long wbytes = (DGRAD && prm.par_mode) ? (long)prm.Nout * prm.w_RS * prm.C * ES : (long)prm.Nout * prm.Ktot * ES;
     const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(prm.wgt), 0, (int)(wbytes < 0x7fffffffL ? wbytes : 0x7fffffffL), 0x00020000);
 
@@ -876,7 +897,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
             const int cp = lane % CPRW;
             const int g = (ROWB >= 256) ? (krow & 3) : ((krow >> 1) & 1);
             const int n = n0 + ((((cp >> 2) ^ g) << 2) | (cp & 3)) * VEC;
-            b_voff[i] = n < prm.Nout ? (int)(((long)krow * RS * prm.Nout + n) * ES) : OOB;
+            b_voff[i] = n < prm.Nout ? (int)(((long)krow * (prm.par_mode ? prm.w_RS : RS) * prm.Nout + n) * ES) : OOB;
         }
     }
 
@@ -911,7 +932,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         const int soff_a = soff_tap + tap_c * ES;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) dma16_buf(srd_a, Ab + i * NW * 1024, voff_eff[i], soff_a);
-        const int soff_b = DGRAD ? (int)(((long)tap_c * RS + tap_t) * prm.Nout * ES) : k0 * ES;
+        // weight rows of this slab: channel tap_c, tap tap_t of the [k][r][s][n] tensor (parity mode: the 3x3 tensor's tap
+        // (wr0 + 2 tap_r, ws0 + 2 tap_s), read in place)
+        const int tap_w = (DGRAD && prm.par_mode) ? (prm.wr0 + 2 * tap_r) * prm.w_S + prm.ws0 + 2 * tap_s : tap_t;
+        const int soff_b = DGRAD ? (int)(((long)tap_c * (prm.par_mode ? prm.w_RS : RS) + tap_w) * prm.Nout * ES) : k0 * ES;
 #pragma unroll
         for (int i = 0; i < NB; ++i) dma16_buf(srd_b, Bb + i * NW * 1024, b_voff[i], soff_b);
         k0 += BK;
@@ -1051,6 +1075,7 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
     return msfwsi_launch_status();
 }
 
+long g_s2_parity = 1;               // key 5: stride-2 3x3 input gradients by output-pixel parity (0 = one masked launch)
 long g_big_tile_min_blocks = 1024;  // tunable through msfwsi_set_tuning
 long g_small_grid_blocks = 100;     // key 4: 128x128 grids below this use 128x64 tiles (measured: helps <= 72 tiles, hurts at 144+)
 
@@ -1096,6 +1121,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 4) {
         g_small_grid_blocks = value;
+        return MSFWSI_OK;
+    }
+    if (key == 5) {
+        g_s2_parity = value;
         return MSFWSI_OK;
     }
     if (key == 0) {
@@ -1260,6 +1289,28 @@ extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, cons
     prm.M = d->N * d->H * d->W;
     prm.Ktot = d->R * d->S * d->K;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int bk = d->dtype == MSFWSI_DT_F32 ? 16 : 32;
+    if (g_s2_parity && g_fast_dma && d->stride == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && d->H % 2 == 0 &&
+        d->W % 2 == 0 && d->P == d->H / 2 && d->Q == d->W / 2 && d->K % bk == 0 && resid_stride <= 1) {
+        // four launches, one per parity (a, b) of the dX pixel: see IgemmParams::par_mode
+        prm.par_mode = 1; prm.stride = 1; prm.w_S = 3; prm.w_RS = 9;
+        prm.P = d->P; prm.Q = d->Q;
+        prm.M = d->N * d->P * d->Q;
+        prm.par_div_pq = make_fastdiv((unsigned)(d->P * d->Q));
+        prm.par_div_q = make_fastdiv((unsigned)d->Q);
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                prm.par_a = a; prm.par_b = b;
+                prm.R = a ? 2 : 1; prm.S = b ? 2 : 1;
+                prm.pad = a; prm.pad_w = b;
+                prm.wr0 = a ? 0 : 1; prm.ws0 = b ? 0 : 1;
+                prm.Ktot = prm.R * prm.S * d->K;
+                int rc2 = MSFWSI_EINVAL;
+                MSFWSI_WITH_T(d->dtype, rc2 = (dispatch_tile<T, true, false>(prm, st)));
+                if (rc2 != MSFWSI_OK) return rc2;
+            }
+        return MSFWSI_OK;
+    }
     MSFWSI_WITH_T(d->dtype, return dispatch_tile<T, true, false>(prm, st));
     return MSFWSI_EINVAL;
 }

@@ -406,3 +406,41 @@ def test_config2_full_size_properties(hip_lib, freed):
     loss2 = float(ts.step(batch))
     assert math.isfinite(loss2)
     del ts, model, batch
+
+
+S2_CONVS = [
+    # N, H, W, C, K, R, stride, pad   (even extents: the parity-class form of the stride-2 3x3 input gradient)
+    (2, 28, 28, 128, 128, 3, 2, 1),
+    (3, 14, 18, 64, 256, 3, 2, 1),
+    (1, 56, 56, 64, 64, 3, 2, 1),      # ResNet-18 first conv of layer2-like: 64 output channels -> 128x64 tile
+    (2, 8, 6, 256, 256, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("dt", tk.DTYPES)
+@pytest.mark.parametrize("geom", S2_CONVS)
+@pytest.mark.parametrize("big", [False, True])
+def test_stride2_dgrad_by_parity(hip_lib, dt, geom, big):
+    """4 launches over the (h % 2, w % 2) classes of the dX pixels (1x1, 1x2, 2x1, 2x2 sub-kernels read in place from the
+    3x3 weights) == the single masked launch == torch; plain, with residual + pooled gradient, and gated with sums"""
+    hip_lib.msfwsi_set_tuning(0, 1 if big else 1024)
+    try:
+        tk.test_conv_dgrad(hip_lib, dt, geom)
+        tk.test_conv_dgrad_fused_activation_backward(hip_lib, dt, geom)
+        # A/B against the single-launch form on the same inputs: identical up to the summation order of the taps
+        from msf_wsi_amd import kernels as kn
+
+        N, H, W, Cc, K, R, st, pad = geom
+        g = torch.Generator().manual_seed(77)
+        d = kn.conv_desc(dt, N, H, W, Cc, K, R, R, st, pad)
+        dy = nhwc(rnd((N, K, d.P, d.Q), dt, g)).to(dt).cuda()
+        w = nhwc(rnd((K, Cc, R, R), dt, g, 0.05)).to(dt).cuda()
+        a, b = torch.empty(N, H, W, Cc, dtype=dt, device="cuda"), torch.empty(N, H, W, Cc, dtype=dt, device="cuda")
+        kn.conv_dgrad(d, dy, w, a)
+        hip_lib.msfwsi_set_tuning(5, 0)
+        kn.conv_dgrad(d, dy, w, b)
+        torch.cuda.synchronize()
+        assert rel(a.float(), b.float()) < (1e-6 if dt == torch.float32 else tol(dt))
+    finally:
+        hip_lib.msfwsi_set_tuning(5, 1)
+        hip_lib.msfwsi_set_tuning(0, 1024)
