@@ -85,9 +85,21 @@ int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, 
  * [N,H,W,CP] with the channels zero-padded to ONE 16-byte chunk (CP = 4 fp32 / 8 16-bit), w_run is
  * [K][R][run] where run = S*CP rounded up to whole k slabs (32 16-bit / 16 fp32 elements) and the padding columns are
  * zero: the S taps of a filter row are contiguous in NHWC memory, so a filter row is one tap over `run` channels.
- * y [N,P,Q,K] raw conv output, stats as in msfwsi_conv_fwd.  MSFWSI_EUNSUPPORTED for other shapes (K > 64 ...). */
+ * y [N,P,Q,K] raw conv output, stats as in msfwsi_conv_fwd.  MSFWSI_EUNSUPPORTED for other shapes (K > 64 ...).
+ * CP may also be a multiple of the chunk (the space-to-depth form below: CP = 16, R = S = 4, stride 1, pad 2);
+ * P, Q > 0 give an explicitly cropped output extent (asymmetric padding), 0 = the convolution formula. */
 int msfwsi_stem_conv_fwd(int dtype, const void* x, const void* w_run, void* y, double* stats, int nshard, int N, int H,
-                         int W, int CP, int K, int R, int S, int stride, int pad, void* stream);
+                         int W, int CP, int K, int R, int S, int stride, int pad, int P, int Q, void* stream);
+
+/* The stem in space-to-depth form: the 7x7 / stride-2 / pad-3 conv on 3 channels (src/models/resnet.py:174) equals a
+ * 4x4 / stride-1 conv (2 rows of padding above / left, H/2 output rows) on y[n][i][j][(a*2+b)*3+c] = x[n][c][2i+a][2j+b]
+ * (12 channels padded to 16) with W2[k][ri][si][(a*2+b)*3+c] = W[k][2ri+a-1][2si+b-1][c]: k range 256 instead of 448,
+ * half the input bytes.  nchw_to_s2d: fp32 NCHW [N,3,H,W] (H, W even) -> storage [N,H/2,W/2,16];
+ * stem_s2d_weights: fp32 [K][7][7][3] -> storage [K][4][4][16]; stem_s2d_wfold: dw[K][7][7][3] += the gathered
+ * dw2[K][4][4][16] (the weight gradient computed on the space-to-depth operand, folded back). */
+int msfwsi_nchw_to_s2d(int dtype, const float* x, void* y, int N, int H, int W, void* stream);
+int msfwsi_stem_s2d_weights(int dtype, const float* w, void* out, int K, void* stream);
+int msfwsi_stem_s2d_wfold(const float* dw2, float* dw, int K, void* stream);
 
 /* Two-source 1x1 input gradient: dx = gate( dy . w_cat[0:K] + src2 . w_cat[K:K+C2] + bias ), w_cat = [K+C2][C]
  * (rows K.. are a second [C2][C] matrix), src2 = [N,H,W,C2], bias fp32 [C] nullable, gate / sums as in

@@ -55,7 +55,10 @@ SIGNATURES = {
     "msfwsi_gap_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
     "msfwsi_bn_act_sum": [_i, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp],
     "msfwsi_fold_matvec": [_vp, _vp, _vp, _i, _i, _vp],
-    "msfwsi_stem_conv_fwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "msfwsi_stem_conv_fwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "msfwsi_nchw_to_s2d": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "msfwsi_stem_s2d_weights": [_i, _vp, _vp, _i, _vp],
+    "msfwsi_stem_s2d_wfold": [_vp, _vp, _i, _vp],
     "msfwsi_conv_fwd_post2": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "msfwsi_conv_dgrad2": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_conv_fwd_post": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],

@@ -100,6 +100,59 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Space-to-depth form of the stem (conv 7x7 / stride 2 / pad 3 on 3 channels, src/models/resnet.py:174):
+//   y[n][i][j][(a*2+b)*3 + c] = x[n][c][2i+a][2j+b]   (12 channels, zero-padded to 16),   H, W even
+//   out(p, q) = sum_{r,s,c} W[r][s][c] x[c][2p-3+r][2q-3+s]  with  2p-3+r = 2(p-2+ri) + a  <=>  r = 2 ri + a - 1
+// => a 4x4 / stride-1 conv with padding 2 (top/left; the output keeps H/2 rows) on y with weights
+//   W2[k][ri][si][(a*2+b)*3 + c] = W[k][2ri+a-1][2si+b-1][c]   (0 where an index is -1, and in channels 12..15).
+// A filter row is then 4 taps x 16 channels = 64 contiguous elements = whole k slabs (K = 256 instead of the 448 of the
+// 7-row-taps form with its 8-padded channels), and the input tensor has half the bytes.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_s2d_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int H, int W) {
+    constexpr int VEC = ElemTraits<T>::VEC, CP = 16;
+    const int H2 = H / 2, W2 = W / 2;
+    const long total = (long)N * H2 * W2 * (CP / VEC);
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(t % (CP / VEC));
+        const long pix = t / (CP / VEC);
+        const int j = (int)(pix % W2);
+        const int i = (int)((pix / W2) % H2);
+        const long n = pix / ((long)W2 * H2);
+        float f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int ch = cv * VEC + e;
+            const int ab = ch / 3, c = ch - ab * 3;
+            f[e] = ch < 12 ? x[((n * 3 + c) * H + 2 * i + (ab >> 1)) * W + 2 * j + (ab & 1)] : 0.f;
+        }
+        *reinterpret_cast<uint4*>(y + pix * CP + cv * VEC) = pack16<T>(f);
+    }
+}
+
+// w fp32 [K][7][7][3] -> out T [K][4][4][16]
+template <typename T>
+__global__ void stem_s2d_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int K) {
+    const int total = K * 4 * 4 * 16;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int ch = t & 15, si = (t >> 4) & 3, ri = (t >> 6) & 3, k = t >> 8;
+        const int ab = ch / 3, c = ch - ab * 3;
+        const int r = 2 * ri + (ab >> 1) - 1, s = 2 * si + (ab & 1) - 1;
+        store_elem<T>(out, t, (ch < 12 && r >= 0 && s >= 0) ? w[((k * 7 + r) * 7 + s) * 3 + c] : 0.f);
+    }
+}
+
+// adjoint: dw fp32 [K][7][7][3] += dw2 fp32 [K][4][4][16] gathered back (atomic: both views' streams add here)
+__global__ void stem_s2d_wfold_kernel(const float* __restrict__ dw2, float* dw, int K) {
+    const int total = K * 7 * 7 * 3;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int c = t % 3, s = (t / 3) % 7, r = (t / 21) % 7, k = t / 147;
+        const int ri = (r + 1) >> 1, a = (r + 1) & 1, si = (s + 1) >> 1, b = (s + 1) & 1;
+        atomicAdd(dw + t, dw2[((k * 4 + ri) * 4 + si) * 16 + (a * 2 + b) * 3 + c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // BatchNorm (training) finalize: sums -> mean / invstd / fused scale+shift, running-stat update.
 // reference: nn.BatchNorm2d / BatchNorm1d in train mode (resnet.py:175,59-62; backbone.py:15,18,21,28):
 // biased variance for normalisation, unbiased into running_var, momentum 0.1, eps 1e-5.
@@ -923,6 +976,27 @@ extern "C" int msfwsi_nchw_to_nhwc(int dtype, const float* x, void* y, int N, in
     const long total = (long)N * H * W * (CP / vec_of(dtype));
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream), x,
                            (T*)y, N, C, H * W, CP));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_nchw_to_s2d(int dtype, const float* x, void* y, int N, int H, int W, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
+    const long total = (long)N * (H / 2) * (W / 2) * (16 / vec_of(dtype));
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(nchw_to_s2d_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream), x,
+                           (T*)y, N, H, W));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_stem_s2d_weights(int dtype, const float* w, void* out, int K, void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && w && out && K > 0);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_s2d_weights_kernel<T>, dim3((K * 256 + 255) / 256), dim3(256), 0, ST(stream),
+                           w, (T*)out, K));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_stem_s2d_wfold(const float* dw2, float* dw, int K, void* stream) {
+    MSFWSI_CHECK_ARG(dw2 && dw && K > 0);
+    hipLaunchKernelGGL(stem_s2d_wfold_kernel, dim3((K * 147 + 255) / 256), dim3(256), 0, ST(stream), dw2, dw, K);
     return msfwsi_launch_status();
 }
 

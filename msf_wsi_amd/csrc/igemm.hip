@@ -1162,20 +1162,22 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
 }
 
 extern "C" int msfwsi_stem_conv_fwd(int dtype, const void* x, const void* w_run, void* y, double* stats, int nshard,
-                                    int N, int H, int W, int CP, int K, int R, int S, int stride, int pad,
-                                    void* stream) {
+                                    int N, int H, int W, int CP, int K, int R, int S, int stride, int pad, int P,
+                                    int Q, void* stream) {
     MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && x && w_run && y && N > 0 && H > 0 && W > 0 && K > 0 && K <= 64);
     MSFWSI_CHECK_ARG(stats == nullptr || nshard >= 1);
     const int vec = msfwsi_vec_of(dtype), bk = dtype == MSFWSI_DT_F32 ? 16 : 32;
     // the run of S pixels x CP channels is padded to whole k slabs; a 16-byte chunk must be one pixel
     const int run = ((S * CP + bk - 1) / bk) * bk;
-    if (CP != vec || K % vec != 0 || R * (run / bk) > 32 || (stride != 1 && stride != 2) || !g_fast_dma)
+    if (CP % vec != 0 || K % vec != 0 || R * (run / bk) > 32 || (stride != 1 && stride != 2) || !g_fast_dma)
         return MSFWSI_EUNSUPPORTED;
     IgemmParams prm{};
     prm.src = x; prm.wgt = w_run; prm.out = y;
     prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
     prm.N = N; prm.H = H; prm.W = W; prm.C = run;
-    prm.P = (H + 2 * pad - R) / stride + 1; prm.Q = (W + 2 * pad - S) / stride + 1; prm.Nout = K;
+    // P, Q > 0: an explicitly cropped output extent (asymmetric padding: `pad` rows above / left, fewer below / right)
+    prm.P = P > 0 ? P : (H + 2 * pad - R) / stride + 1; prm.Q = Q > 0 ? Q : (W + 2 * pad - S) / stride + 1; prm.Nout = K;
+    if (prm.P > (H + 2 * pad - R) / stride + 1 || prm.Q > (W + 2 * pad - S) / stride + 1) return MSFWSI_EINVAL;
     prm.R = R; prm.S = 1; prm.stride = stride; prm.pad = pad;
     prm.pix_stride = CP; prm.s_run = S;
     if ((long)N * prm.P * prm.Q > 0x7fffffffL) return MSFWSI_EINVAL;

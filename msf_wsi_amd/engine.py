@@ -55,6 +55,7 @@ class Unit:
     st: Optional[BNState] = None
     gram: Optional[Tuple[torch.Tensor, torch.Tensor]] = None  # (a^T a, sum a) of the normalised operand, fp32/fp64
     lo: Optional[Tuple[int, tuple]] = None  # (stride, full-resolution shape): x is a strided subsampling of the input
+    s2d: bool = False  # stem in space-to-depth form: desc / x describe the 4x4 / stride-1 conv on the [N,H/2,W/2,16] operand
 
 
 @dataclass
@@ -209,6 +210,7 @@ class Engine:
         self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
+        self.stem_s2d = os.environ.get("MSFWSI_STEM_S2D", "1") != "0"  # ... in space-to-depth form (4x4 / stride 1)
         self.pair_head_wgrad = os.environ.get("MSFWSI_PAIR_HEAD_WGRAD", "1") != "0"  # one dW launch for both views
         # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
         # stem_pool_bwd + bn_bwd_apply (the pool-backward window logic is VALU-bound, not byte-bound): off
@@ -279,6 +281,8 @@ class Engine:
                         CP = chan_pad(dtype)
                         if self.stem_run:
                             self._stem_run_weights(m, dtype, CP)
+                            if self.stem_s2d and m.kernel_size == (7, 7) and m.in_channels == 3:
+                                self._stem_s2d_weights(m, dtype)
                         self.weights.get(m.weight, dtype, pad_to=CP)
                     else:
                         self.weights.get(m.weight, dtype)
@@ -415,6 +419,42 @@ class Engine:
         R, S = op.kernel_size
         return kn.stem_conv_fwd(x, self._stem_run_weights(op, dtype, CP), c, stats, R, S, op.stride[0], op.padding[0])
 
+    # ---- stem in space-to-depth form ---------------------------------------------------------------
+    def _stem_s2d_ok(self, op: nn.Module, H: int, W: int) -> bool:
+        return (self.stem_s2d and self.stem_run and isinstance(op, nn.Conv2d) and op.kernel_size == (7, 7)
+                and op.stride == (2, 2) and op.padding == (3, 3) and op.in_channels == 3 and op.out_channels == 64
+                and op.bias is None and H % 2 == 0 and W % 2 == 0)
+
+    def _stem_s2d_weights(self, op: nn.Module, dtype) -> torch.Tensor:
+        """[K][7][7][3] -> [K][4][4][16] (DESIGN 3.2 / msfwsi_stem_s2d_weights), cached per parameter version"""
+        key = (id(op.weight), dtype, "s2d")
+        ver = (op.weight._version, op.weight.data_ptr())
+        hit = self._stem_cache.get(key)
+        if hit is None or hit[0] != ver:
+            w2 = torch.empty(op.out_channels, 4, 4, 16, dtype=dtype, device=op.weight.device)
+            kn.stem_s2d_weights(WeightStore.physical(op.weight), w2)
+            hit = (ver, w2)
+            self._stem_cache[key] = hit
+        return hit[1]
+
+    def _stem_s2d_fwd(self, enc: nn.Module, x: torch.Tensor, dtype) -> Optional[Unit]:
+        """conv1 (7x7 / stride 2 / pad 3, resnet.py:174) as a 4x4 / stride-1 conv on the space-to-depth input: k range
+        256 instead of 448 (7 row taps x 64-element runs of 8-padded channels), input tensor half the bytes"""
+        op, bn = enc.conv1, enc.bn1
+        N, _, H, W = x.shape
+        H2, W2 = H // 2, W // 2
+        xs = torch.empty(N, H2, W2, 16, dtype=dtype, device=x.device)
+        kn.nchw_to_s2d(x, xs)
+        c = torch.empty(N, H2, W2, op.out_channels, dtype=dtype, device=x.device)
+        stats = kn.new_stats(op.out_channels, 2, x.device)
+        if not kn.stem_conv_fwd(xs, self._stem_s2d_weights(op, dtype), c, stats, 4, 4, 1, 2, P=H2, Q=W2):
+            return None
+        d = _lib.ConvDesc(kn.dt_of(xs), N, H2, W2, 16, H2, W2, op.out_channels, 4, 4, 1, 2)
+        u = Unit(op, bn, True, d, xs, None, c)
+        u.st = self._bn_finalize(stats, N * H2 * W2, bn)
+        u.s2d = True
+        return u
+
     def _stem_run_weights(self, op: nn.Module, dtype, CP: int) -> torch.Tensor:
         """stem weights [K][R][S][CP] -> [K][R][run] (zero columns pad the S*CP run to whole k slabs), cached per
         parameter version"""
@@ -540,7 +580,11 @@ class Engine:
             x = torch.empty_like(u.x)
             kn.bn_act(u.x, pro[0], pro[1], x, relu=True)
             pro = None
-        if u.desc.C != u.op.weight.shape[1]:  # channel-padded stem
+        if u.s2d:  # weight gradient on the space-to-depth operand, folded back into [K][7][7][3]
+            dw2 = kn.zeros((u.desc.K, 4, 4, 16), torch.float32, dc.device)
+            kn.conv_wgrad(u.desc, u.x, dc, dw2)
+            kn.stem_s2d_wfold(dw2, grads.get(u.op.weight))
+        elif u.desc.C != u.op.weight.shape[1]:  # channel-padded stem
             CP = u.desc.C
             dwp = torch.zeros(u.desc.K, u.desc.R, u.desc.S, CP, dtype=torch.float32, device=dc.device)
             kn.conv_wgrad(u.desc, x, dc, dwp, pro=pro)
@@ -581,9 +625,13 @@ class Engine:
         x = x.contiguous()
         N, _, H, W = x.shape
         CP = chan_pad(dtype)
-        xin = torch.empty(N, H, W, CP, dtype=dtype, device=x.device)
-        kn.nchw_to_nhwc(x, xin, CP)
-        stem = self._unit_fwd(enc.conv1, enc.bn1, True, xin, None, (N, H, W, CP), dtype, pad_c=CP)
+        stem = self._stem_s2d_fwd(enc, x, dtype) if self._stem_s2d_ok(enc.conv1, H, W) else None
+        if stem is not None:
+            xin = stem.x
+        else:
+            xin = torch.empty(N, H, W, CP, dtype=dtype, device=x.device)
+            kn.nchw_to_nhwc(x, xin, CP)
+            stem = self._unit_fwd(enc.conv1, enc.bn1, True, xin, None, (N, H, W, CP), dtype, pad_c=CP)
         H0, W0 = stem.desc.P, stem.desc.Q
         P, Q = (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1
         pooled = torch.empty(N, P, Q, 64, dtype=dtype, device=x.device)

@@ -264,9 +264,10 @@ def gate_bytes(d_or_rows, Cn: int = 0, dtype=None, device="cuda") -> torch.Tenso
     return torch.empty(int(d_or_rows), Cn // vec_of(dtype), dtype=torch.uint8, device=device)
 
 
-def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad) -> bool:
+def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad, P: int = 0, Q: int = 0) -> bool:
     """the stem conv as R row taps over runs of S contiguous pixels (x [N,H,W,CP], w_run [K][R][run], run = S*CP
-    padded to whole k slabs with zero columns); False if the library has no kernel for the shape"""
+    padded to whole k slabs with zero columns); P, Q: explicitly cropped output extent (0 = formula); False if the
+    library has no kernel for the shape"""
     lib = _lib.load()
     N, H, W, CP = x.shape
     K = y.shape[-1]
@@ -278,11 +279,15 @@ def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad) -> bool:
         _req(stats, "stats", torch.float64)
         nsh = stats.shape[0]
     d = conv_desc(x.dtype, N, H, W, CP, K, R, S, stride, pad)
+    if P or Q:
+        d = ConvDesc(d.dtype, N, H, W, CP, int(P), int(Q), K, R, S, stride, pad)
+    if y.numel() != N * d.P * d.Q * K:
+        raise ValueError(f"stem_conv_fwd: y must hold {N}x{d.P}x{d.Q}x{K} elements")
     rc = [0]
 
     def run():
         rc[0] = lib.msfwsi_stem_conv_fwd(dt_of(x), _p(x), _p(w_run), _p(y), _p(stats), nsh, N, H, W, CP, K, R, S,
-                                         stride, pad, _stream())
+                                         stride, pad, int(P), int(Q), _stream())
         if rc[0] != -2:
             _lib.check(rc[0], "stem_conv_fwd")
 
@@ -628,6 +633,38 @@ def nchw_to_nhwc(x, y, CP):
     _stream_timed("nchw_to_nhwc", 4 * x.numel() + y.element_size() * y.numel(), lambda: _lib.check(
         lib.msfwsi_nchw_to_nhwc(dt_of(y), _p(x), _p(y), N, Cc, H, W, CP, _stream()), "nchw_to_nhwc"))
     return y
+
+
+def nchw_to_s2d(x, y):
+    """fp32 NCHW [N,3,H,W] (H, W even) -> storage [N,H/2,W/2,16]: channel (a*2+b)*3+c = x[c][2i+a][2j+b]"""
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    if Cc != 3 or H % 2 or W % 2:
+        raise ValueError("nchw_to_s2d: [N,3,H,W] with even H, W")
+    _req(x, "x", torch.float32)
+    _req(y, "y", None, N * (H // 2) * (W // 2) * 16)
+    _stream_timed("nchw_to_nhwc", 4 * x.numel() + y.element_size() * y.numel(), lambda: _lib.check(
+        lib.msfwsi_nchw_to_s2d(dt_of(y), _p(x), _p(y), N, H, W, _stream()), "nchw_to_s2d"))
+    return y
+
+
+def stem_s2d_weights(w, out):
+    """fp32 [K][7][7][3] -> storage [K][4][4][16] (the 4x4 / stride-1 form of the 7x7 / stride-2 stem)"""
+    lib = _lib.load()
+    K = w.shape[0]
+    _req(w, "w", torch.float32, K * 147)
+    _req(out, "out", None, K * 256)
+    _lib.check(lib.msfwsi_stem_s2d_weights(dt_of(out), _p(w), _p(out), K, _stream()), "stem_s2d_weights")
+    return out
+
+
+def stem_s2d_wfold(dw2, dw):
+    """dw [K][7][7][3] += gather of dw2 [K][4][4][16]"""
+    lib = _lib.load()
+    K = dw.shape[0]
+    _req(dw2, "dw2", torch.float32, K * 256)
+    _req(dw, "dw", torch.float32, K * 147)
+    _lib.check(lib.msfwsi_stem_s2d_wfold(_p(dw2), _p(dw), K, _stream()), "stem_s2d_wfold")
 
 
 def stem_pool_fwd(c0, scale, shift, out, argmax, N, H, W, Cn):

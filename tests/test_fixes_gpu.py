@@ -196,3 +196,37 @@ def test_use_checkpoint_selects_recompute_and_keeps_results(hip_lib):
         assert torch.allclose(outs["ac"][2][k].double(), v.double(), rtol=1e-5, atol=1e-7), k
         if k.endswith("num_batches_tracked"):
             assert int(v) == 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hw", [(64, 64), (38, 50), (224, 224)])
+def test_stem_space_to_depth_equals_direct_form(hip_lib, dtype, hw):
+    """conv1 (7x7 / stride 2 / pad 3, resnet.py:174) as a 4x4 / stride-1 conv on the space-to-depth input: output,
+    BatchNorm statistics and the weight gradient (folded back to [64][7][7][3]) against torch fp64"""
+    import torch.nn.functional as F
+    from msf_wsi_amd import kernels as kn
+    from msf_wsi_amd.engine import Engine, GradStore
+    from msf_wsi_amd.models import resnet as R
+
+    H, W = hw
+    torch.manual_seed(5)
+    enc = R.resnet18().cuda().train()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 3, H, W, generator=g)
+    w = enc.conv1.weight.detach().cpu()
+    xq, wq = x.to(dtype).double(), w.to(dtype).double()
+    ref = F.conv2d(xq, wq, stride=2, padding=3)
+    eng = Engine()
+    assert eng._stem_s2d_ok(enc.conv1, H, W)
+    u = eng._stem_s2d_fwd(enc, x.cuda(), dtype)
+    torch.cuda.synchronize()
+    tol = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype]
+    assert rel(u.c.float().cpu().permute(0, 3, 1, 2), ref) < tol
+    cc = u.c.double().cpu().reshape(-1, 64)
+    assert torch.allclose(u.st.mean.cpu().double(), cc.mean(0), rtol=1e-4, atol=1e-5)
+    dy = torch.randn(ref.shape, generator=g).to(dtype)
+    grads = GradStore()
+    eng._unit_wgrad(u, dy.permute(0, 2, 3, 1).contiguous().cuda(), grads, dtype)
+    torch.cuda.synchronize()
+    refw = torch.nn.grad.conv2d_weight(xq, (64, 3, 7, 7), dy.double(), stride=2, padding=3)
+    assert rel(grads.logical(enc.conv1.weight).cpu(), refw) < 2e-5  # exact products, fp32 accumulation
