@@ -234,7 +234,11 @@ class Engine:
         # chip usually holds an MFMA-bound kernel of one beside an HBM-bound kernel of the other, and tails / launch
         # gaps of one are filled by the other.  Per BatchNorm module the running-statistics update of view 1 waits for
         # the one of view 0 (an event), which keeps the reference's update order.
-        self.dual_stream = os.environ.get("MSFWSI_DUAL_STREAM", "0") != "0"
+        # default: on with more than one rank (there it also hides each view's SyncBatchNorm exchanges behind the other
+        # view's compute), off on a single GPU (+24 GiB of allocator pools for -2 %, and per-kernel timings would no
+        # longer be those of isolated kernels); MSFWSI_DUAL_STREAM=0|1 overrides
+        env = os.environ.get("MSFWSI_DUAL_STREAM")
+        self.dual_stream: Optional[bool] = None if env is None else env != "0"
         self._side: Dict[str, torch.cuda.Stream] = {}
         self._bn_order: Optional[Tuple[str, dict]] = None
 
@@ -1185,7 +1189,7 @@ class Engine:
             rec.idx.append(idx.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous())
         # reference call order (backbone.py:140-145): separate BatchNorm batches per call
         self._drop_c3 = False  # the first (small) context pass keeps everything and calibrates the planner
-        dual = self.dual_stream
+        dual = self.dual_stream if self.dual_stream is not None else self._world() > 1
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev) if dual else None
         ev_c, ev_t = {}, {}

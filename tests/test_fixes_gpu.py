@@ -138,6 +138,12 @@ def test_rccl_path_executes_single_rank():
     b = json.loads(plain.stdout.strip().splitlines()[-1])
     assert np.isfinite(a["config"]["loss"])
     assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-4 * max(1.0, abs(b["config"]["loss"]))
+    # ... and with the two views on two HIP streams (the multi-rank default): the RCCL exchanges of view 1 are issued
+    # from the second stream, interleaved with view 0's
+    dual = subprocess.run(cmd, env=dict(env, MSFWSI_DUAL_STREAM="1"), capture_output=True, text=True, timeout=900)
+    assert dual.returncode == 0, dual.stderr[-2000:]
+    c = json.loads(dual.stdout.strip().splitlines()[-1])
+    assert abs(c["config"]["loss"] - b["config"]["loss"]) <= 1e-4 * max(1.0, abs(b["config"]["loss"]))
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
