@@ -260,6 +260,20 @@ int msfwsi_copy2d(int dtype, const void* src, long src_ld, void* dst, long dst_l
 int msfwsi_cosine_loss(int dtype, const void* p, const void* z, long rows, int d, float coef,
                        const float* loss_scale, float eps, double* loss_accum, void* dp, void* stream);
 
+/* ---- InfoNCE variant of the loss (BASELINE.json north_star: "InfoNCE-style contrastive loss ... all-gather of embeddings
+ * for the cross-GPU negative set").  The reference has NO such code (tools/ssl_train.py:422,448-466 is the SimSiam cosine
+ * loss): this is an optional mode of PretrainStep, parity unpinned (checked against a torch restatement:
+ * F.normalize, matmul / temperature, F.cross_entropy).  Rows of p against ALL ranks' z (gathered), positives on the
+ * diagonal: row_l2norm (xhat = x / max(||x||, eps), inv = 1 / max(||x||, eps)), its backward
+ * dx = inv * (dxhat - xhat <xhat, dxhat>), and softmax_ce on logits [rows][n] (label = label0 + row):
+ * *loss_accum += coef * (logsumexp(l / tau) - l[label] / tau); write_grad: logits <- coef * *grad_scale / tau *
+ * (softmax - onehot) in place.  The two GEMMs are msfwsi_conv_fwd / msfwsi_conv_dgrad (1x1, H = W = 1). */
+int msfwsi_row_l2norm(int dtype, const void* x, void* out, float* inv, long rows, int d, float eps, void* stream);
+int msfwsi_row_l2norm_bwd(int dtype, const void* xhat, const void* dxhat, const float* inv, void* dx, long rows, int d,
+                          void* stream);
+int msfwsi_softmax_ce(int dtype, void* logits, long rows, int n, long label0, float inv_tau, float coef,
+                      const float* grad_scale, double* loss_accum, int write_grad, void* stream);
+
 /* GradScaler pieces (tools/ssl_train.py:100,472-474): *found = 1 if any gradient is inf/nan; scale update. */
 int msfwsi_nonfinite_check(const float* g, long n, float* found, void* stream);
 int msfwsi_scaler_update(float* scale, int* growth_tracker, const float* found, float growth_factor,

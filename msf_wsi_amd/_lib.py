@@ -72,6 +72,9 @@ SIGNATURES = {
     "msfwsi_pixel_stride": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "msfwsi_copy2d": [_i, _vp, _l, _vp, _l, _l, _i, _i, _vp],
     "msfwsi_cosine_loss": [_i, _vp, _vp, _l, _i, _f, _vp, _f, _vp, _vp, _vp],
+    "msfwsi_row_l2norm": [_i, _vp, _vp, _vp, _l, _i, _f, _vp],
+    "msfwsi_row_l2norm_bwd": [_i, _vp, _vp, _vp, _vp, _l, _i, _vp],
+    "msfwsi_softmax_ce": [_i, _vp, _l, _i, _l, _f, _f, _vp, _vp, _i, _vp],
     "msfwsi_nonfinite_check": [_vp, _l, _vp, _vp],
     "msfwsi_scaler_update": [_vp, _vp, _vp, _f, _f, _i, _vp],
     "msfwsi_adam": [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _l, _vp, _vp, _vp, _vp, _i, _vp],

@@ -57,6 +57,103 @@ __global__ void cosine_loss_kernel(const T* __restrict__ p, const T* __restrict_
     }
 }
 
+// ---- InfoNCE variant (BASELINE.json north_star wording; the reference itself has only the cosine loss) ----
+// xhat = x / max(||x||, eps) per row, inv[row] = 1 / max(||x||, eps); one wavefront per row
+template <typename T>
+__global__ void row_l2norm_kernel(const T* __restrict__ x, T* __restrict__ out, float* __restrict__ inv, long rows, int d,
+                                  float eps) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const long row = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const T* xr = x + row * d;
+    float ss = 0.f;
+    for (int i = lane * VEC; i < d; i += 64 * VEC) {
+        float a[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(xr + i), a);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ss = fmaf(a[e], a[e], ss);
+    }
+    ss = wave_sum(ss);
+    const float s = 1.f / fmaxf(sqrtf(ss), eps);
+    if (lane == 0) inv[row] = s;
+    for (int i = lane * VEC; i < d; i += 64 * VEC) {
+        float a[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(xr + i), a);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] *= s;
+        *reinterpret_cast<uint4*>(out + row * d + i) = pack16<T>(a);
+    }
+}
+
+// dx = inv * (dxhat - xhat <xhat, dxhat>)   (the clamp is inactive for non-degenerate rows)
+template <typename T>
+__global__ void row_l2norm_bwd_kernel(const T* __restrict__ xhat, const T* __restrict__ dxhat,
+                                      const float* __restrict__ inv, T* __restrict__ dx, long rows, int d) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const long row = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    if (row >= rows) return;
+    const T* xr = xhat + row * d;
+    const T* gr = dxhat + row * d;
+    float dot = 0.f;
+    for (int i = lane * VEC; i < d; i += 64 * VEC) {
+        float a[VEC], b[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(xr + i), a);
+        unpack16<T>(*reinterpret_cast<const uint4*>(gr + i), b);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dot = fmaf(a[e], b[e], dot);
+    }
+    dot = wave_sum(dot);
+    const float s = inv[row];
+    for (int i = lane * VEC; i < d; i += 64 * VEC) {
+        float a[VEC], b[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(xr + i), a);
+        unpack16<T>(*reinterpret_cast<const uint4*>(gr + i), b);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = s * (b[e] - a[e] * dot);
+        *reinterpret_cast<uint4*>(dx + row * d + i) = pack16<T>(a);
+    }
+}
+
+// cross entropy of logits[row][:] * inv_tau against label = label0 + row, one 256-thread workgroup per row:
+//   loss += coef * (logsumexp - logit[label] * inv_tau);  logits <- coef * gs * inv_tau * (softmax - onehot)  (in place)
+template <typename T>
+__global__ void softmax_ce_kernel(T* __restrict__ logits, long rows, int n, long label0, float inv_tau, float coef,
+                                  const float* __restrict__ grad_scale, double* loss_accum, int write_grad) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    T* lr = logits + row * (long)n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += blockDim.x) mx = fmaxf(mx, load_elem<T>(lr, i) * inv_tau);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < n; i += blockDim.x) sum += expf(load_elem<T>(lr, i) * inv_tau - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    const long label = label0 + row;
+    if (tid == 0 && loss_accum != nullptr) {
+        const float lse = mx + logf(sum);
+        atomicAdd(loss_accum, (double)coef * (double)(lse - load_elem<T>(lr, label) * inv_tau));
+    }
+    if (write_grad) {
+        __syncthreads();  // every thread has read the label logit's neighbours before anything is overwritten
+        const float g = coef * inv_tau * (grad_scale != nullptr ? *grad_scale : 1.f);
+        const float inv_sum = 1.f / sum;
+        for (int i = tid; i < n; i += blockDim.x) {
+            const float pr = expf(load_elem<T>(lr, i) * inv_tau - mx) * inv_sum;
+            store_elem<T>(lr, i, g * (pr - (i == label ? 1.f : 0.f)));
+        }
+    }
+}
+
 __global__ void nonfinite_check_kernel(const float* __restrict__ g, long n, float* found) {
     bool bad = false;
     const long n4 = n >> 2;
@@ -225,6 +322,32 @@ extern "C" int msfwsi_cosine_loss(int dtype, const void* p, const void* z, long 
     const long blocks = (rows + 3) / 4;
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(cosine_loss_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, ST(stream),
                            (const T*)p, (const T*)z, rows, d, coef, loss_scale, eps, loss_accum, (T*)dp));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_row_l2norm(int dtype, const void* x, void* out, float* inv, long rows, int d, float eps,
+                                 void* stream) {
+    MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && x && out && inv && rows > 0 && d > 0 && d % msfwsi_vec_of(dtype) == 0);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(row_l2norm_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream),
+                           (const T*)x, (T*)out, inv, rows, d, eps));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_row_l2norm_bwd(int dtype, const void* xhat, const void* dxhat, const float* inv, void* dx, long rows,
+                                     int d, void* stream) {
+    MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && xhat && dxhat && inv && dx && rows > 0 && d > 0);
+    MSFWSI_CHECK_ARG(d % msfwsi_vec_of(dtype) == 0);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(row_l2norm_bwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                           ST(stream), (const T*)xhat, (const T*)dxhat, inv, (T*)dx, rows, d));
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_softmax_ce(int dtype, void* logits, long rows, int n, long label0, float inv_tau, float coef,
+                                 const float* grad_scale, double* loss_accum, int write_grad, void* stream) {
+    MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && logits && rows > 0 && n > 0 && label0 >= 0 && label0 + rows <= n);
+    MSFWSI_CHECK_ARG(rows <= 0x7fffffffL && inv_tau > 0.f);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(softmax_ce_kernel<T>, dim3((unsigned)rows), dim3(256), 0, ST(stream), (T*)logits,
+                           rows, n, label0, inv_tau, coef, grad_scale, loss_accum, write_grad));
     return msfwsi_launch_status();
 }
 

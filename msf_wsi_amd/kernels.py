@@ -818,6 +818,40 @@ def cosine_loss(p, z, coef, loss_accum, dp=None, loss_scale=None, eps=1e-8):
                                       _p(loss_accum), _p(dp), _stream()), "cosine_loss")
 
 
+def row_l2norm(x, out, inv, eps=1e-12):
+    """out = x / max(||x||_2, eps) per row (F.normalize), inv[row] = the factor"""
+    lib = _lib.load()
+    rows, dd = x.shape
+    _req(x, "x")
+    _req(out, "out", x.dtype, rows * dd)
+    _req(inv, "inv", torch.float32, rows)
+    _lib.check(lib.msfwsi_row_l2norm(dt_of(x), _p(x), _p(out), _p(inv), rows, dd, float(eps), _stream()), "row_l2norm")
+    return out
+
+
+def row_l2norm_bwd(xhat, dxhat, inv, dx):
+    lib = _lib.load()
+    rows, dd = xhat.shape
+    _req(xhat, "xhat")
+    _req(dxhat, "dxhat", xhat.dtype, rows * dd)
+    _req(dx, "dx", xhat.dtype, rows * dd)
+    _req(inv, "inv", torch.float32, rows)
+    _lib.check(lib.msfwsi_row_l2norm_bwd(dt_of(xhat), _p(xhat), _p(dxhat), _p(inv), _p(dx), rows, dd, _stream()),
+               "row_l2norm_bwd")
+    return dx
+
+
+def softmax_ce(logits, label0: int, inv_tau: float, coef: float, loss_accum, grad_scale=None, write_grad=True):
+    """cross entropy of logits [rows, n] / tau against label = label0 + row; in place: logits <- d loss / d logits"""
+    lib = _lib.load()
+    rows, n = logits.shape
+    _req(logits, "logits")
+    _opt(loss_accum, "loss_accum", torch.float64, 1)
+    _opt(grad_scale, "grad_scale", torch.float32, 1)
+    _lib.check(lib.msfwsi_softmax_ce(dt_of(logits), _p(logits), rows, n, int(label0), float(inv_tau), float(coef),
+                                     _p(grad_scale), _p(loss_accum), int(bool(write_grad)), _stream()), "softmax_ce")
+
+
 def nonfinite_check(g, found):
     lib = _lib.load()
     _req(g, "g", torch.float32)

@@ -50,13 +50,19 @@ class PretrainStep:
     def __init__(self, model: nn.Module, lr: float = 1e-3, global_batch: int = 32, ms_lr: Sequence[float] = (1, 1, 1),
                  fuser_weights: Sequence[float] = FUSER_WEIGHTS, dtype: torch.dtype = torch.bfloat16,
                  use_scaler: Optional[bool] = None, init_scale: float = 65536.0, process_group=None,
-                 sync_bn: bool = True, arch: str = "resnet18"):
+                 sync_bn: bool = True, arch: str = "resnet18", loss: str = "cosine", temperature: float = 0.2):
         _lib.load()
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.MsfwsiHipError("PretrainStep needs the model on a HIP device (model.cuda()); no CPU path")
         if dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise _lib.MsfwsiHipError(f"unsupported compute dtype {dtype}")
+        if loss not in ("cosine", "infonce"):
+            raise ValueError("loss must be 'cosine' (the reference, tools/ssl_train.py:448-466) or 'infonce'")
+        # "infonce": the variant BASELINE.json's north_star names -- rows of p against the z of ALL ranks (all-gather),
+        # positives on the diagonal, cross entropy at `temperature`.  The reference has no such code, so
+        # this mode is parity-UNPINNED (checked against a torch restatement); the default stays the reference's loss.
+        self.loss_kind, self.temperature = loss, float(temperature)
         self.model = model
         self.arch = arch
         self.dtype = dtype
@@ -120,11 +126,46 @@ class PretrainStep:
                 rows = p1s[s].shape[0]
                 coef = -0.5 * self.weights_per_scale[s] / rows
                 for v, (p, z) in enumerate(((p1s[s], z2s[s]), (p2s[s], z1s[s]))):
-                    dp = torch.empty_like(p) if want_grad else None
-                    kn.cosine_loss(p, z, coef, self.loss_accum, dp, ls)
+                    if self.loss_kind == "infonce":
+                        dp = self._infonce_term(p, z, 0.5 * self.weights_per_scale[s] / rows, ls, want_grad)
+                    else:
+                        dp = torch.empty_like(p) if want_grad else None
+                        kn.cosine_loss(p, z, coef, self.loss_accum, dp, ls)
                     if want_grad:
                         dps[(grp, s, v)] = dp
         return outs, rec, dps
+
+    def _infonce_term(self, p, z, coef: float, ls, want_grad: bool):
+        """coef * sum_rows CE(normalize(p) . normalize(z_all)^T / tau, own row) -> loss_accum; returns dLoss/dp.
+        z_all = this rank's z rows preceded / followed by the other ranks' (RCCL all-gather): the cross-GPU negative
+        set; z carries no gradient (stop-gradient, backbone.py:188-191)."""
+        import torch.distributed as dist
+
+        rows, dd = p.shape
+        dev = p.device
+        world = world_size(self.group)
+        z_all, label0 = z, 0
+        if world > 1:
+            z_all = torch.empty(world * rows, dd, dtype=z.dtype, device=dev)
+            dist.all_gather_into_tensor(z_all, z.contiguous(), group=self.group)
+            label0 = dist.get_rank(self.group) * rows
+        n = z_all.shape[0]
+        ph, zh = torch.empty_like(p), torch.empty_like(z_all)
+        pinv = torch.empty(rows, dtype=torch.float32, device=dev)
+        zinv = torch.empty(n, dtype=torch.float32, device=dev)
+        kn.row_l2norm(p, ph, pinv)
+        kn.row_l2norm(z_all, zh, zinv)
+        d = kn.conv_desc(self.dtype, rows, 1, 1, dd, n, 1, 1, 1, 0)
+        logits = torch.empty(rows, n, dtype=self.dtype, device=dev)
+        kn.conv_fwd(d, ph, zh, logits)                      # logits[i][j] = <p_hat_i, z_hat_j>
+        kn.softmax_ce(logits, label0, 1.0 / self.temperature, coef, self.loss_accum, ls, write_grad=want_grad)
+        if not want_grad:
+            return None
+        dph = torch.empty_like(p)
+        kn.conv_dgrad(d, logits, zh, dph)                   # d p_hat = dlogits . z_hat
+        dp = torch.empty_like(p)
+        kn.row_l2norm_bwd(ph, dph, pinv, dp)
+        return dp
 
     def step(self, batch) -> torch.Tensor:
         """one optimisation step; returns the (device-resident, fp64) loss of this minibatch"""

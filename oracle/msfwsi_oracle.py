@@ -172,6 +172,27 @@ def loss_terms(outputs, weights: Sequence[float] = FUSER_WEIGHTS) -> Tuple[Tenso
     return total, terms
 
 
+def infonce_terms(outputs, weights: Sequence[float] = FUSER_WEIGHTS, temperature: float = 0.2, gathered=None):
+    """The InfoNCE variant named by BASELINE.json's north_star -- NOT in the reference (its loss is `loss_terms` above;
+    SURVEY D1), hence PARITY UNPINNED: a plain torch statement of the standard formulation, used only to check the
+    product's optional mode.  Per (p, z) pair: cross entropy of normalize(p) @ normalize(z_all)^T / tau against the own
+    row, z_all = the z rows of all ranks (`gathered(z)`; identity for one process); weights and the 1/2 as in loss_terms."""
+    total = 0
+    terms = []
+    for grp in outputs:
+        row = []
+        for i, (p1, p2, z1, z2) in enumerate(zip(*grp)):
+            t = 0
+            for p, z in ((p1, z2), (p2, z1)):
+                z_all, off = (z, 0) if gathered is None else gathered(z)
+                logits = F.normalize(p.float(), dim=1) @ F.normalize(z_all.float(), dim=1).t() / temperature
+                t = t + 0.5 * F.cross_entropy(logits, torch.arange(p.shape[0]) + off)
+            row.append(t.detach())
+            total = total + t * weights[i]
+        terms.append(row)
+    return total, terms
+
+
 # --------------------------------------------------------------------------------------------------
 # parameters / optimizer
 # --------------------------------------------------------------------------------------------------
@@ -217,7 +238,7 @@ class Adam:
 
 
 def train_step(sd: StateDict, batch, opt: Adam, scale: int = 4, mask_ratio: float = 0.5,
-               weights: Sequence[float] = FUSER_WEIGHTS, loss_scale: float = 1.0):
+               weights: Sequence[float] = FUSER_WEIGHTS, loss_scale: float = 1.0, loss_fn=None):
     """one iteration of tools/ssl_train.py:425-474 (fp32, no autocast).  Returns loss, per-term losses,
     the forward outputs and the (unscaled) gradients; updates `sd` in place."""
     (c1, c2), (t1, t2), idx = batch
@@ -226,7 +247,7 @@ def train_step(sd: StateDict, batch, opt: Adam, scale: int = 4, mask_ratio: floa
         v.requires_grad_(True)
         v.grad = None
     outputs = msfwsi_forward(sd, (c1, t1), (c2, t2), idx, scale, mask_ratio)
-    loss, terms = loss_terms(outputs, weights)
+    loss, terms = (loss_fn or loss_terms)(outputs, weights)
     (loss * loss_scale).backward()
     grads = {}
     for k, v in params.items():

@@ -162,3 +162,46 @@ def test_two_ranks_resnet50_encoder_syncbn(hip_lib):
     # two ranks accumulate the fp32 Gram matrices / folded sums in a different order than one: with the +6 sigma
     # means of the open-gate trick that is worth 3e-4..1e-3 on the gradients (a missing or doubled term would be >1e-1)
     assert np.median(list(errs.values())) < 1e-3 and errs[worst] < 5e-3, (worst, errs[worst])
+
+
+def _nce_worker(rank, world, port, ret):
+    from msf_wsi_amd.dist import shard_range
+    from msf_wsi_amd.train import PretrainStep
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        model = build_product("resnet18").cuda().train()
+        ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False, sync_bn=True,
+                          loss="infonce")
+        (c1, c2), (t1, t2), idx = _batch()
+        lo, hi = shard_range(B, world, rank)
+        local = ((c1[lo:hi].cuda(), c2[lo:hi].cuda()), (t1[lo * K:hi * K].cuda(), t2[lo * K:hi * K].cuda()),
+                 [idx[0][lo:hi], idx[1][lo:hi]])
+        ts.step(local)
+        torch.cuda.synchronize()
+        ret[f"loss{rank}"] = ts.epoch_loss()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_infonce_all_gather_negatives_two_ranks(hip_lib):
+    """the cross-GPU negative set: with the z rows gathered over ranks (and SyncBN), the mean loss of 2 ranks x 4 tile
+    pairs equals the one of 1 rank x 8 -- every row sees the same 8 (context) / 128 (target) candidates either way.
+    NOTE rows of rank r sit at columns r*rows.. of the gathered matrix, i.e. a permutation of the one-rank order for the
+    target group only if samples stay contiguous, which shard_range guarantees."""
+    from msf_wsi_amd.train import PretrainStep
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_nce_worker, args=(2, port, ret), nprocs=2, join=True)
+    model = build_product("resnet18").cuda().train()
+    ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False, loss="infonce")
+    (c1, c2), (t1, t2), idx = _batch()
+    loss = float(ts.step(((c1.cuda(), c2.cuda()), (t1.cuda(), t2.cuda()), idx)))
+    torch.cuda.synchronize()
+    assert abs(ret["loss0"] - ret["loss1"]) < 1e-12            # epoch_loss is the all-reduced sample-weighted mean
+    assert abs(ret["loss0"] - loss) <= 1e-4 * max(1.0, abs(loss)), (ret["loss0"], loss)

@@ -173,3 +173,43 @@ def test_checkpoint_layout_and_resume(hip_lib):
     enc = {k[len("module.context_encoder."):]: v for k, v in ck["state_dict"].items()
            if k.startswith("module.context_encoder.") and ".fc" not in k}
     assert "layer2.0.downsample.1.running_var" in enc and "conv1.weight" in enc and len(enc) == 120
+
+
+def test_infonce_variant_matches_torch_restatement(hip_lib):
+    """PretrainStep(loss="infonce"): the north_star's InfoNCE wording as an optional mode (the reference has only the
+    cosine loss, SURVEY D1 -> parity unpinned): loss and every gradient against a torch restatement of the standard
+    formulation on the oracle's forward, fp32; then the cross-rank negative set on two ranks == one rank on the batch"""
+    from msf_wsi_amd.train import PretrainStep
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden("r18_b8_s64")
+    B, size = man["B"], man["size"]
+    model = build_product("resnet18")
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
+
+    def oracle(dt):
+        sd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        (c1, c2), (t1, t2), idx = batch
+        b = ((c1.to(dt), c2.to(dt)), (t1.to(dt), t2.to(dt)), idx)
+        nop = type("NoOpt", (), {"step": lambda self, *a, **k: None})()
+        loss, _, _, grads = orc.train_step(sd, b, nop, 4, 0.5, WEIGHTS,
+                                           loss_fn=lambda o, w: orc.infonce_terms(o, w, temperature=0.2))
+        return float(loss), grads
+
+    l64, g64 = oracle(torch.float64)
+    l32, g32 = oracle(torch.float32)
+    model = model.cuda().train()
+    ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False, loss="infonce",
+                      temperature=0.2)
+    ts.flats.zero_grads()
+    outs, rec, dps = ts.forward_loss(_gpu_batch(batch), want_grad=True)
+    loss = float(ts.loss_accum)
+    ts.engine.model_backward(model, rec, dps, ts.grads, torch.float32)
+    torch.cuda.synchronize()
+    assert abs(loss - l64) <= 1e-3 * max(abs(l64), 1e-2), (loss, l64)
+    named = list(model.named_parameters())
+    names = [n for n, _ in named]
+    rels = np.array([rel(ts.grads.logical(p), g64[n]) for n, p in named])
+    box = np.array([rel(g32[n], g64[n]) for n in names])
+    spread_gate(rels, names, [box], "InfoNCE gradients vs the torch restatement (fp64)")
