@@ -234,6 +234,7 @@ int msfwsi_colsum(int dtype, const void* x, double* sums, int nshard, long M, in
  * BatchNorm1d (src/models/backbone.py:15,18,21,28), whose inputs have a batch mean far larger than their batch
  * deviation (E[x^2] - mean^2 cancels 3-4 digits; the GEMM epilogue's fp32 partial sums are not enough there). */
 int msfwsi_colstats(int dtype, const void* x, double* sums, int nshard, long M, int C, void* stream);
+int msfwsi_add_f64(const double* in, double* out, int n, void* stream); /* out[i] += in[i] (fp64 statistics vectors) */
 int msfwsi_add_f64_to_f32(const double* in, float* out, int n, float alpha, void* stream);
 
 /* scatter == 0: out[b*K+k] = in[b*K+idx[b][k]] (jigsaw un-shuffle, src/models/backbone.py:147-158);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "msfwsi_fold_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_colsum": [_i, _vp, _vp, _i, _l, _i, _vp],
     "msfwsi_colstats": [_i, _vp, _vp, _i, _l, _i, _vp],
+    "msfwsi_add_f64": [_vp, _vp, _i, _vp],
     "msfwsi_add_f64_to_f32": [_vp, _vp, _i, _f, _vp],
     "msfwsi_rows_permute": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "msfwsi_pixel_stride": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

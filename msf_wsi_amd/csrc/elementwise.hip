@@ -858,6 +858,11 @@ __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __
     atomicAdd(bvec + c, bacc);
 }
 
+__global__ void add_f64_kernel(const double* __restrict__ in, double* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += in[i];
+}
+
 __global__ void add_f64_to_f32_kernel(const double* __restrict__ in, float* out, int n, float alpha) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) atomicAdd(out + i, alpha * (float)in[i]);
@@ -1190,6 +1195,12 @@ extern "C" int msfwsi_fold_weights(const float* W, const float* M, const float* 
     MSFWSI_CHECK_ARG(W && M && WA && k1 && k2 && k3 && sa && dW && Wk1 && Wk2 && bvec && K > 0 && C > 0);
     hipLaunchKernelGGL(fold_weights_kernel, dim3((C + 63) / 64, (K + kFoldRows - 1) / kFoldRows), dim3(64), 0,
                        ST(stream), W, M, WA, k1, k2, k3, sa, dW, Wk1, Wk2, bvec, K, C);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_add_f64(const double* in, double* out, int n, void* stream) {
+    MSFWSI_CHECK_ARG(in && out && n > 0);
+    hipLaunchKernelGGL(add_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), in, out, n);
     return msfwsi_launch_status();
 }
 

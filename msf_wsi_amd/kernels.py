@@ -757,7 +757,7 @@ def colsum(x, sums):
     _lib.check(lib.msfwsi_colsum(dt_of(x), _p(x), _p(part), NSHARD, M, Cn, _stream()), "colsum")
     tot = torch.empty(Cn, dtype=torch.float64, device=x.device)
     shard_sum(part, tot)
-    sums.add_(tot)
+    _lib.check(lib.msfwsi_add_f64(_p(tot), _p(sums), Cn, _stream()), "add_f64")
 
 
 def colstats(x, stats):
