@@ -289,8 +289,10 @@ class Engine:
                                 self._stem_s2d_weights(m, dtype)
                         self.weights.get(m.weight, dtype, pad_to=CP)
                     else:
-                        self.weights.get(m.weight, dtype)
+                        w = self.weights.get(m.weight, dtype)
                         self._unit_gate(m.weight.shape[0], dev)
+                        if dtype != torch.float32 and isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1):
+                            self._f32_of(w)  # the fold algebra's fp32 copy (_gram_stats), shared by both streams
 
     def _msg_buf(self, kind: str, n: int, dev) -> torch.Tensor:
         """pre-allocated fp64 message buffer of the cross-replica BatchNorm exchange, one per (direction, length).
@@ -486,7 +488,7 @@ class Engine:
             return self._bn_eval_state(bn, count)
         K, Cw = w.shape[0], w.shape[-1]
         dev = w.device
-        Wq = w if dtype == torch.float32 else kn.upcast_f32(w)
+        Wq = w if dtype == torch.float32 else self._f32_of(w)
         dlin = kn.conv_desc(torch.float32, K, 1, 1, Cw, Cw, 1, 1, 1, 0)
         WA = torch.empty(K, 1, 1, Cw, dtype=torch.float32, device=dev)
         kn.conv_fwd(dlin, Wq, A, WA)  # A is symmetric
@@ -494,6 +496,15 @@ class Engine:
         kn.fold_matvec(Wq, sa, stats[0, 0])
         kn.fold_dots(Wq, WA, stats[0, 1])
         return self._bn_finalize(stats, count, bn)
+
+    def _f32_of(self, w16: torch.Tensor) -> torch.Tensor:
+        """fp32 copy of a 16-bit weight tensor, shared by the passes of one step (dropped by invalidate_weights)"""
+        key = ("f32", w16.data_ptr(), w16.numel())
+        hit = self.weights._cache.get(key)
+        if hit is None:
+            hit = (None, kn.upcast_f32(w16))
+            self.weights._cache[key] = hit
+        return hit[1]
 
     def _ds_tail_fwd(self, conv3, bn3, dconv, dbn, c2: torch.Tensor, pro: BNState, x: torch.Tensor, geom, dtype,
                      want_bits: bool):
