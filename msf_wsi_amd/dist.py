@@ -43,9 +43,11 @@ def shard_range(n_samples: int, world: int, r: int) -> Tuple[int, int]:
     return r * per, (r + 1) * per
 
 
-def sync_sums(packed: torch.Tensor, group=None) -> torch.Tensor:
-    """in-place SUM all-reduce of a packed statistics vector"""
-    if world_size(group) > 1:
+def sync_sums(packed: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    """The cross-replica BatchNorm exchange: in-place SUM all-reduce of a packed fp64 statistics vector ([sum, sumsq]
+    forward, [sum g, sum g*c] backward).  The engine (GPU tensors, RCCL) and tests/test_dist_cpu.py (CPU tensors, gloo)
+    both go through this function.  force: issue the collective even with one rank (RCCL rehearsal)."""
+    if world_size(group) > 1 or (force and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     return packed
 

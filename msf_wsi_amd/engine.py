@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import kernels as kn
+from .dist import sync_sums
 
 
 # ------------------------------------------------------------------------------------------------
@@ -335,7 +336,7 @@ class Engine:
         if self._sync(bn):
             packed = self._msg_buf("fwd", 2 * Cn, dev)
             kn.shard_sum(stats, packed)
-            dist.all_reduce(packed, group=self.group)  # RCCL sum of [sum, sumsq]; equal shards per rank
+            sync_sums(packed, self.group, force=self.force_sync)  # RCCL sum of [sum, sumsq]; equal shards per rank
             stats = packed.view(1, 2, Cn)
             total *= self._world()
         if bn.momentum is None:
@@ -372,7 +373,7 @@ class Engine:
                 # taken from the message buffer before the exchange overwrites it (k is scratch here)
                 kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count, bn.weight, st.mean, st.invstd,
                                    grads.get(bn.weight), grads.get(bn.bias), k[0], k[1], k[2])
-            dist.all_reduce(packed, group=self.group)
+            sync_sums(packed, self.group, force=self.force_sync)
             kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count,
                                bn.weight if bn.affine else None, st.mean, st.invstd, None, None, k[0], k[1], k[2])
             return k
