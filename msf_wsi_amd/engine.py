@@ -235,11 +235,12 @@ class Engine:
         # chip usually holds an MFMA-bound kernel of one beside an HBM-bound kernel of the other, and tails / launch
         # gaps of one are filled by the other.  Per BatchNorm module the running-statistics update of view 1 waits for
         # the one of view 0 (an event), which keeps the reference's update order.
-        # default: on with more than one rank (there it also hides each view's SyncBatchNorm exchanges behind the other
-        # view's compute), off on a single GPU (+24 GiB of allocator pools for -2 %, and per-kernel timings would no
-        # longer be those of isolated kernels); MSFWSI_DUAL_STREAM=0|1 overrides
+        # Off by default (MSFWSI_DUAL_STREAM=1 turns it on): it measured -2 % step time on one GPU (and with more ranks
+        # also hides each view's SyncBatchNorm exchanges behind the other view's compute), but the second allocator
+        # pool raises the reserved memory of BASELINE config 2 from 233 to 260 GiB of the card's 268 GiB -- too little
+        # headroom beside RCCL's buffers to be the default -- and per-kernel timings stop being those of isolated kernels
         env = os.environ.get("MSFWSI_DUAL_STREAM")
-        self.dual_stream: Optional[bool] = None if env is None else env != "0"
+        self.dual_stream: Optional[bool] = False if env is None else env != "0"
         self._side: Dict[str, torch.cuda.Stream] = {}
         self._bn_order: Optional[Tuple[str, dict]] = None
 

@@ -23,9 +23,12 @@ def _batch():
 
 
 def _worker(rank, world, port, ret):
+    import os
+
     from msf_wsi_amd.dist import shard_range
     from msf_wsi_amd.train import PretrainStep
 
+    os.environ["MSFWSI_DUAL_STREAM"] = "1"  # the optional two-stream schedule under a real multi-rank exchange
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:

@@ -127,7 +127,12 @@ def test_rccl_path_executes_single_rank():
     probe, fp64 SUM all-reduces of the BatchNorm statistics, the collective recompute plan, AVG all-reduce of the flat
     gradient groups on their own communicator -- with ONE rank (RCCL refuses two ranks on one device): every call
     executes, the numbers must equal the plain single-process step"""
-    env = dict(os.environ, MSFWSI_FORCE_SYNC="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MSFWSI_FORCE_SYNC="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--arch",
            "resnet18", "--batch", "8", "--size", "64", "--dtype", "fp32", "--no-cpu-baseline", "--no-kernel-timer"]
     forced = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
