@@ -104,3 +104,25 @@ def test_resnet50_derived_fixture_manifest(case_name):
     assert vec["grad_norm"].shape == (462,) and (vec["grad_norm"] >= 0).all()
     if "spread_grad" in vec:  # the reference's own fp32<->fp64 noise floor on this model: ~2e-2 on most tensors
         assert vec["spread_grad"].shape == (462,) and np.median(vec["spread_grad"]) > 1e-3
+
+
+def test_updated_weights_gate_accepts_reference_noise_and_rejects_a_wrong_step():
+    """the gate of the GPU parity tests, exercised on the CPU: the reference arithmetic in fp32 against fp64 passes
+    (its Adam sign flips are the Adam steps of gradients within tolerance); an update that is wrong on a tenth of one
+    tensor, or a step with the wrong learning rate, does not"""
+    from helpers import oracle_case, updated_weights_gate
+
+    oc = oracle_case("r18_b8_s64")
+    sp, gsp = [oc["vec"]["spread_step"]], [oc["vec"]["spread_grad"]]
+    named = [(n, oc["sd32"][n]) for n in oc["names"]]
+    updated_weights_gate(named, oc["sd0"], oc["sd64"], oc["grads64"], oc["lr"], sp, gsp, "fp32 oracle vs fp64")
+    k = oc["names"].index("context_encoder.layer3.0.conv1.weight")
+    bad = list(named)
+    t = named[k][1].clone().contiguous()
+    t.view(-1)[: t.numel() // 10] += 2 * oc["lr"]
+    bad[k] = (named[k][0], t)
+    with pytest.raises(AssertionError):
+        updated_weights_gate(bad, oc["sd0"], oc["sd64"], oc["grads64"], oc["lr"], sp, gsp, "corrupted tensor")
+    half = [(n, oc["sd0"][n].double() + 0.5 * (oc["sd64"][n].double() - oc["sd0"][n].double())) for n in oc["names"]]
+    with pytest.raises(AssertionError):
+        updated_weights_gate(half, oc["sd0"], oc["sd64"], oc["grads64"], oc["lr"], sp, gsp, "half learning rate")

@@ -19,7 +19,7 @@ import pytest
 import torch
 
 from helpers import (LR, WEIGHTS, build_product, flat_outputs, grad_rels, load_golden, other_spreads,
-                     reference_loop_loss, rel, spread_gate, step_rels)
+                     reference_loop_loss, rel, spread_gate, updated_weights_gate)
 
 pytestmark = pytest.mark.gpu
 
@@ -122,8 +122,9 @@ def run_reference_loop_case(case, check_golden_outputs=True):
     torch.cuda.synchronize()
     box_step = np.array([rel(sd32[n], sd64[n]) for n in names])
     fixture = [vec["spread_step"]] if "spread_step" in vec else []
-    spread_gate(step_rels(named, sd64), names, fixture + [box_step], f"{case} updated weights vs fp64 oracle",
-                envelope=other_spreads("spread_step", case))
+    gfix = [vec["spread_grad"]] if "spread_grad" in vec else []
+    updated_weights_gate(named, sd0, sd64, grads64, lr, fixture + [box_step], gfix + [box_spread],
+                         f"{case} updated weights vs fp64 oracle")
 
 
 def test_step_parity_r18_b8_s64(hip_lib):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import LR, WEIGHTS, build_product, load_golden, rel, spread_gate, step_rels
+from helpers import LR, WEIGHTS, build_product, load_golden, rel, spread_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -78,14 +78,9 @@ def test_fused_single_step_weights_fp32(hip_lib):
     ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False)
     ts.step(_gpu_batch(batch))
     torch.cuda.synchronize()
-    from helpers import other_spreads
+    from helpers import gate_updated_weights
 
-    named = list(model.named_parameters())
-    names = [n for n, _ in named]
-    assert names == man["param_keys"]
-    box_step = np.array([rel(osd32[n], osd[n]) for n in names])
-    spread_gate(step_rels(named, osd), names, [vec["spread_step"], box_step], "fused step: updated weights vs fp64",
-                envelope=other_spreads("spread_step", "r18_b8_s64"))
+    gate_updated_weights(list(model.named_parameters()), "r18_b8_s64", "fused step: updated weights vs fp64")
     for k, v in osd.items():
         if k.endswith("running_var"):
             assert torch.allclose(model.state_dict()[k].cpu().double(), v, rtol=1e-4, atol=1e-6), k
