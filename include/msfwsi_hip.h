@@ -361,7 +361,7 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * kernels switch from the 128x128 / 4-wave tile to the 256x128 / 8-wave tile; key 1 = 0 disables the pure-DMA
  * (buffer_load ... lds) conv kernel, key 2 = 0 the linear-addressing weight-gradient path, key 4 = grid size (in
  * 128x128 tiles) below which 128x64 tiles are used, key 5 = 0 disables the parity-class form of the stride-2 3x3 input
- * gradient (A/B measurements). */
+ * gradient, key 6 = 0 the 256x256 / 16-wave weight-gradient tile (A/B measurements). */
 int msfwsi_set_tuning(int key, long value);
 
 /* library identification: returns the gfx target string the code objects were built for */

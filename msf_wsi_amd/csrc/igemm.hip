@@ -29,6 +29,10 @@
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
+#ifndef MSFWSI_FETCH_FIRST
+#define MSFWSI_FETCH_FIRST 0  // 1 = the round-1 order (A/B builds: make EXTRA=-DMSFWSI_FETCH_FIRST=1)
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];  // 256 bytes of zeros (never written)
@@ -1021,8 +1025,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         }
         __builtin_amdgcn_s_barrier();  // slab kt visible to all waves; stage st_f (read in kt-1) is free
         asm volatile("" ::: "memory");
+        // The MFMAs of slab kt go first, the DMA requests of slab kt+2 after them: a wave that issues
+        // `buffer_load ... lds` stalls in the issue while earlier pieces are still landing, and with the requests ahead of
+        // the MFMAs every wave of the workgroup sat in that stall at the same time, the matrix pipe idle (measured on the
+        // weight-gradient kernel: DMA-only time + MFMA-only time = total; in this order 704 -> 845 TFLOP/s).
+#if MSFWSI_FETCH_FIRST
         if (kt + 2 < nk) fetch(st_f);
         compute(st_c);
+#else
+        compute(st_c);
+        if (kt + 2 < nk) fetch(st_f);
+#endif
         st_c = st_c == 2 ? 0 : st_c + 1;
         st_f = st_f == 2 ? 0 : st_f + 1;
     }
@@ -1113,10 +1126,15 @@ int check_desc(const msfwsi_conv_desc* d) {
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long v);
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
         msfwsi_wgrad_set_lin(value);
+        return MSFWSI_OK;
+    }
+    if (key == 6) {
+        msfwsi_wgrad_set_big(value);
         return MSFWSI_OK;
     }
     if (key == 4) {

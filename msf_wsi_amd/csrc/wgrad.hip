@@ -17,6 +17,16 @@
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
+#ifndef MSFWSI_WGRAD_BIG_WAVES
+#define MSFWSI_WGRAD_BIG_WAVES 16  // waves of the 256 x 256 tile (8: 128 x 64 per wave, 16: 64 x 64)
+#endif
+#ifndef MSFWSI_WGRAD_BIG_STAGES
+#define MSFWSI_WGRAD_BIG_STAGES 3  // LDS stages of the 256 x 256 tile (32 KiB each)
+#endif
+#ifndef MSFWSI_FETCH_FIRST
+#define MSFWSI_FETCH_FIRST 0  // 1 = the round-1 order (A/B builds: make EXTRA=-DMSFWSI_FETCH_FIRST=1)
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(256))) unsigned int g_wzero_page[64];
@@ -36,21 +46,31 @@ struct WgradParams {
     FastDiv div_pq, div_q;
 };
 
+constexpr int wgrad_waves(int bi, int bj) { return (bi == 256 && bj == 256) ? MSFWSI_WGRAD_BIG_WAVES : 4; }
+constexpr int wgrad_threads(int bi, int bj) { return 64 * wgrad_waves(bi, bj); }
+
 template <typename T, int BI, int BJ, bool XPRO = false>
 struct WgradCfg {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int BKM = ElemTraits<T>::BK;  // pixels per stage
     static constexpr int ROWI = BI * (int)sizeof(T);
     static constexpr int ROWJ = BJ * (int)sizeof(T);
-    static constexpr int WI = (BI >= 128 || BJ <= 64) ? 2 : 1;  // waves along co
-    static constexpr int WJ = 4 / WI;
+    // 256 x 256 for the deep layers: per 32-pixel slab the workgroup takes in 32 KiB for 2 x 256 x 256 x 32 FLOP,
+    // 128 FLOP per ingested byte against 64 for the 128 x 128 tile.  Measured with the MFMAs removed, `buffer_load ...
+    // lds` delivers 15.5 TB/s chip-wide out of L2: a roof of 0.99 PFLOP/s for the small tile and 1.98 for this one.
+    // Sixteen waves of 64 x 64 (2 DMA pieces and 8 MFMAs per wave and slab) rather than eight of 128 x 64: a wave
+    // stalls in the ISSUE of a DMA piece while earlier ones land (about one piece per 150 ns and wave), so the
+    // requests are spread over as many waves as the register file allows (+5-9 % over eight waves).
+    static constexpr int NW = wgrad_waves(BI, BJ);
+    static constexpr int WI = NW == 16 ? 4 : ((BI >= 128 || BJ <= 64) ? 2 : 1);  // waves along co
+    static constexpr int WJ = NW / WI;
     static constexpr int TI = BI / WI / 32;
     static constexpr int TJ = BJ / WJ / 32;
     static constexpr int A_BYTES = BKM * ROWI;
     static constexpr int B_BYTES = BKM * ROWJ;
-    static constexpr int A_IT = A_BYTES / 4096;  // 1-KiB DMA instructions per wave per slab
-    static constexpr int B_IT = B_BYTES / 4096;
-    static constexpr int NST = XPRO ? 2 : 3;
+    static constexpr int A_IT = A_BYTES / (1024 * NW);  // 1-KiB DMA instructions per wave per slab
+    static constexpr int B_IT = B_BYTES / (1024 * NW);
+    static constexpr int NST = XPRO ? 2 : (NW >= 8 ? MSFWSI_WGRAD_BIG_STAGES : 3);
     static constexpr int LDS_BYTES = NST * (A_BYTES + B_BYTES);
     static_assert(TI >= 1 && TJ >= 1, "tile too small");
     static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");
@@ -69,6 +89,18 @@ __device__ __forceinline__ void wdma16(const void* gsrc, void* lds_wave_base) {
 __device__ __forceinline__ void wdma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff,
                                              soff, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 16, "vmcnt literal table");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
 template <int ROWB>
@@ -113,11 +145,11 @@ __device__ __forceinline__ typename WFrag<T>::type read_tr_frag(const char* tile
 // filters and ~13 VALU per piece (image-border test) for 3x3.  (The generic path spends two integer divisions per
 // piece and slab: measured 21 VALU instructions per MFMA.)
 template <typename T, int BI, int BJ, bool XPRO, bool LIN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
+__global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const WgradParams prm) {
     static_assert(!(XPRO && LIN), "the linear fast path is pure DMA");
     typedef WgradCfg<T, BI, BJ, XPRO> Cfg;
     constexpr int VEC = Cfg::VEC, BKM = Cfg::BKM, ROWI = Cfg::ROWI, ROWJ = Cfg::ROWJ;
-    constexpr int WI = Cfg::WI, TI = Cfg::TI, TJ = Cfg::TJ;
+    constexpr int WI = Cfg::WI, TI = Cfg::TI, TJ = Cfg::TJ, NW = Cfg::NW;
     constexpr int A_IT = Cfg::A_IT, B_IT = Cfg::B_IT;
     constexpr int CPI = ROWI / 16, CPJ = ROWJ / 16;      // 16-byte chunks per row
     constexpr int RPI_A = 1024 / ROWI, RPI_B = 1024 / ROWJ;  // rows per DMA instruction
@@ -151,7 +183,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
     bool a_colok[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int krow = (i * 4 + wave) * RPI_A + lane / CPI;
+        const int krow = (i * NW + wave) * RPI_A + lane / CPI;
         const int cp = lane % CPI;
         const int cl = (((cp >> 2) ^ wswz<ROWI>(krow)) << 2) | (cp & 3);
         a_row[i] = krow;
@@ -163,7 +195,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
     float psc[XPRO ? B_IT : 1][VEC], psh[XPRO ? B_IT : 1][VEC];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int krow = (i * 4 + wave) * RPI_B + lane / CPJ;
+        const int krow = (i * NW + wave) * RPI_B + lane / CPJ;
         const int cp = lane % CPJ;
         const int cl = (((cp >> 2) ^ wswz<ROWJ>(krow)) << 2) | (cp & 3);
         const int jcol = j0 + cl * VEC;
@@ -224,7 +256,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
         if constexpr (LIN) {  // slabs are fetched in order: the scalar offsets and the pixel position advance by BKM
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
-                wdma16_buf(srd_a, Ab + (i * 4 + wave) * 1024, la_voff[i], l_soff_a);
+                wdma16_buf(srd_a, Ab + (i * NW + wave) * 1024, la_voff[i], l_soff_a);
             if (taps) {
 #pragma unroll
                 for (int i = 0; i < B_IT; ++i) {
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i)
-                wdma16_buf(srd_b, Bb + (i * 4 + wave) * 1024, lb_eff[i], l_soff_b);
+                wdma16_buf(srd_b, Bb + (i * NW + wave) * 1024, lb_eff[i], l_soff_b);
             l_soff_a += BKM * prm.K * ES;
             l_soff_b += BKM * prm.C * ES;
             return;
@@ -251,7 +283,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
             const bool ok = m < mend && a_colok[i];
             const void* g = ok ? reinterpret_cast<const void*>(dy + (long)m * prm.K + a_col[i])
                                : reinterpret_cast<const void*>(zero);
-            wdma16(g, Ab + (i * 4 + wave) * 1024);
+            wdma16(g, Ab + (i * NW + wave) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
@@ -274,7 +306,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
                 if (ok) b_reg[i] = *reinterpret_cast<const uint4*>(x + off);
             } else {
                 const void* g = ok ? reinterpret_cast<const void*>(x + off) : reinterpret_cast<const void*>(zero);
-                wdma16(g, Bb + (i * 4 + wave) * 1024);
+                wdma16(g, Bb + (i * NW + wave) * 1024);
             }
         }
     };
@@ -291,7 +323,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
                     for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], psc[i][e], psh[i][e]), 0.f);
                     v = pack16<T>(f);
                 }
-                *reinterpret_cast<uint4*>(Bb + (i * 4 + wave) * 1024 + lane * 16) = v;
+                *reinterpret_cast<uint4*>(Bb + (i * NW + wave) * 1024 + lane * 16) = v;
             }
         }
     };
@@ -317,9 +349,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < TJ; ++tj) {
-                    mma32<T>(acc[ti][tj], af[ti], bf[tj]);
-                }
+                for (int tj = 0; tj < TJ; ++tj) mma32<T>(acc[ti][tj], af[ti], bf[tj]);
         }
     };
 
@@ -328,23 +358,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
     if constexpr (!XPRO) {
         constexpr int DMA_PER_SLAB = A_IT + B_IT;
         static_assert(DMA_PER_SLAB >= 2 && DMA_PER_SLAB <= 4, "vmcnt literal table");
-        fetch(mbeg, 0);
-        if (nk > 1) fetch(mbeg + BKM, 1);
-        int st_c = 0, st_f = 2;
+        // NST stages: slab kt is consumed while kt+1 .. kt+NST-2 are in flight
+        constexpr int NST = Cfg::NST, AHEAD = NST - 1;
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i)
+            if (i < nk) fetch(mbeg + i * BKM, i);
+        int st_c = 0, st_f = AHEAD;
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) {
-                if constexpr (DMA_PER_SLAB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if constexpr (DMA_PER_SLAB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            // wait until only the slabs after kt are outstanding (DMA pieces complete in order)
+            const int rem = min(nk - 1 - kt, AHEAD - 1);
+            if (rem >= 2) wait_vmcnt<2 * DMA_PER_SLAB>();
+            else if (rem == 1) wait_vmcnt<DMA_PER_SLAB>();
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 2 < nk) fetch(mbeg + (kt + 2) * BKM, st_f);
+            // MFMAs of slab kt first, then the DMA requests of slab kt+NST-1 (its stage was read in kt-1, every wave is
+            // past this iteration's barrier): a wave stalls in the issue of `buffer_load ... lds` while earlier pieces
+            // land, and with the requests ahead of the MFMAs all waves of the workgroup sat in that stall together --
+            // measured DMA-only + MFMA-only = total; in this order 704 -> 845 TFLOP/s (128 x 128), 759 -> 997 (256 x 256).
+#if MSFWSI_FETCH_FIRST
+            if (kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
             compute(st_c);
-            st_c = st_c == 2 ? 0 : st_c + 1;
-            st_f = st_f == 2 ? 0 : st_f + 1;
+#else
+            compute(st_c);
+            if (kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
+#endif
+            st_c = st_c == NST - 1 ? 0 : st_c + 1;
+            st_f = st_f == NST - 1 ? 0 : st_f + 1;
         }
     } else {
         fetch(mbeg, 0);
@@ -374,13 +414,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm) {
 }
 
 long g_wgrad_lin = 1;  // msfwsi_set_tuning(2, .): 0 = always the generic staging
+long g_wgrad_big = 1;  // msfwsi_set_tuning(6, .): 0 = never the 256 x 256 tile
 
 // workgroups of `kern` that fit the device at once (all splits carry equal work, so a grid that overshoots this by
 // one workgroup costs a whole second round: measured 0.75 vs 0.56 ms for 1025 vs 1020 workgroups)
 template <typename K>
-int resident_slots(K kern, int lds_bytes) {
+int resident_slots(K kern, int threads, int lds_bytes) {
     int per_cu = 0, dev = 0, ncu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, (size_t)lds_bytes) != hipSuccess) per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, (size_t)lds_bytes) != hipSuccess) per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         ncu = 0;
@@ -397,7 +438,25 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
     if (tiles > 0x7fffffffL) return MSFWSI_EINVAL;
     constexpr int lds_pro = WgradCfg<T, BI, BJ, true>::LDS_BYTES;
     constexpr int lds_dma = WgradCfg<T, BI, BJ, false>::LDS_BYTES;
+    constexpr int threads = 64 * Cfg::NW;
     const bool pro = prm.pro_scale != nullptr;
+    if constexpr (lds_dma > 65536 || lds_pro > 65536) {  // more than the default dynamic LDS limit: raise it once
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipSuccess;
+            if (lds_pro > 65536)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, true, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_pro);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, false, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+    }
     // pixel splits: fill the resident workgroup slots once, never overshoot them (target_blocks > 0 overrides)
     long splits;
     if (target_blocks > 0) {
@@ -406,8 +465,8 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
         static int slots_pro = 0, slots_dma = 0;  // same occupancy for the generic and the linear DMA instance
         int& slots = pro ? slots_pro : slots_dma;
         if (slots == 0)
-            slots = pro ? resident_slots(wgrad_kernel<T, BI, BJ, true, false>, lds_pro)
-                        : resident_slots(wgrad_kernel<T, BI, BJ, false, true>, lds_dma);
+            slots = pro ? resident_slots(wgrad_kernel<T, BI, BJ, true, false>, threads, lds_pro)
+                        : resident_slots(wgrad_kernel<T, BI, BJ, false, true>, threads, lds_dma);
         splits = slots / tiles;
     }
     const long max_splits = (prm.M + Cfg::BKM - 1) / Cfg::BKM;
@@ -423,13 +482,13 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
                      prm.R <= 3 && prm.S <= 3 && prm.R == 2 * prm.pad + 1 && prm.S == 2 * prm.pad + 1 &&
                      (rows + 2L * prm.W + 4) * (prm.C > prm.K ? prm.C : prm.K) * (long)sizeof(T) < 0x7fffffffL;
     if (pro)
-        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, true, false>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
+        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, true, false>), dim3((unsigned)tiles, (unsigned)splits), dim3(threads),
                            lds_pro, stream, prm);
     else if (lin)
-        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, false, true>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
+        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, false, true>), dim3((unsigned)tiles, (unsigned)splits), dim3(threads),
                            lds_dma, stream, prm);
     else
-        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, false, false>), dim3((unsigned)tiles, (unsigned)splits), dim3(256),
+        hipLaunchKernelGGL((wgrad_kernel<T, BI, BJ, false, false>), dim3((unsigned)tiles, (unsigned)splits), dim3(threads),
                            lds_dma, stream, prm);
     return msfwsi_launch_status();
 }
@@ -437,6 +496,7 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v) { g_wgrad_lin = v; }
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long v) { g_wgrad_big = v; }
 
 extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw,
                                  const float* pro_scale, const float* pro_shift, int target_blocks,
@@ -461,6 +521,13 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool small_i = d->K <= 64;
     const bool small_j = prm.Jtot <= 64;
+    // 2-byte types, both extents in whole 256-wide tiles, no recomputed prologue: the eight-wave tile
+    const bool big = g_wgrad_big && d->dtype != MSFWSI_DT_F32 && d->K % 256 == 0 && prm.Jtot % 256 == 0 &&
+                     pro_scale == nullptr;
+    if (big) {
+        if (d->dtype == MSFWSI_DT_BF16) return launch_wgrad<__bf16, 256, 256>(prm, target_blocks, st);
+        return launch_wgrad<_Float16, 256, 256>(prm, target_blocks, st);
+    }
     MSFWSI_WITH_T(d->dtype, {
         if (small_i && small_j) return launch_wgrad<T, 64, 64>(prm, target_blocks, st);
         if (small_i) return launch_wgrad<T, 64, 128>(prm, target_blocks, st);

@@ -115,6 +115,42 @@ def test_wgrad_production_pixel_counts(hip_lib, dt, geom):
     assert rel(dw.cpu().permute(0, 3, 1, 2), ref) < 2e-5
 
 
+@pytest.mark.parametrize("dt", LOWP)
+@pytest.mark.parametrize("geom", [
+    # N, H, W, C, K, R, stride   (both extents whole multiples of 256: the 256 x 256 tile)
+    (64, 14, 14, 256, 256, 3, 1),     # linear addressing, image-border taps, 9 column tiles
+    (64, 14, 14, 1024, 256, 1, 1),    # 1x1, four column tiles
+    (96, 7, 7, 512, 2048, 1, 1),      # eight row tiles
+    (48, 14, 14, 256, 256, 3, 2),     # stride 2: generic staging
+    (3, 7, 7, 256, 512, 1, 1),        # fewer pixels than one slab per resident workgroup
+])
+def test_wgrad_big_tile(hip_lib, dt, geom):
+    """the 256 x 256 / 16-wave weight-gradient instance against fp64, with the 128 x 128 instance on the same operands
+    beside it"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K, R, st = geom
+    pad = R // 2
+    g = torch.Generator().manual_seed(37)
+    d = kn.conv_desc(dt, N, H, W, Cc, K, R, R, st, pad)
+    x = rnd((N, Cc, H, W), dt, g)
+    dy = rnd((N, K, d.P, d.Q), dt, g, 0.05)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (K, Cc, R, R), dy.double(), stride=st, padding=pad)
+    xd, dyd = nhwc(x).to(dt).cuda(), nhwc(dy).to(dt).cuda()
+    got = {}
+    try:
+        for big in (1, 0):
+            hip_lib.msfwsi_set_tuning(6, big)
+            dw = torch.zeros(K, R, R, Cc, device="cuda")
+            kn.conv_wgrad(d, xd, dyd, dw)
+            torch.cuda.synchronize()
+            got[big] = dw.cpu().permute(0, 3, 1, 2)
+    finally:
+        hip_lib.msfwsi_set_tuning(6, 1)
+    for key, val in got.items():
+        assert rel(val, ref) < 2e-5, key
+
+
 # ------------------------------------------------------------------------------------------------
 # beyond 2^31 bytes
 # ------------------------------------------------------------------------------------------------
