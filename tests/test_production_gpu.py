@@ -5,6 +5,7 @@ runs -- everything the small-shape tests of test_kernels_gpu.py never reach:
     with msfwsi_set_tuning(0, 1)) in every epilogue class: forward + statistics (EPI 0), forward + BatchNorm apply +
     identity + ReLU + gate bits (EPI 1), its two-source form, input gradient plain / gated by activation / gated by
     bits (EPI 0), two-source input gradient, strided residual (EPI 3) -- against torch fp64 on the CPU;
+  * the 256x256 / 16-wave weight-gradient tile of the deep layers against the 128x128 one;
   * the weight-gradient kernel at production pixel counts (hundreds of pixel splits, linear-addressing path);
   * tensors beyond 2^31 BYTES (layer-1 activations of config 2 are 6.6 GB): the kernels address operands with 32-bit
     per-lane byte offsets against a per-workgroup 64-bit base, so a wrap would show as wrong images -- checked on whole
