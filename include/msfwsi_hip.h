@@ -114,6 +114,10 @@ int msfwsi_conv_dgrad2(const msfwsi_conv_desc* d, const void* dy, const void* w_
  * msfwsi_conv_dgrad without prologue/bias/gapg; `supported` tells whether a geometry qualifies.
  * Replaces: conv3x3 forward / backward(input), src/models/resnet.py:25-28. */
 int msfwsi_conv3x3_supported(const msfwsi_conv_desc* d);
+/* 1 if msfwsi_conv3x3_fwd / _dgrad serve this geometry with the weights-stationary persistent kernel (2-byte types,
+ * 64 -> 64 channels: all nine taps of the filter resident in LDS, each halo pixel loaded once); callers then prefer
+ * them over msfwsi_conv_fwd / msfwsi_conv_dgrad. */
+int msfwsi_conv3x3_stationary(const msfwsi_conv_desc* d);
 int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, double* stats, int nshard,
                        void* stream);
 int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx, const void* resid,
@@ -361,7 +365,8 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * kernels switch from the 128x128 / 4-wave tile to the 256x128 / 8-wave tile; key 1 = 0 disables the pure-DMA
  * (buffer_load ... lds) conv kernel, key 2 = 0 the linear-addressing weight-gradient path, key 4 = grid size (in
  * 128x128 tiles) below which 128x64 tiles are used, key 5 = 0 disables the parity-class form of the stride-2 3x3 input
- * gradient, key 6 = 0 the 256x256 / 16-wave weight-gradient tile (A/B measurements). */
+ * gradient, key 6 = 0 the 256x256 / 16-wave weight-gradient tile, key 9 = 0 the weights-stationary 3x3
+ * kernel of the 64 -> 64 layers (A/B measurements). */
 int msfwsi_set_tuning(int key, long value);
 
 /* library identification: returns the gfx target string the code objects were built for */

@@ -362,6 +362,342 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const C3Params prm) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels (layer1 of every ResNet here): WEIGHTS-STATIONARY, persistent workgroups.
+//
+// All nine taps of the 64 x 64 filter (72 KiB in a 2-byte type) stay in LDS for the life of the workgroup, which walks
+// a contiguous range of 256-pixel tiles of the batch's global raster (images back to back: a tap that would cross an
+// image's top / bottom / left / right edge zeroes the fragment, as the horizontal edges always did).  Per tile the
+// 384 halo pixels (256 + 2W + 2, both channel slabs, 48 KiB) are loaded ONCE -- by ordinary global loads into
+// registers while the previous tile computes, written to LDS between two barriers -- and the 72 MFMAs of a wave run
+// back to back from LDS: four barriers per tile instead of one per (slab, tap) step, no LDS-DMA request in the MFMA
+// stream (a wave stalls in the issue of one), 9x less L2 -> LDS traffic than the gather kernel, and the halo rows a
+// tile shares with its predecessor come from the same CU's L2 slice.  The BatchNorm sums accumulate in registers
+// over all tiles of the workgroup and reach memory with one set of atomics.
+// ---------------------------------------------------------------------------------------------------------------
+struct C3WParams {
+    const void* src;   // [Mtot][64]
+    const void* wgt;   // [64][3][3][64]
+    void* out;         // [Mtot][64]
+    double* stats;
+    const void* resid;
+    const void* mask_c;
+    const float* mask_scale;
+    const float* mask_shift;
+    int H, W;
+    long Mtot;
+    int ntiles, tiles_per_wg, nshard;
+    FastDiv div_w, div_h;
+};
+
+#ifndef MSFWSI_C3W_BM
+#define MSFWSI_C3W_BM 256  // 512 (halo 640 rows, 4 accumulator tiles per wave) spills: measured 430 vs 764 TFLOP/s
+#endif
+template <typename T>
+struct C3WCfg {
+    static constexpr int VEC = ElemTraits<T>::VEC, BK = ElemTraits<T>::BK;  // 8, 32
+    static constexpr int BM = MSFWSI_C3W_BM, BN = 64, CH = 64, NW = 8, WM = 4, WN = 2, TM = BM / WM / 32;
+    static constexpr int MAXW = 56;
+    static constexpr int HALO_ROWS = ((BM + 2 * MAXW + 2 + 63) / 64) * 64;  // 640 (BM = 512), 384 (256)
+    static constexpr int PLANE = HALO_ROWS * 64 + 128;  // one channel slab of the halo; +128 B: the two slabs of a pixel
+                                                        // (written by neighbouring lanes) start 32 banks apart
+    static constexpr int W_TILE = 4096;                 // one (slab, tap) weight tile: [64 n][64 B] or [32 k][128 B]
+    static constexpr int W_BYTES = 18 * W_TILE;
+    static constexpr int A_BYTES = 2 * PLANE;
+    static constexpr int LDC = BN + VEC;
+    static constexpr int C_BYTES = BM * LDC * (int)sizeof(T) + NW * BN * 2 * (int)sizeof(float);
+    static constexpr int LDS_BYTES = W_BYTES + (A_BYTES > C_BYTES ? A_BYTES : C_BYTES);
+    static constexpr int A_LOADS = HALO_ROWS * 8 / (64 * NW);  // 16-byte chunks per thread and tile: 10 (6)
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+    static_assert(sizeof(T) == 2 && A_LOADS * 64 * NW == HALO_ROWS * 8, "2-byte types, whole chunks per thread");
+};
+
+template <typename T, bool DGRAD>
+__global__ __launch_bounds__(512) void conv3x3_ws_kernel(const C3WParams prm) {
+    typedef C3WCfg<T> Cfg;
+    constexpr int VEC = Cfg::VEC, BM = Cfg::BM, BN = Cfg::BN, NW = Cfg::NW, WM = Cfg::WM, TM = Cfg::TM;
+    constexpr int LDC = Cfg::LDC, NT = 64 * NW, PLANE = Cfg::PLANE, AL = Cfg::A_LOADS;
+    constexpr int ROWB = 128;  // natural weight row (DGRAD): 64 input channels
+    typedef typename Frag3<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ws = smem;                                     // 18 weight tiles
+    char* As = smem + Cfg::W_BYTES;                      // 2 halo planes
+    T* Cs = reinterpret_cast<T*>(smem + Cfg::W_BYTES);   // epilogue tile over the halo planes
+    float* red = reinterpret_cast<float*>(smem + Cfg::W_BYTES + BM * LDC * (int)sizeof(T));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int W = prm.W, H = prm.H;
+    const T* __restrict__ src = reinterpret_cast<const T*>(prm.src);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(prm.wgt);
+    T* __restrict__ out = reinterpret_cast<T*>(prm.out);
+    const T* __restrict__ resid = reinterpret_cast<const T*>(prm.resid);
+    const T* __restrict__ mask_c = reinterpret_cast<const T*>(prm.mask_c);
+
+    const int t_beg = blockIdx.x * prm.tiles_per_wg;
+    const int t_end = min(prm.ntiles, t_beg + prm.tiles_per_wg);
+    if (t_beg >= t_end) return;
+
+    // ---- weights -> LDS, once (18 tiles x 4 KiB = 72 pieces of 1 KiB: nine per wave) ----
+    for (int g = wave; g < 72; g += NW) {
+        const int wt = g >> 2, q = g & 3;  // tile (slab, tap), quarter
+        const int sl = wt / 9, t = wt - sl * 9;
+        const void* gp;
+        if (!DGRAD) {
+            const int row = q * 16 + (lane >> 2);  // output channel n
+            const int kc = swz3(row, lane & 3);
+            gp = wgt + ((long)row * 9 + t) * 64 + sl * 32 + kc * VEC;
+        } else {
+            const int krow = q * 8 + (lane >> 3);  // forward output channel within the slab
+            const int cp = lane & 7;
+            const int gsw = (krow >> 1) & 1;
+            const int n = ((((cp >> 2) ^ gsw) << 2) | (cp & 3)) * VEC;
+            gp = wgt + ((long)(sl * 32 + krow) * 9 + (8 - t)) * 64 + n;  // flipped tap, see conv3x3_kernel
+        }
+        dma16c(gp, Ws + g * 1024);
+    }
+
+    // ---- per-thread staging map of the halo: chunk i*512 + tid -> (halo row, slab, 16-byte chunk) ----
+    int a_lds[AL];
+    int a_hr[AL], a_col[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int idx = i * NT + tid;
+        const int hr = idx >> 3, c8 = idx & 7;
+        a_hr[i] = hr;
+        a_col[i] = c8 * VEC;
+        a_lds[i] = (c8 >> 2) * PLANE + hr * 64 + swz3(hr, c8 & 3) * 16;
+    }
+    uint4 a_reg[AL];
+    auto load_A = [&](int tile) {
+        const long g0 = (long)tile * BM - W - 1;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const long g = g0 + a_hr[i];
+            a_reg[i] = make_uint4(0, 0, 0, 0);
+            if (g >= 0 && g < prm.Mtot && a_hr[i] < BM + 2 * W + 2)
+                a_reg[i] = *reinterpret_cast<const uint4*>(src + g * 64 + a_col[i]);
+        }
+    };
+
+    // epilogue row-chunk map
+    constexpr int CPR = BN / VEC, RPP = NT / CPR, NP = BM / RPP;  // 8 chunks per row, 64 rows per pass, 4 passes
+    const int cc = tid % CPR, rr = tid / CPR;
+    const int ncol = cc * VEC;
+    float ssum[VEC], ssq[VEC], msc[VEC], msh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
+    if (mask_c != nullptr) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            msc[e] = prm.mask_scale[ncol + e];
+            msh[e] = prm.mask_shift[ncol + e];
+        }
+    }
+
+    load_A(t_beg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights (and the first halo) have landed
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        __syncthreads();  // the previous tile's epilogue is done with the region the halo planes share
+#pragma unroll
+        for (int i = 0; i < AL; ++i) *reinterpret_cast<uint4*>(As + a_lds[i]) = a_reg[i];
+        __syncthreads();
+        // next tile's halo and this tile's epilogue operands: in flight while the MFMAs run
+        if (tile + 1 < t_end) load_A(tile + 1);
+        uint4 r_res[NP], r_msk[NP];
+        const long m0 = (long)tile * BM;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const long m = m0 + rr + ps * RPP;
+            if (m < prm.Mtot) {
+                if (resid != nullptr) r_res[ps] = *reinterpret_cast<const uint4*>(resid + m * 64 + ncol);
+                if (mask_c != nullptr) r_msk[ps] = *reinterpret_cast<const uint4*>(mask_c + m * 64 + ncol);
+            }
+        }
+
+        // image-edge flags of the TM pixels this lane owns as MFMA columns
+        bool e_top[TM], e_bot[TM], e_l[TM], e_r[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const unsigned g = (unsigned)(m0 + (wm * TM + tm) * 32 + l31);
+            const unsigned yy = fast_div(g, prm.div_w);
+            const unsigned x = g - yy * (unsigned)W;
+            const unsigned y = yy - fast_div(yy, prm.div_h) * (unsigned)H;
+            e_top[tm] = y == 0;
+            e_bot[tm] = y == (unsigned)(H - 1);
+            e_l[tm] = x == 0;
+            e_r[tm] = x == (unsigned)(W - 1);
+        }
+
+        f32x16 acc[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
+
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s2 = t - r * 3;
+                const int roff = r * W + s2;
+                const char* Ab = As + sl * PLANE;
+                const char* Bb = Ws + (sl * 9 + t) * Cfg::W_TILE;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    frag_t xf[TM], wf;
+                    const int cidx = ks * 2 + lh;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        const int row = (wm * TM + tm) * 32 + l31 + roff;
+                        xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * 64 + swz3(row, cidx) * 16);
+                        const bool kill = (r == 0 && e_top[tm]) || (r == 2 && e_bot[tm]) || (s2 == 0 && e_l[tm]) ||
+                                          (s2 == 2 && e_r[tm]);
+                        if (kill) xf[tm] = frag_t{};
+                    }
+                    const int ncl = wn * 32;
+                    if (!DGRAD) {
+                        const int row = ncl + l31;
+                        wf = *reinterpret_cast<const frag_t*>(Bb + row * 64 + swz3(row, cidx) * 16);
+                    } else {
+                        const int li = lane & 15, G = lane >> 4;
+                        const int q = li >> 2, pp = li & 3;
+                        const int kbase = ks * 16 + (G >> 1) * 8 + q;
+                        const int cb = (ncl + (G & 1) * 16 + pp * 4) * 2;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(Bb + nat_off3<ROWB>(kbase, cb)));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(Bb + nat_off3<ROWB>(kbase + 4, cb)));
+                        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        wf = __builtin_bit_cast(frag_t, both);
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) mma32<T>(acc[tm], wf, xf[tm]);
+                }
+            }
+        }
+        __syncthreads();  // every wave has read its last halo fragment: the region becomes the output tile
+
+        // ---- epilogue: accumulators -> LDS tile -> 16-byte row chunks ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nc = wn * 32 + 8 * g + 4 * lh;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = (wm * TM + tm) * 32 + l31;
+                T* dst = Cs + row * LDC + nc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) store_elem<T>(dst, e, acc[tm][g * 4 + e]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int row = rr + ps * RPP;
+            const long m = m0 + row;
+            if (m < prm.Mtot) {
+                uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
+                const long off = m * 64 + ncol;
+                if (resid != nullptr) {
+                    float f[VEC], g[VEC];
+                    unpack16<T>(v, f);
+                    unpack16<T>(r_res[ps], g);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) f[e] += g[e];
+                    v = pack16<T>(f);
+                }
+                if (mask_c != nullptr) {
+                    float f[VEC], cv[VEC];
+                    unpack16<T>(v, f);
+                    unpack16<T>(r_msk[ps], cv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if (!(fmaf(cv[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
+                        ssum[e] += f[e];
+                        ssq[e] = fmaf(f[e], cv[e], ssq[e]);
+                    }
+                    v = pack16<T>(f);
+                    *reinterpret_cast<uint4*>(out + off) = v;
+                } else {
+                    *reinterpret_cast<uint4*>(out + off) = v;
+                    if (prm.stats != nullptr) {
+                        float f[VEC];
+                        unpack16<T>(v, f);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            ssum[e] += f[e];
+                            ssq[e] = fmaf(f[e], f[e], ssq[e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (prm.stats != nullptr) {
+        __syncthreads();  // the last tile's row passes have read the tile the scratch follows
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+            for (int off = CPR; off < 64; off <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], off, 64);
+                ssq[e] += __shfl_xor(ssq[e], off, 64);
+            }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                red[(wave * BN + lane * VEC + e) * 2 + 0] = ssum[e];
+                red[(wave * BN + lane * VEC + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += NT) {
+            const int col = i % BN, which = i / BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[(w * BN + col) * 2 + which];
+            double* dst = prm.stats + ((long)(blockIdx.x % prm.nshard) * 2 + which) * 64 + col;
+            atomicAdd(dst, (double)t);
+        }
+    }
+}
+
+long g_c3_stationary = 1;  // msfwsi_set_tuning(9, .): 0 = the 64 -> 64 layers on the per-tile kernels
+
+template <typename T, bool DGRAD>
+int launch_c3w(C3WParams& prm, hipStream_t stream) {
+    typedef C3WCfg<T> Cfg;
+    prm.ntiles = (int)((prm.Mtot + Cfg::BM - 1) / Cfg::BM);
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        ncu = 256;
+    (void)hipGetLastError();
+    // one persistent workgroup per CU (120 KiB of LDS each), contiguous tile ranges; short launches spread thinner
+    prm.tiles_per_wg = (prm.ntiles + ncu - 1) / ncu;
+    const int nblk = (prm.ntiles + prm.tiles_per_wg - 1) / prm.tiles_per_wg;
+    auto kern = conv3x3_ws_kernel<T, DGRAD>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), Cfg::LDS_BYTES, stream, prm);
+    return msfwsi_launch_status();
+}
+
+// the weights-stationary kernel serves: 2-byte types, 64 -> 64 channels, 3x3 / stride 1 / pad 1, W <= 56
+bool c3w_ok(const msfwsi_conv_desc* d) {
+    return g_c3_stationary && d->dtype != MSFWSI_DT_F32 && d->C == 64 && d->K == 64 && d->W <= C3WCfg<__bf16>::MAXW &&
+           d->W >= 3 && d->H >= 3 && (long)d->N * d->H * d->W * 64 * 2 < (1L << 46);
+}
+
 template <typename T, int BN, bool DGRAD>
 int launch_c3(C3Params& prm, hipStream_t stream) {
     typedef C3Cfg<T, BN, DGRAD> Cfg;
@@ -395,6 +731,12 @@ extern "C" int msfwsi_conv3x3_supported(const msfwsi_conv_desc* d) {
     return 1;
 }
 
+// 1 if the weights-stationary persistent kernel would serve this geometry (callers prefer it over the gather kernel)
+extern "C" int msfwsi_conv3x3_stationary(const msfwsi_conv_desc* d) {
+    return d != nullptr && msfwsi_conv3x3_supported(d) && c3w_ok(d) ? 1 : 0;
+}
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(long v) { g_c3_stationary = v; }
+
 extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, double* stats,
                                   int nshard, void* stream) {
     if (!msfwsi_conv3x3_supported(d)) return MSFWSI_EUNSUPPORTED;
@@ -404,6 +746,14 @@ extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, cons
     prm.src = x; prm.wgt = w; prm.out = y; prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C; prm.Nout = d->K;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (c3w_ok(d)) {
+        C3WParams wp{};
+        wp.src = x; wp.wgt = w; wp.out = y; wp.stats = stats; wp.nshard = prm.nshard;
+        wp.H = d->H; wp.W = d->W; wp.Mtot = (long)d->N * d->H * d->W;
+        wp.div_w = make_fastdiv((unsigned)d->W); wp.div_h = make_fastdiv((unsigned)d->H);
+        if (d->dtype == MSFWSI_DT_BF16) return launch_c3w<__bf16, false>(wp, st);
+        return launch_c3w<_Float16, false>(wp, st);
+    }
     MSFWSI_WITH_T(d->dtype, return d->K <= 64 ? launch_c3<T, 64, false>(prm, st) : launch_c3<T, 128, false>(prm, st));
     return MSFWSI_EINVAL;
 }
@@ -422,6 +772,16 @@ extern "C" int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, c
     prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->K; prm.Nout = d->C;  // stride 1: same H, W
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (c3w_ok(d)) {
+        C3WParams wp{};
+        wp.src = dy; wp.wgt = w; wp.out = dx; wp.resid = resid;
+        wp.mask_c = mask_c; wp.mask_scale = mask_scale; wp.mask_shift = mask_shift;
+        wp.stats = sums; wp.nshard = prm.nshard;
+        wp.H = d->H; wp.W = d->W; wp.Mtot = (long)d->N * d->H * d->W;
+        wp.div_w = make_fastdiv((unsigned)d->W); wp.div_h = make_fastdiv((unsigned)d->H);
+        if (d->dtype == MSFWSI_DT_BF16) return launch_c3w<__bf16, true>(wp, st);
+        return launch_c3w<_Float16, true>(wp, st);
+    }
     MSFWSI_WITH_T(d->dtype, return d->C <= 64 ? launch_c3<T, 64, true>(prm, st) : launch_c3<T, 128, true>(prm, st));
     return MSFWSI_EINVAL;
 }

@@ -1127,6 +1127,7 @@ int check_desc(const msfwsi_conv_desc* d) {
 
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(long v);
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
@@ -1135,6 +1136,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 6) {
         msfwsi_wgrad_set_big(value);
+        return MSFWSI_OK;
+    }
+    if (key == 9) {
+        msfwsi_c3_set_stationary(value);
         return MSFWSI_OK;
     }
     if (key == 4) {

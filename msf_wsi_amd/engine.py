@@ -411,7 +411,8 @@ class Engine:
             pro = None
         if pad_c and pro is None and bias is None and self.stem_run and self._stem_run_fwd(op, xin, c, stats, dtype, pad_c):
             pass  # stem: 7 row taps over runs of contiguous pixels on the pure-DMA kernel
-        elif self.halo3x3_fwd and pro is None and bias is None and not pad_c and kn.conv3x3_supported(d):
+        elif (pro is None and bias is None and not pad_c
+              and (kn.conv3x3_stationary(d) if not self.halo3x3_fwd else kn.conv3x3_supported(d))):
             kn.conv3x3_fwd(d, xin, w, c, stats=stats)  # input patch staged once per channel slab, 9 taps reuse it
         else:
             kn.conv_fwd(d, xin, w, c, pro=pro, bias=bias.data if bias is not None else None, stats=epi_stats)

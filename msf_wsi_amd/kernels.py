@@ -181,6 +181,8 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
         return f"wgrad_kernelI{tcode}Li{bi}ELi{bj}ELb{int(pro)}ELb{int(lin)}E"
     dgrad = kind == "conv_dgrad"
     if halo:
+        if es == 2 and d.C == 64 and d.K == 64 and os.environ.get("MSFWSI_C3_STATIONARY", "1") != "0":
+            return f"conv3x3_ws_kernelI{tcode}Lb{int(dgrad)}E"
         bn = 64 if (d.C if dgrad else d.K) <= 64 else 128
         return f"conv3x3_kernelI{tcode}Li{bn}ELb{int(dgrad)}E"
     M = d.N * (d.H * d.W if dgrad else d.P * d.Q)
@@ -946,6 +948,11 @@ def unpad_add(src, dst, rows, Cn, CP):
 # ------------------------------------------------------------------------------------------------
 def conv3x3_supported(d: ConvDesc) -> bool:
     return bool(_lib.load().msfwsi_conv3x3_supported(C.byref(d)))
+
+
+def conv3x3_stationary(d: ConvDesc) -> bool:
+    """the weights-stationary persistent kernel serves this geometry (64 -> 64 channels, 2-byte types)"""
+    return bool(_lib.load().msfwsi_conv3x3_stationary(C.byref(d)))
 
 
 def conv3x3_fwd(d: ConvDesc, x, w, y, stats=None):

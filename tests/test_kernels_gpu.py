@@ -674,6 +674,12 @@ HALO = [  # N, H, W, C, K     (3x3, stride 1, pad 1)
     (5, 14, 14, 64, 256),    # one 196-pixel image per 256-row tile
     (2, 20, 23, 32, 96),     # odd width, HW not a multiple of the tile, K not a tile multiple
     (1, 16, 8, 96, 32),
+    # 64 -> 64 channels: the weights-stationary persistent kernel (2-byte types); tiles run over the batch's global
+    # raster, so these put image boundaries inside tiles
+    (5, 14, 14, 64, 64),     # 196-pixel images: every tile spans two of them
+    (3, 20, 23, 64, 64),     # odd width
+    (1, 12, 11, 64, 64),     # a single ragged tile
+    (2, 9, 56, 64, 64),      # the widest row the halo holds
 ]
 
 

@@ -152,6 +152,47 @@ def test_wgrad_big_tile(hip_lib, dt, geom):
         assert rel(val, ref) < 2e-5, key
 
 
+@pytest.mark.parametrize("dt", LOWP)
+def test_conv3x3_stationary_persistent_ranges(hip_lib, dt):
+    """the weights-stationary 64 -> 64 kernel with several tiles per persistent workgroup (784 tiles on 256 CUs), forward
+    with BatchNorm sums and gated input gradient, against fp64 and against the gather kernels on the same operands"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc = 64, 56, 56, 64
+    g = torch.Generator().manual_seed(41)
+    d = kn.conv_desc(dt, N, H, W, Cc, Cc, 3, 3, 1, 1)
+    assert kn.conv3x3_stationary(d)
+    x = rnd((N, Cc, H, W), dt, g)
+    w = rnd((Cc, Cc, 3, 3), dt, g, 1.0 / math.sqrt(Cc * 9))
+    ref = F.conv2d(x.double(), w.double(), None, stride=1, padding=1)
+    xd, wd = nhwc(x).to(dt).cuda(), nhwc(w).to(dt).cuda()
+    y, y2 = (torch.empty(N, H, W, Cc, dtype=dt, device="cuda") for _ in range(2))
+    st = kn.new_stats(Cc)
+    kn.conv3x3_fwd(d, xd, wd, y, stats=st)
+    kn.conv_fwd(d, xd, wd, y2)
+    torch.cuda.synchronize()
+    assert rel(y.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt)
+    assert rel(y.float(), y2.float()) < 1e-3  # same products, another summation order, one rounding to the storage type
+    yy = y.double().reshape(-1, Cc)
+    assert torch.allclose(st.sum(0)[0], yy.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st.sum(0)[1], (yy * yy).sum(0), rtol=1e-5, atol=1e-3)
+    # input gradient, gated by the producer's activation, with its BatchNorm-backward sums
+    dy = rnd((N, Cc, H, W), dt, g)
+    c = rnd((N, Cc, H, W), dt, g)
+    sc, sh = torch.rand(Cc, generator=g) - 0.3, torch.randn(Cc, generator=g) * 0.3
+    refd = torch.nn.grad.conv2d_input((N, Cc, H, W), w.double(), dy.double(), stride=1, padding=1)
+    refd = refd * ((c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0)
+    dyd, cd = nhwc(dy).to(dt).cuda(), nhwc(c).to(dt).cuda()
+    dx = torch.empty(N, H, W, Cc, dtype=dt, device="cuda")
+    sums = kn.new_stats(Cc)
+    kn.conv3x3_dgrad(d, dyd, wd, dx, mask=(cd, sc.cuda(), sh.cuda()), sums=sums)
+    torch.cuda.synchronize()
+    assert rel(dx.float().cpu().permute(0, 3, 1, 2), refd) < 2 * tol(dt)
+    gd = dx.double().reshape(-1, Cc)
+    assert torch.allclose(sums.sum(0)[0], gd.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sums.sum(0)[1], (gd * cd.double().reshape(-1, Cc)).sum(0), rtol=1e-5, atol=1e-3)
+
+
 # ------------------------------------------------------------------------------------------------
 # beyond 2^31 bytes
 # ------------------------------------------------------------------------------------------------

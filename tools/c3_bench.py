@@ -1,0 +1,53 @@
+"""GPU box: the 64 -> 64 3x3 layers of the bench workload (N = 4096 target tiles of 56 x 56): weights-stationary
+persistent kernel against the gather kernels.   python tools/c3_bench.py"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from msf_wsi_amd import _lib, kernels as kn  # noqa: E402
+
+
+def timed(fn):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 5
+
+
+def main():
+    lib = _lib.load()
+    dt = torch.bfloat16
+    for N in (4096, 256):
+        H = W = 56
+        Cc = 64
+        d = kn.conv_desc(dt, N, H, W, Cc, Cc, 3, 3, 1, 1)
+        x = torch.randn(N * H * W * Cc, device="cuda").to(dt)
+        w = (torch.randn(Cc * 9 * Cc, device="cuda") * 0.05).to(dt)
+        y = torch.empty_like(x)
+        c = torch.randn(N * H * W * Cc, device="cuda").to(dt)
+        sc, sh = torch.rand(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        stats, sums = kn.new_stats(Cc), kn.new_stats(Cc)
+        flop = 2.0 * N * H * W * Cc * 9 * Cc
+        line = f"N{N} 56x56 C64->K64 3x3: "
+        for on in (0, 1):
+            lib.msfwsi_set_tuning(9, on)
+            f = timed(lambda: kn.conv3x3_fwd(d, x, w, y, stats=stats))
+            g = timed(lambda: kn.conv3x3_dgrad(d, x, w, y, mask=(c, sc, sh), sums=sums))
+            line += f"  stationary={on}: fwd {f:.3f} ms {flop / f / 1e9:5.0f} TF, dgrad(gated) {g:.3f} ms {flop / g / 1e9:5.0f} TF"
+        f = timed(lambda: kn.conv_fwd(d, x, w, y, stats=stats))
+        line += f"  gather fwd {f:.3f} ms {flop / f / 1e9:5.0f} TF"
+        print(line, flush=True)
+    lib.msfwsi_set_tuning(9, 1)
+
+
+if __name__ == "__main__":
+    main()
