@@ -72,7 +72,7 @@ int msfwsi_conv_fwd_post2(const msfwsi_conv_desc* d, const void* x, const void* 
  * sums[shard][2][C] += {sum dx, sum dx*c} (what msfwsi_act_bwd_reduce would compute in a second pass).
  * mask_bits != NULL (instead of mask_c): the gate comes from the bytes msfwsi_conv_fwd_post wrote
  * ([N*H*W][C/vec]); sums slot 0 += sum dx, slot 1 is left alone.
- * resid_stride s > 1: resid is the LOW-resolution tensor [N][(H-1)/s+1][(W-1)/s+1][C] and is added only at pixels
+ * resid_stride s = 2 (others: MSFWSI_EUNSUPPORTED): resid is the LOW-resolution tensor [N][(H-1)/s+1][(W-1)/s+1][C] and is added only at pixels
  * with h % s == w % s == 0 -- the input gradient of a stride-s downsample branch without its zero-stuffed copy.
  * Replaces: autograd's convolution_backward(input) / linear backward(input) (+ threshold_backward and the
  * reduction half of batch_norm_backward) reached through scaler.scale(loss).backward(), ssl_train.py:472. */

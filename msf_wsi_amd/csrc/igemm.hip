@@ -245,13 +245,14 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
             if (resid != nullptr) {
                 if constexpr (LORES) {
                     // pixel m = (n, h, w) of the [N][P][Q] output; the residual lives on the s-strided sub-grid
-                    const int sr = prm.resid_stride;
+                    // the stride is 2 (the only one a ResNet stage boundary has; checked by the entry point): parity
+                    // test and shift instead of two runtime modulos and two divisions per row pass
                     const unsigned n = fast_div((unsigned)m, prm.div_pq);
                     const unsigned rem = (unsigned)m - n * (unsigned)PQ;
                     const unsigned h = fast_div(rem, prm.div_q);
                     const unsigned w = rem - h * (unsigned)prm.Q;
-                    if (h % sr == 0 && w % sr == 0) {
-                        const long lo = (((long)n * Pl + h / sr) * Ql + w / sr) * prm.Nout + ncol;
+                    if (((h | w) & 1u) == 0) {
+                        const long lo = (((long)n * Pl + (h >> 1)) * Ql + (w >> 1)) * prm.Nout + ncol;
                         r_res[pi] = *reinterpret_cast<const uint4*>(resid + lo);
                         r_has[pi] = true;
                     }
@@ -1295,6 +1296,7 @@ extern "C" int msfwsi_conv_dgrad(const msfwsi_conv_desc* d, const void* dy, cons
     if (rc != MSFWSI_OK) return rc;
     MSFWSI_CHECK_ARG(dy != nullptr && w != nullptr && dx != nullptr);
     MSFWSI_CHECK_ARG(resid_stride >= 0 && (resid_stride <= 1 || resid != nullptr));
+    if (resid_stride > 2) return MSFWSI_EUNSUPPORTED;  // the kernel's strided-residual class tests pixel parity
     MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
     MSFWSI_CHECK_ARG(mask_c == nullptr || mask_bits == nullptr);
     MSFWSI_CHECK_ARG((mask_c == nullptr && mask_bits == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
