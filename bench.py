@@ -38,8 +38,9 @@ def pmc_entry(symbol):
     try:
         with open(paths[-1]) as f:
             tab = json.load(f).get("kernels", {})
-        hit = [v for k, v in tab.items() if k in symbol or symbol in k]
-        return dict(hit[0], source=os.path.basename(paths[-1])) if hit else {}
+        hit = sorted(((len(k), v) for k, v in tab.items() if k.strip() and (k in symbol or symbol in k)),
+                     key=lambda kv: -kv[0])  # the longest (most specific) matching name
+        return dict(hit[0][1], source=os.path.basename(paths[-1])) if hit else {}
     except (OSError, ValueError, KeyError):
         return {}
 

@@ -118,8 +118,11 @@ int msfwsi_conv3x3_supported(const msfwsi_conv_desc* d);
  * 64 -> 64 channels: all nine taps of the filter resident in LDS, each halo pixel loaded once); callers then prefer
  * them over msfwsi_conv_fwd / msfwsi_conv_dgrad. */
 int msfwsi_conv3x3_stationary(const msfwsi_conv_desc* d);
+/* pro_scale / pro_shift (both or neither; only where msfwsi_conv3x3_stationary() is 1, else MSFWSI_EUNSUPPORTED): x is
+ * the producer's RAW conv output and the conv sees relu(scale[c] * x + shift[c]) -- conv2 of a block reads bn1+ReLU of
+ * conv1's output without that activation ever being stored (src/models/resnet.py:120-126 fused). */
 int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, double* stats, int nshard,
-                       void* stream);
+                       const float* pro_scale, const float* pro_shift, void* stream);
 int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx, const void* resid,
                          const void* mask_c, const float* mask_scale, const float* mask_shift, double* sums,
                          int nshard, void* stream);

@@ -92,7 +92,7 @@ SIGNATURES = {
     "msfwsi_set_tuning": [_i, _l],
     "msfwsi_conv3x3_supported": [_desc],
     "msfwsi_conv3x3_stationary": [_desc],
-    "msfwsi_conv3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_conv3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "msfwsi_conv3x3_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
 }
 

@@ -384,6 +384,8 @@ struct C3WParams {
     const void* mask_c;
     const float* mask_scale;
     const float* mask_shift;
+    const float* pro_scale;  // nullable: the input is the producer's RAW conv output, relu(scale*c + shift) is applied
+    const float* pro_shift;  //   on the way from the staging registers to LDS (the activation is never materialised)
     int H, W;
     long Mtot;
     int ntiles, tiles_per_wg, nshard;
@@ -472,16 +474,30 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const C3WParams prm) {
         a_lds[i] = (c8 >> 2) * PLANE + hr * 64 + swz3(hr, c8 & 3) * 16;
     }
     uint4 a_reg[AL];
+    unsigned a_valid = 0;  // bit i: chunk i of the staged tile lies inside the tensor (padding stays zero)
     auto load_A = [&](int tile) {
         const long g0 = (long)tile * BM - W - 1;
+        a_valid = 0;
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             const long g = g0 + a_hr[i];
             a_reg[i] = make_uint4(0, 0, 0, 0);
-            if (g >= 0 && g < prm.Mtot && a_hr[i] < BM + 2 * W + 2)
+            if (g >= 0 && g < prm.Mtot && a_hr[i] < BM + 2 * W + 2) {
                 a_reg[i] = *reinterpret_cast<const uint4*>(src + g * 64 + a_col[i]);
+                a_valid |= 1u << i;
+            }
         }
     };
+    // producer BatchNorm + ReLU of this thread's channels (every chunk it stages has the same 8: 512 threads % 8 == 0)
+    const bool has_pro = prm.pro_scale != nullptr;
+    float qsc[VEC], qsh[VEC];
+    if (has_pro) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            qsc[e] = prm.pro_scale[a_col[0] + e];
+            qsh[e] = prm.pro_shift[a_col[0] + e];
+        }
+    }
 
     // epilogue row-chunk map
     constexpr int CPR = BN / VEC, RPP = NT / CPR, NP = BM / RPP;  // 8 chunks per row, 64 rows per pass, 4 passes
@@ -503,7 +519,17 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const C3WParams prm) {
     for (int tile = t_beg; tile < t_end; ++tile) {
         __syncthreads();  // the previous tile's epilogue is done with the region the halo planes share
 #pragma unroll
-        for (int i = 0; i < AL; ++i) *reinterpret_cast<uint4*>(As + a_lds[i]) = a_reg[i];
+        for (int i = 0; i < AL; ++i) {
+            uint4 v = a_reg[i];
+            if (has_pro && ((a_valid >> i) & 1u)) {
+                float f[VEC];
+                unpack16<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], qsc[e], qsh[e]), 0.f);
+                v = pack16<T>(f);
+            }
+            *reinterpret_cast<uint4*>(As + a_lds[i]) = v;
+        }
         __syncthreads();
         // next tile's halo and this tile's epilogue operands: in flight while the MFMAs run
         if (tile + 1 < t_end) load_A(tile + 1);
@@ -738,8 +764,10 @@ extern "C" int msfwsi_conv3x3_stationary(const msfwsi_conv_desc* d) {
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(long v) { g_c3_stationary = v; }
 
 extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, double* stats,
-                                  int nshard, void* stream) {
+                                  int nshard, const float* pro_scale, const float* pro_shift, void* stream) {
     if (!msfwsi_conv3x3_supported(d)) return MSFWSI_EUNSUPPORTED;
+    MSFWSI_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr));
+    if (pro_scale != nullptr && !c3w_ok(d)) return MSFWSI_EUNSUPPORTED;  // fused prologue: weights-stationary kernel only
     MSFWSI_CHECK_ARG(x != nullptr && w != nullptr && y != nullptr && (stats == nullptr || nshard >= 1));
     MSFWSI_CHECK_ARG((long)d->N * d->H * d->W <= 0x7fffffffL);
     C3Params prm{};
@@ -749,6 +777,7 @@ extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, cons
     if (c3w_ok(d)) {
         C3WParams wp{};
         wp.src = x; wp.wgt = w; wp.out = y; wp.stats = stats; wp.nshard = prm.nshard;
+        wp.pro_scale = pro_scale; wp.pro_shift = pro_shift;
         wp.H = d->H; wp.W = d->W; wp.Mtot = (long)d->N * d->H * d->W;
         wp.div_w = make_fastdiv((unsigned)d->W); wp.div_h = make_fastdiv((unsigned)d->H);
         if (d->dtype == MSFWSI_DT_BF16) return launch_c3w<__bf16, false>(wp, st);

@@ -200,6 +200,7 @@ class Engine:
         # for the 64-channel input gradient (494 vs 450 TFLOP/s); wider layers and the forward use the gather kernel
         self.halo3x3 = os.environ.get("MSFWSI_HALO3X3", "1") != "0"
         self.halo3x3_fwd = os.environ.get("MSFWSI_HALO3X3_FWD", "0") != "0"
+        self.fuse_pro3x3 = os.environ.get("MSFWSI_FUSE_PRO3X3", "1") != "0"  # 64->64 3x3: BatchNorm+ReLU in the conv's staging
         # Bottleneck conv3+bn3 backward folded into weights (no c3 in backward at all); 0 = keep / re-make c3
         self.fold_bn3 = os.environ.get("MSFWSI_FOLD_BN3", "1") != "0"
         # ... and the closing ReLU gate of a folded block applied by the producer of its output gradient
@@ -403,7 +404,10 @@ class Engine:
         epi_stats = stats if not isinstance(op, nn.Linear) else None
         bias = getattr(op, "bias", None)
         xin, pro = x, (x_pro.scale, x_pro.shift) if x_pro is not None else None
-        if pro is not None and self.materialize_3x3 and (R * S > 1 or (self.materialize_1x1 and N * H * W >= self.mat_min_rows)):
+        fuse_pro = (pro is not None and self.fuse_pro3x3 and bias is None and not pad_c and kn.conv3x3_stationary(d))
+        if fuse_pro:
+            pass  # the weights-stationary 3x3 kernel applies BatchNorm + ReLU on the way into LDS: nothing to materialise
+        elif pro is not None and self.materialize_3x3 and (R * S > 1 or (self.materialize_1x1 and N * H * W >= self.mat_min_rows)):
             # a 3x3 gather reads every input element 9 times: normalising it once into a transient tensor and
             # letting the conv stage by pure LDS-DMA is cheaper than re-applying BatchNorm+ReLU per tap
             xin = torch.empty_like(x)
@@ -411,6 +415,8 @@ class Engine:
             pro = None
         if pad_c and pro is None and bias is None and self.stem_run and self._stem_run_fwd(op, xin, c, stats, dtype, pad_c):
             pass  # stem: 7 row taps over runs of contiguous pixels on the pure-DMA kernel
+        elif fuse_pro:
+            kn.conv3x3_fwd(d, xin, w, c, stats=stats, pro=pro)
         elif (pro is None and bias is None and not pad_c
               and (kn.conv3x3_stationary(d) if not self.halo3x3_fwd else kn.conv3x3_supported(d))):
             kn.conv3x3_fwd(d, xin, w, c, stats=stats)  # input patch staged once per channel slab, 9 taps reuse it

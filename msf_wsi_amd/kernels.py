@@ -176,6 +176,9 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
     if kind == "conv_wgrad":
         bi = 64 if d.K <= 64 else 128
         bj = 64 if d.R * d.S * d.C <= 64 else 128
+        if (es == 2 and not pro and d.K % 256 == 0 and (d.R * d.S * d.C) % 256 == 0
+                and os.environ.get("MSFWSI_WGRAD_BIG", "1") != "0"):
+            bi = bj = 256  # the 16-wave tile of the deep layers (msfwsi_conv_wgrad)
         lin = (not pro and os.environ.get("MSFWSI_WGRAD_LIN", "1") != "0" and d.stride == 1 and d.P == d.H
                and d.Q == d.W and d.pad <= 1 and d.R <= 3 and d.S <= 3 and d.R == 2 * d.pad + 1 and d.S == 2 * d.pad + 1)
         return f"wgrad_kernelI{tcode}Li{bi}ELi{bj}ELb{int(pro)}ELb{int(lin)}E"
@@ -955,9 +958,15 @@ def conv3x3_stationary(d: ConvDesc) -> bool:
     return bool(_lib.load().msfwsi_conv3x3_stationary(C.byref(d)))
 
 
-def conv3x3_fwd(d: ConvDesc, x, w, y, stats=None):
+def conv3x3_fwd(d: ConvDesc, x, w, y, stats=None, pro=None):
+    """pro = (scale, shift) of the producer BatchNorm: x is its raw conv output (only where conv3x3_stationary(d))"""
     lib = _lib.load()
     dt = x.dtype
+    ps = psh = None
+    if pro is not None:
+        ps, psh = pro
+        _req(ps, "pro_scale", torch.float32, d.C)
+        _req(psh, "pro_shift", torch.float32, d.C)
     _req(x, "x", dt, d.N * d.H * d.W * d.C)
     _req(w, "w", dt, d.K * 9 * d.C)
     _req(y, "y", dt, d.N * d.P * d.Q * d.K)
@@ -968,8 +977,8 @@ def conv3x3_fwd(d: ConvDesc, x, w, y, stats=None):
         if stats.numel() != nsh * 2 * d.K:
             raise ValueError("stats must be [nshard,2,K]")
     _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
-        lib.msfwsi_conv3x3_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(stats), nsh, _stream()), "conv3x3_fwd"),
-        halo=True, dtype=x.dtype)
+        lib.msfwsi_conv3x3_fwd(C.byref(d), _p(x), _p(w), _p(y), _p(stats), nsh, _p(ps), _p(psh), _stream()),
+        "conv3x3_fwd"), halo=True, dtype=x.dtype)
     return y
 
 

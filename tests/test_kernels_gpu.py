@@ -709,6 +709,31 @@ def test_conv3x3_halo_fwd(hip_lib, dt, geom):
     assert torch.allclose(s[1], (yy * yy).sum(0), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [g for g in HALO if g[3] == 64 and g[4] == 64])
+def test_conv3x3_stationary_fused_prologue(hip_lib, dt, geom):
+    """conv(relu(scale * c + shift)) with the BatchNorm + ReLU applied inside the weights-stationary kernel (padding stays
+    zero in ACTIVATION space, image borders inside a tile included) against the materialised activation"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K = geom
+    g = torch.Generator().manual_seed(23)
+    d = kn.conv_desc(dt, N, H, W, Cc, K, 3, 3, 1, 1)
+    assert kn.conv3x3_stationary(d)
+    x = rnd((N, Cc, H, W), dt, g)
+    w = rnd((K, Cc, 3, 3), dt, g, 1.0 / math.sqrt(Cc * 9))
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3 + 0.2  # shift > 0: relu(shift) != 0
+    a = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dt).float()         # the stored activation
+    ref = F.conv2d(a.double(), w.double(), None, stride=1, padding=1)
+    y = torch.empty(N, H, W, K, dtype=dt, device="cuda")
+    stats = kn.new_stats(K)
+    kn.conv3x3_fwd(d, nhwc(x).to(dt).cuda(), nhwc(w).to(dt).cuda(), y, stats=stats, pro=(sc.cuda(), sh.cuda()))
+    torch.cuda.synchronize()
+    assert rel(y.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt)
+    yy = y.double().cpu().reshape(-1, K)
+    assert torch.allclose(stats.sum(0).cpu()[0], yy.sum(0), rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", HALO)
 @pytest.mark.parametrize("fused", [False, True])

@@ -46,7 +46,10 @@ def load(d):
 
 def short(n):
     m = re.search(r"_GLOBAL__N_1\d+(.*?)EvNS", n)
-    return m.group(1) if m else n.split("(")[0][:80]
+    if m:
+        return m.group(1)
+    n = re.sub(r"^void\s+", "", n).replace("(anonymous namespace)::", "")  # demangled names of non-template kernels
+    return n.split("(")[0].split("<")[0][:80] or n[:80]
 
 
 def main():
