@@ -132,6 +132,10 @@ int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* 
  * Replaces: convolution_backward(weight) / linear backward(weight), tools/ssl_train.py:472. */
 int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* pro_scale,
                       const float* pro_shift, int target_blocks, void* stream);
+/* 1 if msfwsi_conv_wgrad serves this geometry with the output-stationary persistent kernel (2-byte types, 64 -> 64
+ * channels, 3x3 / stride 1 / pad 1): the whole gradient stays in one workgroup's accumulators, every activation element
+ * is loaded once, and pro_scale / pro_shift cost nothing -- callers pass them instead of materialising the activation. */
+int msfwsi_conv_wgrad_stationary(const msfwsi_conv_desc* d);
 
 /* ---- BatchNorm (training mode) ------------------------------------------------------------------ */
 
@@ -369,7 +373,8 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * (buffer_load ... lds) conv kernel, key 2 = 0 the linear-addressing weight-gradient path, key 4 = grid size (in
  * 128x128 tiles) below which 128x64 tiles are used, key 5 = 0 disables the parity-class form of the stride-2 3x3 input
  * gradient, key 6 = 0 the 256x256 / 16-wave weight-gradient tile, key 9 = 0 the weights-stationary 3x3
- * kernel of the 64 -> 64 layers (A/B measurements). */
+ * kernel of the 64 -> 64 layers, key 10 = 0 their output-stationary weight-gradient kernel, key 11 = smallest
+ * padded raster (positions) that kernel takes (A/B measurements, tests). */
 int msfwsi_set_tuning(int key, long value);
 
 /* library identification: returns the gfx target string the code objects were built for */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "msfwsi_set_tuning": [_i, _l],
     "msfwsi_conv3x3_supported": [_desc],
     "msfwsi_conv3x3_stationary": [_desc],
+    "msfwsi_conv_wgrad_stationary": [_desc],
     "msfwsi_conv3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "msfwsi_conv3x3_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
 }
@@ -142,7 +143,8 @@ def load() -> C.CDLL:
     lib.msfwsi_target.restype = C.c_char_p
     for key, env in ((0, "MSFWSI_BIG_TILE_MIN_BLOCKS"), (1, "MSFWSI_FAST_DMA"), (2, "MSFWSI_WGRAD_LIN"),
                      (4, "MSFWSI_SMALL_GRID_BLOCKS"), (5, "MSFWSI_S2_PARITY"), (6, "MSFWSI_WGRAD_BIG"),
-                     (9, "MSFWSI_C3_STATIONARY")):  # A/B switches (see msfwsi_set_tuning)
+                     (9, "MSFWSI_C3_STATIONARY"),
+                     (10, "MSFWSI_WGRAD_OS")):  # A/B switches (see msfwsi_set_tuning)
         if env in os.environ:
             lib.msfwsi_set_tuning(key, int(os.environ[env]))
     _lib = lib

@@ -1129,6 +1129,8 @@ int check_desc(const msfwsi_conv_desc* d) {
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(long v);
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
@@ -1141,6 +1143,14 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 9) {
         msfwsi_c3_set_stationary(value);
+        return MSFWSI_OK;
+    }
+    if (key == 10) {
+        msfwsi_wgrad_set_os(value);
+        return MSFWSI_OK;
+    }
+    if (key == 11) {
+        msfwsi_wgrad_set_os_min(value);
         return MSFWSI_OK;
     }
     if (key == 4) {

@@ -413,6 +413,272 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels, 3x3 / stride 1 / pad 1 (layer1 of every ResNet here): OUTPUT-STATIONARY, persistent workgroups.
+//
+// The whole gradient (64 x 9 x 64 fp32 = 36 MFMA tiles) lives in the accumulators of ONE 8-wave workgroup: wave w owns
+// tap w (four 32x32 tiles), the four tiles of tap 8 go to waves 0-3 -- nine tiles per SIMD.  The workgroup walks a
+// contiguous range of 256-position chunks of a ZERO-PADDED raster of the batch (rows of W+1, images of H+1 rows: the
+// one pad column / row between neighbours is every tap's out-of-image value, so no tap needs a mask; dY is zero on pad
+// positions).  Per chunk, dY (256 rows) and the activation halo (256 + 2(W+1) + 2 rows) are loaded ONCE by plain global
+// loads into registers while the previous chunk computes -- optionally with the producer's relu(scale*c + shift) applied
+// on the way to LDS, so the activation is never materialised for this kernel either -- and all nine taps read their
+// shifted rows of the same halo through the transposed LDS read.  The gather kernel fetched every activation element
+// nine times through L2 -> LDS on a 64 x 128 tile (43 FLOP per ingested byte: 594 TFLOP/s of a 660 roof).
+// ---------------------------------------------------------------------------------------------------------------
+struct WgWParams {
+    const void* x;   // [N][H][W][64]  activation (or the producer's raw conv output with pro_*)
+    const void* dy;  // [N][H][W][64]
+    float* dw;       // [64][3][3][64]
+    const float* pro_scale;
+    const float* pro_shift;
+    int N, H, W;
+    long npos;       // N * (H+1) * (W+1) positions of the padded raster
+    int nchunks, chunks_per_wg;
+    FastDiv div_img, div_wp;
+};
+
+struct WgWCfg {
+    static constexpr int BP = 256, NW = 8, MAXW = 56;
+    static constexpr int HALO = ((BP + 2 * (MAXW + 1) + 2 + 63) / 64) * 64;  // 384
+    static constexpr int DY_BYTES = BP * 128, A_BYTES = HALO * 128;
+    static constexpr int LDS_BYTES = DY_BYTES + A_BYTES;                      // 80 KiB
+    static constexpr int DY_LOADS = BP * 8 / (64 * NW), A_LOADS = HALO * 8 / (64 * NW);  // 4, 6 chunks per thread
+};
+
+// fragment of a natural-layout [row][128 B] LDS image: 32 columns from col0, 16 rows from ABSOLUTE row `row0`
+// (the block swizzle is a function of the absolute row, so a tap's shifted view needs no copy)
+template <typename T>
+__device__ __forceinline__ typename WFrag<T>::type read_tr_rows(const char* img, int row0, int col0, int lane) {
+    typedef typename WFrag<T>::type frag_t;
+    const int li = lane & 15, G = lane >> 4;
+    const int q = li >> 2, p = li & 3;
+    const int kb = row0 + (G >> 1) * 8 + q;
+    const int cb = (col0 + (G & 1) * 16 + p * 4) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(img + wnat_off<128>(kb, cb)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(img + wnat_off<128>(kb + 4, cb)));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(frag_t, both);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_os_kernel(const WgWParams prm) {
+    typedef WgWCfg Cfg;
+    constexpr int BP = Cfg::BP, NT = 64 * Cfg::NW, DL = Cfg::DY_LOADS, AL = Cfg::A_LOADS;
+    constexpr int VEC = 8;
+    static_assert(sizeof(T) == 2, "2-byte storage types");
+    typedef typename WFrag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ds = smem;                   // [BP][128 B]   dY rows (position-major)
+    char* As = smem + Cfg::DY_BYTES;   // [HALO][128 B] activation rows: row hr <-> position chunk*BP - Wp - 1 + hr
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int W = prm.W, H = prm.H, Wp = W + 1;
+    const T* __restrict__ x = reinterpret_cast<const T*>(prm.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(prm.dy);
+
+    const int c_beg = blockIdx.x * prm.chunks_per_wg;
+    const int c_end = min(prm.nchunks, c_beg + prm.chunks_per_wg);
+    if (c_beg >= c_end) return;
+
+    // staging map: chunk i*512 + tid -> (row, 16-byte column chunk); the 8 channels are the same for every i
+    const int c8 = tid & 7;
+    int d_lds[DL], a_lds[AL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) {
+        const int row = (i * NT + tid) >> 3;
+        d_lds[i] = wnat_off<128>(row, c8 * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int row = (i * NT + tid) >> 3;
+        a_lds[i] = wnat_off<128>(row, c8 * 16);
+    }
+    const bool has_pro = prm.pro_scale != nullptr;
+    float qsc[VEC], qsh[VEC];
+    if (has_pro) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            qsc[e] = prm.pro_scale[c8 * VEC + e];
+            qsh[e] = prm.pro_shift[c8 * VEC + e];
+        }
+    }
+    uint4 d_reg[DL], a_reg[AL];
+    unsigned a_valid = 0;
+    // (image, row, column) of every staged slot's position, advanced by BP positions per chunk with carries instead of
+    // two divisions per slot and chunk (the staging arithmetic stood in front of every chunk's MFMAs)
+    int d_img[DL], d_y[DL], d_x[DL], a_img[AL], a_y[AL], a_x[AL];
+    const int Hp = H + 1;
+    auto locate = [&](long q, int& img, int& y, int& xx) {  // q may be negative (before the batch): image -1
+        if (q < 0) {
+            img = -1;
+            const long r = q + (long)Hp * Wp;  // q >= -(Wp+1) > -Hp*Wp
+            y = (int)(r / Wp);
+            xx = (int)(r - (long)y * Wp);
+            return;
+        }
+        img = (int)fast_div((unsigned)q, prm.div_img);
+        const unsigned rem = (unsigned)q - (unsigned)img * (unsigned)(Hp * Wp);
+        y = (int)fast_div(rem, prm.div_wp);
+        xx = (int)(rem - (unsigned)y * (unsigned)Wp);
+    };
+    const int adv_y = BP / Wp, adv_x = BP - adv_y * Wp;  // BP positions = adv_y rows + adv_x columns
+    auto advance = [&](int& img, int& y, int& xx) {
+        xx += adv_x;
+        y += adv_y;
+        if (xx >= Wp) {
+            xx -= Wp;
+            ++y;
+        }
+        while (y >= Hp) {  // small images: a chunk may span several
+            y -= Hp;
+            ++img;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < DL; ++i) locate((long)c_beg * BP + ((i * NT + tid) >> 3), d_img[i], d_y[i], d_x[i]);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) locate((long)c_beg * BP - Wp - 1 + ((i * NT + tid) >> 3), a_img[i], a_y[i], a_x[i]);
+    auto load_chunk = [&]() {  // loads the chunk the slot positions point at, then advances them to the next
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            d_reg[i] = make_uint4(0, 0, 0, 0);
+            if ((unsigned)d_img[i] < (unsigned)prm.N && d_y[i] < H && d_x[i] < W)
+                d_reg[i] = *reinterpret_cast<const uint4*>(dy + (((long)d_img[i] * H + d_y[i]) * W + d_x[i]) * 64 + c8 * VEC);
+            advance(d_img[i], d_y[i], d_x[i]);
+        }
+        a_valid = 0;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const int hr = (i * NT + tid) >> 3;
+            a_reg[i] = make_uint4(0, 0, 0, 0);
+            if (hr < BP + 2 * Wp + 2 && (unsigned)a_img[i] < (unsigned)prm.N && a_y[i] < H && a_x[i] < W) {
+                a_reg[i] = *reinterpret_cast<const uint4*>(x + (((long)a_img[i] * H + a_y[i]) * W + a_x[i]) * 64 + c8 * VEC);
+                a_valid |= 1u << i;
+            }
+            advance(a_img[i], a_y[i], a_x[i]);
+        }
+    };
+
+    // tiles: acc[cb*2+ib] = tap `wave`, output-channel block cb, input-channel block ib; acc[4] = tap 8, block (wave>>1, wave&1)
+    f32x16 acc[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[a][j] = 0.f;
+    const bool extra = wave < 4;
+    const int roff_w = (wave / 3) * Wp + (wave % 3);  // halo row of a position's tap-`wave` neighbour: + r*Wp + s
+    const int roff_8 = 2 * Wp + 2;
+    const int xcb = wave >> 1, xib = wave & 1;
+
+    load_chunk();
+    for (int chunk = c_beg; chunk < c_end; ++chunk) {
+        __syncthreads();  // every wave has read the previous chunk's last fragment
+#pragma unroll
+        for (int i = 0; i < DL; ++i) *reinterpret_cast<uint4*>(Ds + d_lds[i]) = d_reg[i];
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            uint4 v = a_reg[i];
+            if (has_pro && ((a_valid >> i) & 1u)) {
+                float f[VEC];
+                unpack16<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], qsc[e], qsh[e]), 0.f);
+                v = pack16<T>(f);
+            }
+            *reinterpret_cast<uint4*>(As + a_lds[i]) = v;
+        }
+        __syncthreads();
+        if (chunk + 1 < c_end) load_chunk();  // in flight while the MFMAs run
+        // fragments of step ks+1 are requested before the MFMAs of step ks (two waves per SIMD and four or five MFMAs
+        // per step do not cover an LDS round trip: measured 30 % MFMA utilisation without this)
+        frag_t af[2][2], bf[2][2], bx[2];
+        auto fetch_frags = [&](int ks, int s) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) af[s][cb] = read_tr_rows<T>(Ds, ks * 16, cb * 32, lane);
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) bf[s][ib] = read_tr_rows<T>(As, ks * 16 + roff_w, ib * 32, lane);
+            if (extra) bx[s] = read_tr_rows<T>(As, ks * 16 + roff_8, xib * 32, lane);
+        };
+        auto mma_step = [&](int s) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) mma32<T>(acc[cb * 2 + ib], af[s][cb], bf[s][ib]);
+            if (extra) mma32<T>(acc[4], xcb ? af[s][1] : af[s][0], bx[s]);
+        };
+        fetch_frags(0, 0);
+#pragma unroll 1  // a real loop of step pairs: the two fragment sets are static registers, nothing else is hoisted
+        for (int kk = 0; kk < BP / 32; ++kk) {
+            fetch_frags(2 * kk + 1, 1);
+            mma_step(0);
+            if (kk + 1 < BP / 32) fetch_frags(2 * kk + 2, 0);
+            mma_step(1);
+        }
+    }
+
+    // dW[co][t][ci] += partial: lane -> ci (contiguous), registers -> co
+    auto flush = [&](const f32x16& a, int t, int cb, int ib) {
+        const int j = t * 64 + ib * 32 + l31;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            atomicAdd(prm.dw + (long)co * 576 + j, a[reg]);
+        }
+    };
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) flush(acc[cb * 2 + ib], wave, cb, ib);
+    if (extra) flush(acc[4], 8, xcb, xib);
+}
+
+long g_wgrad_os = 1;  // msfwsi_set_tuning(10, .): 0 = the 64 -> 64 3x3 weight gradient on the gather kernel
+long g_wgrad_os_min_pos = 32L * 256 * 256;  // msfwsi_set_tuning(11, .): smallest padded raster the kernel takes
+
+bool wgrad_os_ok(const msfwsi_conv_desc* d) {
+    return g_wgrad_os && d->dtype != MSFWSI_DT_F32 && d->C == 64 && d->K == 64 && d->R == 3 && d->S == 3 &&
+           d->stride == 1 && d->pad == 1 && d->P == d->H && d->Q == d->W && d->W <= WgWCfg::MAXW && d->W >= 2 &&
+           (long)d->N * (d->H + 1) * (d->W + 1) <= 0x7fffffffL &&
+           // each workgroup ends with 36 864 atomic adds: worth it from ~32 chunks per workgroup (measured: 13 chunks
+           // 0.114 vs 0.101 ms for the gather kernel, 203 chunks 1.10 vs 1.66 ms)
+           (long)d->N * (d->H + 1) * (d->W + 1) >= g_wgrad_os_min_pos;
+}
+
+template <typename T>
+int launch_wgrad_os(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* ps,
+                    const float* psh, hipStream_t stream) {
+    WgWParams prm{};
+    prm.x = x; prm.dy = dy; prm.dw = dw; prm.pro_scale = ps; prm.pro_shift = psh;
+    prm.N = d->N; prm.H = d->H; prm.W = d->W;
+    prm.npos = (long)d->N * (d->H + 1) * (d->W + 1);
+    prm.nchunks = (int)((prm.npos + WgWCfg::BP - 1) / WgWCfg::BP);
+    prm.div_img = make_fastdiv((unsigned)((d->H + 1) * (d->W + 1)));
+    prm.div_wp = make_fastdiv((unsigned)(d->W + 1));
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        ncu = 256;
+    (void)hipGetLastError();
+    prm.chunks_per_wg = (prm.nchunks + ncu - 1) / ncu;
+    const int nblk = (prm.nchunks + prm.chunks_per_wg - 1) / prm.chunks_per_wg;
+    auto kern = wgrad_os_kernel<T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WgWCfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), WgWCfg::LDS_BYTES, stream, prm);
+    return msfwsi_launch_status();
+}
+
 long g_wgrad_lin = 1;  // msfwsi_set_tuning(2, .): 0 = always the generic staging
 long g_wgrad_big = 1;  // msfwsi_set_tuning(6, .): 0 = never the 256 x 256 tile
 
@@ -497,6 +763,12 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
 
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v) { g_wgrad_lin = v; }
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long v) { g_wgrad_big = v; }
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os(long v) { g_wgrad_os = v; }
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(long v) { g_wgrad_os_min_pos = v; }
+
+// 1 if msfwsi_conv_wgrad serves this geometry with the output-stationary kernel (whose BatchNorm+ReLU prologue is free:
+// callers then pass pro_scale / pro_shift instead of materialising the activation)
+extern "C" int msfwsi_conv_wgrad_stationary(const msfwsi_conv_desc* d) { return d != nullptr && wgrad_os_ok(d) ? 1 : 0; }
 
 extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw,
                                  const float* pro_scale, const float* pro_shift, int target_blocks,
@@ -508,6 +780,11 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->P <= 0 || d->Q <= 0 || d->R <= 0 || d->S <= 0) return MSFWSI_EINVAL;
     if ((pro_scale == nullptr) != (pro_shift == nullptr)) return MSFWSI_EINVAL;
     if ((long)d->N * d->P * d->Q > 0x7fffffffL || (long)d->N * d->H * d->W > 0x7fffffffL) return MSFWSI_EINVAL;
+    if (wgrad_os_ok(d)) {
+        hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
+        if (d->dtype == MSFWSI_DT_BF16) return launch_wgrad_os<__bf16>(d, x, dy, dw, pro_scale, pro_shift, st0);
+        return launch_wgrad_os<_Float16>(d, x, dy, dw, pro_scale, pro_shift, st0);
+    }
     WgradParams prm{};
     prm.x = x; prm.dy = dy; prm.dw = dw;
     prm.pro_scale = pro_scale; prm.pro_shift = pro_shift;

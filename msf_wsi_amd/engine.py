@@ -598,6 +598,8 @@ class Engine:
         x = u.x
         if x_mat is not None:
             x, pro = x_mat, None
+        elif pro is not None and self.fuse_pro3x3 and kn.conv_wgrad_stationary(u.desc) and not u.s2d:
+            pass  # the output-stationary kernel applies BatchNorm + ReLU in its staging: nothing to materialise
         elif pro is not None and self.materialize_wgrad and u.desc.N * u.desc.H * u.desc.W >= 8192:
             # normalise the operand once into a transient tensor: the weight-gradient kernel then stages both
             # tiles by LDS-DMA (3-stage pipeline) instead of register-staging with the BatchNorm prologue

@@ -174,6 +174,9 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
     es = 4 if tcode == "f" else 2
     bk = 16 if es == 4 else 32
     if kind == "conv_wgrad":
+        if (es == 2 and d.C == 64 and d.K == 64 and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1
+                and d.N * (d.H + 1) * (d.W + 1) >= 32 * 256 * 256 and os.environ.get("MSFWSI_WGRAD_OS", "1") != "0"):
+            return f"wgrad_os_kernelI{tcode}E"
         bi = 64 if d.K <= 64 else 128
         bj = 64 if d.R * d.S * d.C <= 64 else 128
         if (es == 2 and not pro and d.K % 256 == 0 and (d.R * d.S * d.C) % 256 == 0
@@ -461,6 +464,12 @@ def conv_dgrad2(d: ConvDesc, dy, w_cat, dx, src2, bias=None, mask=None, sums=Non
     _timed("conv_dgrad", d, dy.element_size(), run,
            extra_elems=src2.numel() + (dx.numel() if mask is not None else 0), dtype=dt, two=True)
     return rc[0] == 0
+
+
+def conv_wgrad_stationary(d: ConvDesc) -> bool:
+    """the output-stationary persistent kernel serves this geometry (64 -> 64, 3x3 / stride 1): its BatchNorm+ReLU
+    prologue is free, so callers pass `pro` instead of materialising the activation"""
+    return bool(_lib.load().msfwsi_conv_wgrad_stationary(C.byref(d)))
 
 
 def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=0):

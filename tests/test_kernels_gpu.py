@@ -734,6 +734,42 @@ def test_conv3x3_stationary_fused_prologue(hip_lib, dt, geom):
     assert torch.allclose(stats.sum(0).cpu()[0], yy.sum(0), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [g for g in HALO if g[3] == 64 and g[4] == 64] + [(9, 3, 2, 64, 64)])
+@pytest.mark.parametrize("pro", [False, True])
+def test_conv_wgrad_output_stationary(hip_lib, dt, geom, pro):
+    """the 64 -> 64 3x3 weight gradient on the zero-padded raster (with and without the fused BatchNorm + ReLU of the
+    producer) against fp64, and against the gather kernel on the same operands"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K = geom
+    g = torch.Generator().manual_seed(24)
+    d = kn.conv_desc(dt, N, H, W, Cc, K, 3, 3, 1, 1)
+    x = rnd((N, Cc, H, W), dt, g)
+    dy = rnd((N, K, H, W), dt, g, 0.1)
+    sc, sh = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.3 + 0.2
+    xin = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dt).float() if pro else x
+    ref = torch.nn.grad.conv2d_weight(xin.double(), (K, Cc, 3, 3), dy.double(), stride=1, padding=1)
+    xd, dyd = nhwc(x).to(dt).cuda(), nhwc(dy).to(dt).cuda()
+    kw = dict(pro=(sc.cuda(), sh.cuda())) if pro else {}
+    got = {}
+    try:
+        hip_lib.msfwsi_set_tuning(11, 0)  # small test shapes: lift the size threshold of the kernel
+        assert kn.conv_wgrad_stationary(d)
+        for on in (1, 0):
+            hip_lib.msfwsi_set_tuning(10, on)
+            dw = torch.zeros(K, 3, 3, Cc, device="cuda")
+            kn.conv_wgrad(d, xd, dyd, dw, **kw)
+            kn.conv_wgrad(d, xd, dyd, dw, **kw)  # accumulates
+            torch.cuda.synchronize()
+            got[on] = dw.cpu().permute(0, 3, 1, 2) * 0.5
+    finally:
+        hip_lib.msfwsi_set_tuning(10, 1)
+        hip_lib.msfwsi_set_tuning(11, 32 * 256 * 256)
+    assert rel(got[1], ref) < 2e-5
+    assert rel(got[0], ref) < 2e-5
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", HALO)
 @pytest.mark.parametrize("fused", [False, True])

@@ -191,6 +191,19 @@ def test_conv3x3_stationary_persistent_ranges(hip_lib, dt):
     gd = dx.double().reshape(-1, Cc)
     assert torch.allclose(sums.sum(0)[0], gd.sum(0), rtol=1e-5, atol=1e-3)
     assert torch.allclose(sums.sum(0)[1], (gd * cd.double().reshape(-1, Cc)).sum(0), rtol=1e-5, atol=1e-3)
+    # weight gradient: output-stationary kernel (N = 64: its size threshold lifted) with the producer's BatchNorm + ReLU
+    # fused into the staging, against fp64 on the materialised activation
+    a = F.relu(c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dt).float()
+    refw = torch.nn.grad.conv2d_weight(a.double(), (Cc, Cc, 3, 3), dy.double(), stride=1, padding=1)
+    dw = torch.zeros(Cc, 3, 3, Cc, device="cuda")
+    try:
+        hip_lib.msfwsi_set_tuning(11, 0)
+        assert kn.conv_wgrad_stationary(d)
+        kn.conv_wgrad(d, cd, dyd, dw, pro=(sc.cuda(), sh.cuda()))
+        torch.cuda.synchronize()
+    finally:
+        hip_lib.msfwsi_set_tuning(11, 32 * 256 * 256)
+    assert rel(dw.cpu().permute(0, 3, 1, 2), refw) < 2e-5
 
 
 # ------------------------------------------------------------------------------------------------

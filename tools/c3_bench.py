@@ -45,6 +45,13 @@ def main():
             line += f"  stationary={on}: fwd {f:.3f} ms {flop / f / 1e9:5.0f} TF, dgrad(gated) {g:.3f} ms {flop / g / 1e9:5.0f} TF"
         f = timed(lambda: kn.conv_fwd(d, x, w, y, stats=stats))
         line += f"  gather fwd {f:.3f} ms {flop / f / 1e9:5.0f} TF"
+        dw = torch.zeros(Cc * 9 * Cc, device="cuda")
+        for on in (0, 1):
+            lib.msfwsi_set_tuning(10, on)
+            g = timed(lambda: kn.conv_wgrad(d, x, c, dw))
+            gp = timed(lambda: kn.conv_wgrad(d, x, c, dw, pro=(sc, sh))) if on else float("nan")
+            line += f"  wgrad os={on}: {g:.3f} ms {flop / g / 1e9:5.0f} TF (fused prologue {gp:.3f} ms)"
+        lib.msfwsi_set_tuning(10, 1)
         print(line, flush=True)
     lib.msfwsi_set_tuning(9, 1)
 
