@@ -144,7 +144,8 @@ def load() -> C.CDLL:
     for key, env in ((0, "MSFWSI_BIG_TILE_MIN_BLOCKS"), (1, "MSFWSI_FAST_DMA"), (2, "MSFWSI_WGRAD_LIN"),
                      (4, "MSFWSI_SMALL_GRID_BLOCKS"), (5, "MSFWSI_S2_PARITY"), (6, "MSFWSI_WGRAD_BIG"),
                      (9, "MSFWSI_C3_STATIONARY"),
-                     (10, "MSFWSI_WGRAD_OS")):  # A/B switches (see msfwsi_set_tuning)
+                     (10, "MSFWSI_WGRAD_OS"),
+                     (12, "MSFWSI_STEM_WS")):  # A/B switches (see msfwsi_set_tuning)
         if env in os.environ:
             lib.msfwsi_set_tuning(key, int(os.environ[env]))
     _lib = lib

@@ -1131,6 +1131,7 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long 
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v);
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
@@ -1151,6 +1152,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 11) {
         msfwsi_wgrad_set_os_min(value);
+        return MSFWSI_OK;
+    }
+    if (key == 12) {
+        msfwsi_stem_set_ws(value);
         return MSFWSI_OK;
     }
     if (key == 4) {
@@ -1195,11 +1200,20 @@ extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const v
     return MSFWSI_EINVAL;
 }
 
+extern "C" __attribute__((visibility("hidden"))) int msfwsi_stem_ws_fwd(int dtype, const void* x, const void* w, void* y,
+                                                                       double* stats, int nshard, int N, int H, int W,
+                                                                       int CP, int K, int R, int S, int stride, int pad,
+                                                                       int P, int Q, void* stream);
+
 extern "C" int msfwsi_stem_conv_fwd(int dtype, const void* x, const void* w_run, void* y, double* stats, int nshard,
                                     int N, int H, int W, int CP, int K, int R, int S, int stride, int pad, int P,
                                     int Q, void* stream) {
     MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && x && w_run && y && N > 0 && H > 0 && W > 0 && K > 0 && K <= 64);
     MSFWSI_CHECK_ARG(stats == nullptr || nshard >= 1);
+    {   // the space-to-depth stem (4x4 / stride 1 / pad 2 over 16 channels): weights-stationary kernel (stem.hip)
+        const int rc = msfwsi_stem_ws_fwd(dtype, x, w_run, y, stats, nshard, N, H, W, CP, K, R, S, stride, pad, P, Q, stream);
+        if (rc != MSFWSI_EUNSUPPORTED) return rc;
+    }
     const int vec = msfwsi_vec_of(dtype), bk = dtype == MSFWSI_DT_F32 ? 16 : 32;
     // the run of S pixels x CP channels is padded to whole k slabs; a 16-byte chunk must be one pixel
     const int run = ((S * CP + bk - 1) / bk) * bk;

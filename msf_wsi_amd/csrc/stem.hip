@@ -1,0 +1,290 @@
+// The ResNet stem conv (conv1: 7x7 / stride 2 / pad 3, 3 -> 64 channels; src/models/resnet.py:174) in its
+// space-to-depth form -- a 4x4 / stride-1 conv with pad 2 (top/left) over [N][H/2][W/2][16] -- as a WEIGHTS-STATIONARY,
+// persistent kernel (the third of the family: conv3x3_ws_kernel, wgrad_os_kernel).
+//
+// The gather kernel fetched 512 bytes per output pixel through L2 -> LDS for 128 bytes of output on a 128 x 64 tile
+// (43 FLOP per ingested byte; measured 356 TFLOP/s, 1.7 TB/s).  Here the 32 KiB filter stays in LDS; a workgroup walks a
+// contiguous range of 256-position tiles of a ZERO-PADDED raster of the batch (rows of W+2 positions, images of H+2
+// rows: the two pad positions / rows between neighbours are every tap's out-of-image value) and loads the
+// 256 + 3(W+2) + 3 halo positions of a tile (32 bytes each) ONCE, by plain global loads into registers while the
+// previous tile computes.  Two adjacent taps of a filter row are 64 contiguous bytes of the halo = one 32-deep k slab, so
+// the MFMA fragments are plain ds_read_b128 at constant offsets; the 16-byte halves of a position are swapped on every
+// other group of 8 positions, which makes those reads conflict-free.  Outputs of pad positions are dropped in the row
+// pass; BatchNorm sums accumulate in registers over the workgroup's tiles.  Two workgroups share a CU (69 KiB of LDS
+// each), so one's loads / stores overlap the other's MFMAs.
+#include "common.h"
+#include "../../include/msfwsi_hip.h"
+
+namespace {
+
+struct StemParams {
+    const void* x;    // [N][H][W][16]   space-to-depth input
+    const void* wgt;  // [64][4][4][16]
+    void* out;        // [N][H][W][64]   raw conv output
+    double* stats;    // [nshard][2][64], nullable
+    int N, H, W;
+    long npos;        // N * (H+2) * (W+2)
+    int ntiles, tiles_per_wg, nshard;
+    FastDiv div_img, div_wp;
+};
+
+struct StemCfg {
+    static constexpr int BM = 256, BN = 64, NW = 8, WM = 4, WN = 2, TM = 2, VEC = 8;
+    static constexpr int MAXW = 112;
+    static constexpr int HALO = ((BM + 3 * (MAXW + 2) + 3 + 63) / 64) * 64;  // 640 positions
+    static constexpr int W_BYTES = 8 * 4096;                                 // eight (filter row, tap pair) slabs
+    static constexpr int A_BYTES = HALO * 32;
+    static constexpr int LDC = BN + VEC;
+    static constexpr int C_BYTES = BM * LDC * 2;
+    static constexpr int RED_BYTES = NW * BN * 2 * (int)sizeof(float);
+    static constexpr int AC_BYTES = A_BYTES > C_BYTES ? A_BYTES : C_BYTES;   // the output tile reuses the halo's bytes
+    static constexpr int LDS_BYTES = W_BYTES + AC_BYTES;
+    static constexpr int A_LOADS = (HALO * 2 + 64 * NW - 1) / (64 * NW);     // 16-byte chunks per thread and tile: 3
+    static_assert(RED_BYTES <= AC_BYTES, "statistics scratch reuses the tile region");
+};
+
+__device__ __forceinline__ int swzs(int row, int c) { return c ^ ((row >> 2) & 3); }
+__device__ __forceinline__ int halo_off(int pos, int half) { return pos * 32 + ((half ^ ((pos >> 3) & 1)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void stem_ws_kernel(const StemParams prm) {
+    typedef StemCfg Cfg;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NW = Cfg::NW, WM = Cfg::WM, TM = Cfg::TM, VEC = Cfg::VEC;
+    constexpr int LDC = Cfg::LDC, NT = 64 * NW, AL = Cfg::A_LOADS;
+    static_assert(sizeof(T) == 2, "2-byte storage types");
+    typedef typename MmaFrag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ws = smem;
+    char* As = smem + Cfg::W_BYTES;
+    T* Cs = reinterpret_cast<T*>(smem + Cfg::W_BYTES);
+    float* red = reinterpret_cast<float*>(smem + Cfg::W_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int W = prm.W, H = prm.H, Wp = W + 2, Hp = H + 2;
+    const T* __restrict__ x = reinterpret_cast<const T*>(prm.x);
+    const T* __restrict__ wgt = reinterpret_cast<const T*>(prm.wgt);
+    T* __restrict__ out = reinterpret_cast<T*>(prm.out);
+
+    const int t_beg = blockIdx.x * prm.tiles_per_wg;
+    const int t_end = min(prm.ntiles, t_beg + prm.tiles_per_wg);
+    if (t_beg >= t_end) return;
+
+    // ---- filter -> LDS, once: slab sl = (filter row r, tap pair sp) is [64 n][64 B], 32 pieces of 1 KiB ----
+    for (int g = wave; g < 32; g += NW) {
+        const int sl = g >> 2, q = g & 3;
+        const int row = q * 16 + (lane >> 2);
+        const int kc = swzs(row, lane & 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wgt + (long)row * 256 + sl * 32 + kc * VEC),
+                                         (__attribute__((address_space(3))) void*)(Ws + g * 1024), 16, 0, 0);
+    }
+
+    // padded-raster position -> (image, row, column); advanced by BM positions per tile with carries
+    auto locate = [&](long q, int& img, int& y, int& xx) {
+        if (q < 0) {  // before the batch (q >= -(2 Wp + 2) > -Hp Wp): the pad rows of "image -1"
+            img = -1;
+            const long r = q + (long)Hp * Wp;
+            y = (int)(r / Wp);
+            xx = (int)(r - (long)y * Wp);
+            return;
+        }
+        img = (int)fast_div((unsigned)q, prm.div_img);
+        const unsigned rem = (unsigned)q - (unsigned)img * (unsigned)(Hp * Wp);
+        y = (int)fast_div(rem, prm.div_wp);
+        xx = (int)(rem - (unsigned)y * (unsigned)Wp);
+    };
+    const int adv_y = BM / Wp, adv_x = BM - adv_y * Wp;
+    auto advance = [&](int& img, int& y, int& xx) {
+        xx += adv_x;
+        y += adv_y;
+        if (xx >= Wp) {
+            xx -= Wp;
+            ++y;
+        }
+        while (y >= Hp) {
+            y -= Hp;
+            ++img;
+        }
+    };
+
+    // halo staging: chunk i*512 + tid -> (halo position, 16-byte half); halo position hr <-> q0 - 2 Wp - 2 + hr
+    int a_lds[AL], a_img[AL], a_y[AL], a_x[AL];
+    bool a_in[AL];
+    const int half = tid & 1;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int hr = (i * NT + tid) >> 1;
+        a_in[i] = hr < BM + 3 * Wp + 3;
+        a_lds[i] = halo_off(hr < Cfg::HALO ? hr : 0, half);
+        if (hr >= Cfg::HALO) a_lds[i] = -1;
+        locate((long)t_beg * BM - 2 * Wp - 2 + hr, a_img[i], a_y[i], a_x[i]);
+    }
+    uint4 a_reg[AL];
+    auto load_A = [&]() {  // loads the tile the slot positions point at, then advances them to the next tile
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            a_reg[i] = make_uint4(0, 0, 0, 0);
+            if (a_in[i] && (unsigned)a_img[i] < (unsigned)prm.N && a_y[i] < H && a_x[i] < W)
+                a_reg[i] = *reinterpret_cast<const uint4*>(x + (((long)a_img[i] * H + a_y[i]) * W + a_x[i]) * 16 + half * VEC);
+            advance(a_img[i], a_y[i], a_x[i]);
+        }
+    };
+
+    // row pass: chunk cc of rows rr + ps*64; the output position of each of this thread's rows, advanced per tile
+    constexpr int CPR = BN / VEC, RPP = NT / CPR, NP = BM / RPP;  // 8 chunks per row, 64 rows per pass, 4 passes
+    const int cc = tid % CPR, rr = tid / CPR;
+    int o_img[NP], o_y[NP], o_x[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) locate((long)t_beg * BM + rr + ps * RPP, o_img[ps], o_y[ps], o_x[ps]);
+    float ssum[VEC], ssq[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ssum[e] = ssq[e] = 0.f;
+
+    load_A();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the filter (and the first halo) have landed
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        __syncthreads();  // the previous tile's row pass is done with the bytes the halo shares
+#pragma unroll
+        for (int i = 0; i < AL; ++i)
+            if (a_lds[i] >= 0) *reinterpret_cast<uint4*>(As + a_lds[i]) = a_reg[i];
+        __syncthreads();
+        if (tile + 1 < t_end) load_A();  // in flight while the MFMAs run
+
+        f32x16 acc[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[b][j] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const int roff = (sl >> 1) * Wp + 2 * (sl & 1);  // halo position of an output position's tap (r, 2 sp)
+            const char* Bb = Ws + sl * 4096;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int j = ks * 2 + lh;  // 16-byte k chunk of the slab: tap (j >> 1), channel half (j & 1)
+                frag_t xf[TM], wf;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int pos = (wm * TM + tm) * 32 + l31 + roff + (j >> 1);
+                    xf[tm] = *reinterpret_cast<const frag_t*>(As + halo_off(pos, j & 1));
+                }
+                const int nrow = wn * 32 + l31;
+                wf = *reinterpret_cast<const frag_t*>(Bb + nrow * 64 + swzs(nrow, j) * 16);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) mma32<T>(acc[tm], wf, xf[tm]);
+            }
+        }
+        __syncthreads();  // every wave has read its last halo fragment: the bytes become the output tile
+
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nc = wn * 32 + 8 * g + 4 * lh;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int row = (wm * TM + tm) * 32 + l31;
+                T* dst = Cs + row * LDC + nc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) store_elem<T>(dst, e, acc[tm][g * 4 + e]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            if ((unsigned)o_img[ps] < (unsigned)prm.N && o_y[ps] < H && o_x[ps] < W) {  // pad positions produce nothing
+                const int row = rr + ps * RPP;
+                const uint4 v = *reinterpret_cast<const uint4*>(Cs + row * LDC + cc * VEC);
+                *reinterpret_cast<uint4*>(out + (((long)o_img[ps] * H + o_y[ps]) * W + o_x[ps]) * 64 + cc * VEC) = v;
+                if (prm.stats != nullptr) {
+                    float f[VEC];
+                    unpack16<T>(v, f);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        ssum[e] += f[e];
+                        ssq[e] = fmaf(f[e], f[e], ssq[e]);
+                    }
+                }
+            }
+            advance(o_img[ps], o_y[ps], o_x[ps]);
+        }
+    }
+
+    if (prm.stats != nullptr) {
+        __syncthreads();  // the last row pass has read the tile the scratch overlays
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+#pragma unroll
+            for (int off = CPR; off < 64; off <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], off, 64);
+                ssq[e] += __shfl_xor(ssq[e], off, 64);
+            }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                red[(wave * BN + lane * VEC + e) * 2 + 0] = ssum[e];
+                red[(wave * BN + lane * VEC + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += NT) {
+            const int col = i % BN, which = i / BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[(w * BN + col) * 2 + which];
+            atomicAdd(prm.stats + ((long)(blockIdx.x % prm.nshard) * 2 + which) * 64 + col, (double)t);
+        }
+    }
+}
+
+long g_stem_ws = 1;  // msfwsi_set_tuning(12, .): 0 = the stem on the gather kernel
+
+template <typename T>
+int launch_stem_ws(StemParams& prm, hipStream_t stream) {
+    typedef StemCfg Cfg;
+    prm.ntiles = (int)((prm.npos + Cfg::BM - 1) / Cfg::BM);
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        ncu = 256;
+    (void)hipGetLastError();
+    const int slots = 2 * ncu;  // two workgroups per CU
+    prm.tiles_per_wg = (prm.ntiles + slots - 1) / slots;
+    const int nblk = (prm.ntiles + prm.tiles_per_wg - 1) / prm.tiles_per_wg;
+    auto kern = stem_ws_kernel<T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), Cfg::LDS_BYTES, stream, prm);
+    return msfwsi_launch_status();
+}
+
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v) { g_stem_ws = v; }
+
+// the space-to-depth stem on the weights-stationary kernel; MSFWSI_EUNSUPPORTED where it does not apply (the caller,
+// msfwsi_stem_conv_fwd, then takes the gather kernel)
+extern "C" __attribute__((visibility("hidden"))) int msfwsi_stem_ws_fwd(int dtype, const void* x, const void* w, void* y,
+                                                                       double* stats, int nshard, int N, int H, int W,
+                                                                       int CP, int K, int R, int S, int stride, int pad,
+                                                                       int P, int Q, void* stream) {
+    if (!g_stem_ws || dtype == MSFWSI_DT_F32 || CP != 16 || K != 64 || R != 4 || S != 4 || stride != 1 || pad != 2 ||
+        P != H || Q != W || W > StemCfg::MAXW || W < 2 || H < 2 || (long)N * (H + 2) * (W + 2) > 0x7fffffffL)
+        return MSFWSI_EUNSUPPORTED;
+    StemParams prm{};
+    prm.x = x; prm.wgt = w; prm.out = y; prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = N; prm.H = H; prm.W = W;
+    prm.npos = (long)N * (H + 2) * (W + 2);
+    prm.div_img = make_fastdiv((unsigned)((H + 2) * (W + 2)));
+    prm.div_wp = make_fastdiv((unsigned)(W + 2));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MSFWSI_DT_BF16) return launch_stem_ws<__bf16>(prm, st);
+    return launch_stem_ws<_Float16>(prm, st);
+}

@@ -54,6 +54,21 @@ def main():
         lib.msfwsi_set_tuning(10, 1)
         print(line, flush=True)
     lib.msfwsi_set_tuning(9, 1)
+    # the stem on its space-to-depth input: [N][112][112][16] -> 64 channels, 4x4 / stride 1 / pad 2
+    N, H2 = 4096, 112
+    xs = torch.randn(N, H2, H2, 16, device="cuda").to(dt)
+    w2 = (torch.randn(64, 4, 4, 16, device="cuda") * 0.05).to(dt)
+    c = torch.empty(N, H2, H2, 64, device="cuda", dtype=dt)
+    stats = kn.new_stats(64)
+    flop = 2.0 * N * H2 * H2 * 64 * 256
+    line = "stem N4096 112x112 C16->K64 4x4: "
+    for on in (0, 1):
+        lib.msfwsi_set_tuning(12, on)
+        f = timed(lambda: kn.stem_conv_fwd(xs, w2, c, stats, 4, 4, 1, 2, P=H2, Q=H2))
+        gb = (xs.numel() + c.numel()) * 2 / f / 1e6
+        line += f"  stationary={on}: {f:.3f} ms {flop / f / 1e9:5.0f} TF {gb:5.0f} GB/s"
+    print(line, flush=True)
+    lib.msfwsi_set_tuning(12, 1)
 
 
 if __name__ == "__main__":
