@@ -374,7 +374,8 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * 128x128 tiles) below which 128x64 tiles are used, key 5 = 0 disables the parity-class form of the stride-2 3x3 input
  * gradient, key 6 = 0 the 256x256 / 16-wave weight-gradient tile, key 9 = 0 the weights-stationary 3x3
  * kernel of the 64 -> 64 layers, key 10 = 0 their output-stationary weight-gradient kernel, key 11 = smallest
- * padded raster (positions) that kernel takes, key 12 = 0 the weights-stationary stem kernel (A/B measurements, tests). */
+ * padded raster (positions) that kernel takes, key 12 = 0 the stationary stem kernels (forward and weight gradient), key 13 =
+ * smallest padded raster the stem's weight-gradient kernel takes (A/B measurements, tests). */
 int msfwsi_set_tuning(int key, long value);
 
 /* library identification: returns the gfx target string the code objects were built for */

@@ -1132,6 +1132,7 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(l
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_os_min(long v);
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
@@ -1156,6 +1157,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 12) {
         msfwsi_stem_set_ws(value);
+        return MSFWSI_OK;
+    }
+    if (key == 13) {
+        msfwsi_stem_set_os_min(value);
         return MSFWSI_OK;
     }
     if (key == 4) {

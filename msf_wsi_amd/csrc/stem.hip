@@ -239,7 +239,208 @@ __global__ __launch_bounds__(512, 4) void stem_ws_kernel(const StemParams prm) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same conv: dW[co][r][s][c] = sum over positions of dY[pos][co] * x[pos + (r-2)(W+2) + (s-2)][c],
+// OUTPUT-STATIONARY like wgrad_os_kernel (wgrad.hip): the 64 x 256 gradient is 16 MFMA tiles, wave w owns the two tiles
+// of k slab w (filter row w/2, tap pair w%2: 32 columns = 64 contiguous bytes of the halo per position) for both halves
+// of the output channels.  dY (256 positions x 128 B) and the activation halo (32 B per position) of a chunk of the
+// zero-padded raster are loaded once through registers; the fragments come from the transposed LDS read -- for the
+// activation with rows that OVERLAP (32-byte stride, 64 bytes wide), which the per-lane addresses of that read allow.
+// ---------------------------------------------------------------------------------------------------------------
+struct StemWgParams {
+    const void* x;   // [N][H][W][16]
+    const void* dy;  // [N][H][W][64]
+    float* dw;       // [64][4][4][16]
+    int N, H, W;
+    long npos;
+    int nchunks, chunks_per_wg;
+    FastDiv div_img, div_wp;
+};
+
+struct StemWgCfg {
+    static constexpr int BP = 256, NW = 8;
+    static constexpr int HALO = StemCfg::HALO;
+    static constexpr int DY_BYTES = BP * 128, A_BYTES = HALO * 32;
+    static constexpr int LDS_BYTES = DY_BYTES + A_BYTES;                       // 52 KiB: two workgroups per CU
+    static constexpr int DY_LOADS = BP * 8 / (64 * NW);                        // 4 chunks per thread
+    static constexpr int A_LOADS = (HALO * 2 + 64 * NW - 1) / (64 * NW);       // 3
+};
+
+// natural [row][128 B] image with the 64-byte block swizzle of wgrad.hip
+__device__ __forceinline__ int dy_off(int k, int cb) { return k * 128 + ((((cb >> 6) ^ ((k >> 1) & 1)) << 6) | (cb & 63)); }
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void stem_wgrad_os_kernel(const StemWgParams prm) {
+    typedef StemWgCfg Cfg;
+    constexpr int BP = Cfg::BP, NT = 64 * Cfg::NW, DL = Cfg::DY_LOADS, AL = Cfg::A_LOADS, VEC = 8;
+    static_assert(sizeof(T) == 2, "2-byte storage types");
+    typedef typename MmaFrag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ds = smem;
+    char* As = smem + Cfg::DY_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int W = prm.W, H = prm.H, Wp = W + 2, Hp = H + 2;
+    const T* __restrict__ x = reinterpret_cast<const T*>(prm.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(prm.dy);
+
+    const int c_beg = blockIdx.x * prm.chunks_per_wg;
+    const int c_end = min(prm.nchunks, c_beg + prm.chunks_per_wg);
+    if (c_beg >= c_end) return;
+
+    auto locate = [&](long q, int& img, int& y, int& xx) {
+        if (q < 0) {
+            img = -1;
+            const long r = q + (long)Hp * Wp;
+            y = (int)(r / Wp);
+            xx = (int)(r - (long)y * Wp);
+            return;
+        }
+        img = (int)fast_div((unsigned)q, prm.div_img);
+        const unsigned rem = (unsigned)q - (unsigned)img * (unsigned)(Hp * Wp);
+        y = (int)fast_div(rem, prm.div_wp);
+        xx = (int)(rem - (unsigned)y * (unsigned)Wp);
+    };
+    const int adv_y = BP / Wp, adv_x = BP - adv_y * Wp;
+    auto advance = [&](int& img, int& y, int& xx) {
+        xx += adv_x;
+        y += adv_y;
+        if (xx >= Wp) {
+            xx -= Wp;
+            ++y;
+        }
+        while (y >= Hp) {
+            y -= Hp;
+            ++img;
+        }
+    };
+
+    const int c8 = tid & 7, half = tid & 1;
+    int d_lds[DL], d_img[DL], d_y[DL], d_x[DL];
+    int a_lds[AL], a_img[AL], a_y[AL], a_x[AL];
+    bool a_in[AL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) {
+        const int row = (i * NT + tid) >> 3;
+        d_lds[i] = dy_off(row, c8 * 16);
+        locate((long)c_beg * BP + row, d_img[i], d_y[i], d_x[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int hr = (i * NT + tid) >> 1;
+        a_in[i] = hr < BP + 3 * Wp + 3;
+        a_lds[i] = hr < Cfg::HALO ? halo_off(hr, half) : -1;
+        locate((long)c_beg * BP - 2 * Wp - 2 + hr, a_img[i], a_y[i], a_x[i]);
+    }
+    uint4 d_reg[DL], a_reg[AL];
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            d_reg[i] = make_uint4(0, 0, 0, 0);
+            if ((unsigned)d_img[i] < (unsigned)prm.N && d_y[i] < H && d_x[i] < W)
+                d_reg[i] = *reinterpret_cast<const uint4*>(dy + (((long)d_img[i] * H + d_y[i]) * W + d_x[i]) * 64 + c8 * VEC);
+            advance(d_img[i], d_y[i], d_x[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            a_reg[i] = make_uint4(0, 0, 0, 0);
+            if (a_in[i] && (unsigned)a_img[i] < (unsigned)prm.N && a_y[i] < H && a_x[i] < W)
+                a_reg[i] = *reinterpret_cast<const uint4*>(x + (((long)a_img[i] * H + a_y[i]) * W + a_x[i]) * 16 + half * VEC);
+            advance(a_img[i], a_y[i], a_x[i]);
+        }
+    };
+
+    // transposed fragments: 16 positions from `row0`, 32 columns
+    auto read_dy = [&](int row0, int col0) -> frag_t {
+        const int li = lane & 15, G = lane >> 4;
+        const int q = li >> 2, p = li & 3;
+        const int kb = row0 + (G >> 1) * 8 + q;
+        const int cb = (col0 + (G & 1) * 16 + p * 4) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Ds + dy_off(kb, cb)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Ds + dy_off(kb + 4, cb)));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(frag_t, both);
+    };
+    // activation: "row" k = 64 bytes starting at halo position hp0 + k (the two taps of the slab), columns = (tap, channel)
+    auto read_x = [&](int hp0) -> frag_t {
+        const int li = lane & 15, G = lane >> 4;
+        const int q = li >> 2, p = li & 3;
+        const int cbyte = ((G & 1) * 16 + p * 4) * 2;  // 0 .. 63: position offset cbyte >> 5, half (cbyte >> 4) & 1
+        const int k0 = hp0 + (G >> 1) * 8 + q + (cbyte >> 5);
+        const int hf = (cbyte >> 4) & 1, in = cbyte & 15;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(As + halo_off(k0, hf) + in));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(As + halo_off(k0 + 4, hf) + in));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(frag_t, both);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[a][j] = 0.f;
+    const int roff = (wave >> 1) * Wp + 2 * (wave & 1);  // halo position of an output position's tap (r, 2 sp) of slab `wave`
+
+    load_chunk();
+    for (int chunk = c_beg; chunk < c_end; ++chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < DL; ++i) *reinterpret_cast<uint4*>(Ds + d_lds[i]) = d_reg[i];
+#pragma unroll
+        for (int i = 0; i < AL; ++i)
+            if (a_lds[i] >= 0) *reinterpret_cast<uint4*>(As + a_lds[i]) = a_reg[i];
+        __syncthreads();
+        if (chunk + 1 < c_end) load_chunk();
+        frag_t af[2][2], bf[2];
+        auto fetch_frags = [&](int ks, int s) {
+            af[s][0] = read_dy(ks * 16, 0);
+            af[s][1] = read_dy(ks * 16, 32);
+            bf[s] = read_x(ks * 16 + roff);
+        };
+        fetch_frags(0, 0);
+#pragma unroll 1
+        for (int kk = 0; kk < BP / 32; ++kk) {
+            fetch_frags(2 * kk + 1, 1);
+            mma32<T>(acc[0], af[0][0], bf[0]);
+            mma32<T>(acc[1], af[0][1], bf[0]);
+            if (kk + 1 < BP / 32) fetch_frags(2 * kk + 2, 0);
+            mma32<T>(acc[0], af[1][0], bf[1]);
+            mma32<T>(acc[1], af[1][1], bf[1]);
+        }
+    }
+
+    // dW[co][256]: lane -> column (slab `wave`, 32 columns), registers -> co
+    const int j = wave * 32 + l31;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            atomicAdd(prm.dw + (long)co * 256 + j, acc[cb][reg]);
+        }
+}
+
+template <typename T>
+int launch_stem_wgrad(StemWgParams& prm, hipStream_t stream) {
+    typedef StemWgCfg Cfg;
+    prm.nchunks = (int)((prm.npos + Cfg::BP - 1) / Cfg::BP);
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        ncu = 256;
+    (void)hipGetLastError();
+    const int slots = 2 * ncu;
+    prm.chunks_per_wg = (prm.nchunks + slots - 1) / slots;
+    const int nblk = (prm.nchunks + prm.chunks_per_wg - 1) / prm.chunks_per_wg;
+    hipLaunchKernelGGL(stem_wgrad_os_kernel<T>, dim3((unsigned)nblk), dim3(512), Cfg::LDS_BYTES, stream, prm);
+    return msfwsi_launch_status();
+}
+
 long g_stem_ws = 1;  // msfwsi_set_tuning(12, .): 0 = the stem on the gather kernel
+long g_stem_os_min_pos = 32L * 512 * 256;  // msfwsi_set_tuning(13, .): smallest padded raster the weight-gradient kernel takes
 
 template <typename T>
 int launch_stem_ws(StemParams& prm, hipStream_t stream) {
@@ -268,6 +469,26 @@ int launch_stem_ws(StemParams& prm, hipStream_t stream) {
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v) { g_stem_ws = v; }
+
+// weight gradient of the space-to-depth stem on the output-stationary kernel; MSFWSI_EUNSUPPORTED where it does not
+// apply (msfwsi_conv_wgrad then takes the gather kernel).  From ~32 chunks per workgroup (16 384 atomics each at the end).
+extern "C" __attribute__((visibility("hidden"))) int msfwsi_stem_os_wgrad(const msfwsi_conv_desc* d, const void* x,
+                                                                         const void* dy, float* dw, void* stream) {
+    if (!g_stem_ws || d->dtype == MSFWSI_DT_F32 || d->C != 16 || d->K != 64 || d->R != 4 || d->S != 4 || d->stride != 1 ||
+        d->pad != 2 || d->P != d->H || d->Q != d->W || d->W > StemCfg::MAXW || d->W < 2 || d->H < 2)
+        return MSFWSI_EUNSUPPORTED;
+    const long npos = (long)d->N * (d->H + 2) * (d->W + 2);
+    if (npos > 0x7fffffffL || npos < g_stem_os_min_pos) return MSFWSI_EUNSUPPORTED;
+    StemWgParams prm{};
+    prm.x = x; prm.dy = dy; prm.dw = dw;
+    prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.npos = npos;
+    prm.div_img = make_fastdiv((unsigned)((d->H + 2) * (d->W + 2)));
+    prm.div_wp = make_fastdiv((unsigned)(d->W + 2));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MSFWSI_DT_BF16) return launch_stem_wgrad<__bf16>(prm, st);
+    return launch_stem_wgrad<_Float16>(prm, st);
+}
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_os_min(long v) { g_stem_os_min_pos = v; }
 
 // the space-to-depth stem on the weights-stationary kernel; MSFWSI_EUNSUPPORTED where it does not apply (the caller,
 // msfwsi_stem_conv_fwd, then takes the gather kernel)

@@ -770,6 +770,9 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(lo
 // callers then pass pro_scale / pro_shift instead of materialising the activation)
 extern "C" int msfwsi_conv_wgrad_stationary(const msfwsi_conv_desc* d) { return d != nullptr && wgrad_os_ok(d) ? 1 : 0; }
 
+extern "C" __attribute__((visibility("hidden"))) int msfwsi_stem_os_wgrad(const msfwsi_conv_desc* d, const void* x,
+                                                                         const void* dy, float* dw, void* stream);
+
 extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw,
                                  const float* pro_scale, const float* pro_shift, int target_blocks,
                                  void* stream) {
@@ -780,6 +783,10 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->P <= 0 || d->Q <= 0 || d->R <= 0 || d->S <= 0) return MSFWSI_EINVAL;
     if ((pro_scale == nullptr) != (pro_shift == nullptr)) return MSFWSI_EINVAL;
     if ((long)d->N * d->P * d->Q > 0x7fffffffL || (long)d->N * d->H * d->W > 0x7fffffffL) return MSFWSI_EINVAL;
+    if (pro_scale == nullptr) {  // the space-to-depth stem (stem.hip)
+        const int rc = msfwsi_stem_os_wgrad(d, x, dy, dw, stream);
+        if (rc != MSFWSI_EUNSUPPORTED) return rc;
+    }
     if (wgrad_os_ok(d)) {
         hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
         if (d->dtype == MSFWSI_DT_BF16) return launch_wgrad_os<__bf16>(d, x, dy, dw, pro_scale, pro_shift, st0);

@@ -174,6 +174,9 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
     es = 4 if tcode == "f" else 2
     bk = 16 if es == 4 else 32
     if kind == "conv_wgrad":
+        if (es == 2 and d.C == 16 and d.K == 64 and (d.R, d.S, d.stride, d.pad) == (4, 4, 1, 2) and d.P == d.H
+                and d.N * (d.H + 2) * (d.W + 2) >= 32 * 512 * 256 and os.environ.get("MSFWSI_STEM_WS", "1") != "0"):
+            return f"stem_wgrad_os_kernelI{tcode}E"
         if (es == 2 and d.C == 64 and d.K == 64 and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1
                 and d.N * (d.H + 1) * (d.W + 1) >= 32 * 256 * 256 and os.environ.get("MSFWSI_WGRAD_OS", "1") != "0"):
             return f"wgrad_os_kernelI{tcode}E"

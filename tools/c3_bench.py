@@ -69,6 +69,16 @@ def main():
         line += f"  stationary={on}: {f:.3f} ms {flop / f / 1e9:5.0f} TF {gb:5.0f} GB/s"
     print(line, flush=True)
     lib.msfwsi_set_tuning(12, 1)
+    d = kn.conv_desc(dt, N, H2, H2, 16, 64, 4, 4, 1, 2)
+    d = type(d)(d.dtype, N, H2, H2, 16, H2, H2, 64, 4, 4, 1, 2)
+    dw = torch.zeros(64 * 256, device="cuda")
+    line = "stem wgrad: "
+    for on in (0, 1):
+        lib.msfwsi_set_tuning(12, on)
+        f = timed(lambda: kn.conv_wgrad(d, xs, c, dw))
+        line += f"  stationary={on}: {f:.3f} ms {flop / f / 1e9:5.0f} TF"
+    print(line, flush=True)
+    lib.msfwsi_set_tuning(12, 1)
 
 
 if __name__ == "__main__":
