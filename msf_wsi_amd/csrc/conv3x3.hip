@@ -399,8 +399,8 @@ template <typename T>
 struct C3WCfg {
     static constexpr int VEC = ElemTraits<T>::VEC, BK = ElemTraits<T>::BK;  // 8, 32
     static constexpr int BM = MSFWSI_C3W_BM, BN = 64, CH = 64, NW = 8, WM = 4, WN = 2, TM = BM / WM / 32;
-    static constexpr int MAXW = 56;
-    static constexpr int HALO_ROWS = ((BM + 2 * MAXW + 2 + 63) / 64) * 64;  // 640 (BM = 512), 384 (256)
+    static constexpr int MAXW = 64;  // 56: ResNet layer1 at 224^2; 64: at the 256^2 tiles of the fine-tune model
+    static constexpr int HALO_ROWS = ((BM + 2 * MAXW + 2 + 63) / 64) * 64;  // 448
     static constexpr int PLANE = HALO_ROWS * 64 + 128;  // one channel slab of the halo; +128 B: the two slabs of a pixel
                                                         // (written by neighbouring lanes) start 32 banks apart
     static constexpr int W_TILE = 4096;                 // one (slab, tap) weight tile: [64 n][64 B] or [32 k][128 B]
@@ -720,8 +720,9 @@ int launch_c3w(C3WParams& prm, hipStream_t stream) {
 
 // the weights-stationary kernel serves: 2-byte types, 64 -> 64 channels, 3x3 / stride 1 / pad 1, W <= 56
 bool c3w_ok(const msfwsi_conv_desc* d) {
-    return g_c3_stationary && d->dtype != MSFWSI_DT_F32 && d->C == 64 && d->K == 64 && d->W <= C3WCfg<__bf16>::MAXW &&
-           d->W >= 3 && d->H >= 3 && (long)d->N * d->H * d->W * 64 * 2 < (1L << 46);
+    return g_c3_stationary && d->dtype != MSFWSI_DT_F32 && d->C == 64 && d->K == 64 && d->R == 3 && d->S == 3 &&
+           d->stride == 1 && d->pad == 1 && d->P == d->H && d->Q == d->W && d->W <= C3WCfg<__bf16>::MAXW && d->W >= 3 &&
+           d->H >= 3 && (long)d->H * d->W >= 128 && (long)d->N * d->H * d->W <= 0x7fffffffL;
 }
 
 template <typename T, int BN, bool DGRAD>
@@ -759,22 +760,24 @@ extern "C" int msfwsi_conv3x3_supported(const msfwsi_conv_desc* d) {
 
 // 1 if the weights-stationary persistent kernel would serve this geometry (callers prefer it over the gather kernel)
 extern "C" int msfwsi_conv3x3_stationary(const msfwsi_conv_desc* d) {
-    return d != nullptr && msfwsi_conv3x3_supported(d) && c3w_ok(d) ? 1 : 0;
+    return d != nullptr && msfwsi_dtype_ok(d->dtype) && c3w_ok(d) ? 1 : 0;
 }
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(long v) { g_c3_stationary = v; }
 
 extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, double* stats,
                                   int nshard, const float* pro_scale, const float* pro_shift, void* stream) {
-    if (!msfwsi_conv3x3_supported(d)) return MSFWSI_EUNSUPPORTED;
+    if (d == nullptr || !msfwsi_dtype_ok(d->dtype)) return MSFWSI_EUNSUPPORTED;
+    const bool ws = c3w_ok(d);  // (a little wider than the per-tile kernel: rows of up to 64 pixels)
+    if (!ws && !msfwsi_conv3x3_supported(d)) return MSFWSI_EUNSUPPORTED;
     MSFWSI_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr));
-    if (pro_scale != nullptr && !c3w_ok(d)) return MSFWSI_EUNSUPPORTED;  // fused prologue: weights-stationary kernel only
+    if (pro_scale != nullptr && !ws) return MSFWSI_EUNSUPPORTED;  // fused prologue: weights-stationary kernel only
     MSFWSI_CHECK_ARG(x != nullptr && w != nullptr && y != nullptr && (stats == nullptr || nshard >= 1));
     MSFWSI_CHECK_ARG((long)d->N * d->H * d->W <= 0x7fffffffL);
     C3Params prm{};
     prm.src = x; prm.wgt = w; prm.out = y; prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C; prm.Nout = d->K;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (c3w_ok(d)) {
+    if (ws) {
         C3WParams wp{};
         wp.src = x; wp.wgt = w; wp.out = y; wp.stats = stats; wp.nshard = prm.nshard;
         wp.pro_scale = pro_scale; wp.pro_shift = pro_shift;
@@ -790,7 +793,8 @@ extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, cons
 extern "C" int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* w, void* dx,
                                     const void* resid, const void* mask_c, const float* mask_scale,
                                     const float* mask_shift, double* sums, int nshard, void* stream) {
-    if (!msfwsi_conv3x3_supported(d)) return MSFWSI_EUNSUPPORTED;
+    if (d == nullptr || !msfwsi_dtype_ok(d->dtype)) return MSFWSI_EUNSUPPORTED;
+    if (!c3w_ok(d) && !msfwsi_conv3x3_supported(d)) return MSFWSI_EUNSUPPORTED;
     MSFWSI_CHECK_ARG(dy != nullptr && w != nullptr && dx != nullptr);
     MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
     MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));

@@ -30,8 +30,8 @@ struct StemParams {
 
 struct StemCfg {
     static constexpr int BM = 256, BN = 64, NW = 8, WM = 4, WN = 2, TM = 2, VEC = 8;
-    static constexpr int MAXW = 112;
-    static constexpr int HALO = ((BM + 3 * (MAXW + 2) + 3 + 63) / 64) * 64;  // 640 positions
+    static constexpr int MAXW = 128;  // 112: 224^2 tiles; 128: the 256^2 tiles of the fine-tune model
+    static constexpr int HALO = ((BM + 3 * (MAXW + 2) + 3 + 63) / 64) * 64;  // 704 positions
     static constexpr int W_BYTES = 8 * 4096;                                 // eight (filter row, tap pair) slabs
     static constexpr int A_BYTES = HALO * 32;
     static constexpr int LDC = BN + VEC;

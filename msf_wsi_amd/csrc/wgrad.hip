@@ -439,7 +439,7 @@ struct WgWParams {
 };
 
 struct WgWCfg {
-    static constexpr int BP = 256, NW = 8, MAXW = 56;
+    static constexpr int BP = 256, NW = 8, MAXW = 56;  // (64 would need a seventh staged chunk per thread: spills, 1.10 -> 1.95 ms)
     static constexpr int HALO = ((BP + 2 * (MAXW + 1) + 2 + 63) / 64) * 64;  // 384
     static constexpr int DY_BYTES = BP * 128, A_BYTES = HALO * 128;
     static constexpr int LDS_BYTES = DY_BYTES + A_BYTES;                      // 80 KiB

@@ -304,7 +304,7 @@ def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad, P: int = 0, Q: int = 0)
 
     tc = "DF16_" if x.dtype == torch.float16 else _TCODE[x.element_size()]
     ws = (x.element_size() == 2 and CP == 16 and K == 64 and (R, S, stride, pad) == (4, 4, 1, 2) and d.P == H and d.Q == W
-          and W <= 112 and os.environ.get("MSFWSI_STEM_WS", "1") != "0")  # mirrors msfwsi_stem_ws_fwd (csrc/stem.hip)
+          and W <= 128 and os.environ.get("MSFWSI_STEM_WS", "1") != "0")  # mirrors msfwsi_stem_ws_fwd (csrc/stem.hip)
     _timed("conv_fwd", d, x.element_size(), run, dtype=x.dtype,
            symbol_override=f"stem_ws_kernelI{tc}E" if ws else f"igemm_dma_kernelI{tc}Li128ELi64ELi2ELi2ELb0ELi0ELb0ELb1E")
     return rc[0] == 0

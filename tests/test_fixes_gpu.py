@@ -210,7 +210,7 @@ def test_use_checkpoint_selects_recompute_and_keeps_results(hip_lib):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("hw", [(64, 64), (38, 50), (224, 224)])
+@pytest.mark.parametrize("hw", [(64, 64), (38, 50), (224, 224), (256, 256)])
 def test_stem_space_to_depth_equals_direct_form(hip_lib, dtype, hw):
     """conv1 (7x7 / stride 2 / pad 3, resnet.py:174) as a 4x4 / stride-1 conv on the space-to-depth input: output,
     BatchNorm statistics and the weight gradient (folded back to [64][7][7][3]) against torch fp64"""

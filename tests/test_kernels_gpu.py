@@ -679,7 +679,8 @@ HALO = [  # N, H, W, C, K     (3x3, stride 1, pad 1)
     (5, 14, 14, 64, 64),     # 196-pixel images: every tile spans two of them
     (3, 20, 23, 64, 64),     # odd width
     (1, 12, 11, 64, 64),     # a single ragged tile
-    (2, 9, 56, 64, 64),      # the widest row the halo holds
+    (2, 9, 56, 64, 64),
+    (2, 5, 64, 64, 64),      # the widest row the stationary kernels' halo holds (layer1 of a 256 x 256 tile)
 ]
 
 
@@ -696,7 +697,9 @@ def test_conv3x3_halo_fwd(hip_lib, dt, geom):
     x = rnd((N, Cc, H, W), dt, g)
     w = rnd((K, Cc, 3, 3), dt, g, 1.0 / math.sqrt(Cc * 9))
     d = kn.conv_desc(dt, N, H, W, Cc, K, 3, 3, 1, 1)
-    assert kn.conv3x3_supported(d)
+    if W > 56 and not kn.conv3x3_stationary(d):
+        pytest.skip("rows wider than 56 pixels: stationary kernel (2-byte types) only")
+    assert kn.conv3x3_supported(d) or kn.conv3x3_stationary(d)
     ref = F.conv2d(x.double(), w.double(), None, stride=1, padding=1)
     y = torch.empty(N, H, W, K, dtype=dt, device="cuda")
     stats = kn.new_stats(K)
@@ -735,7 +738,7 @@ def test_conv3x3_stationary_fused_prologue(hip_lib, dt, geom):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("geom", [g for g in HALO if g[3] == 64 and g[4] == 64] + [(9, 3, 2, 64, 64)])
+@pytest.mark.parametrize("geom", [g for g in HALO if g[3] == 64 and g[4] == 64 and g[2] <= 56] + [(9, 3, 2, 64, 64)])
 @pytest.mark.parametrize("pro", [False, True])
 def test_conv_wgrad_output_stationary(hip_lib, dt, geom, pro):
     """the 64 -> 64 3x3 weight gradient on the zero-padded raster (with and without the fused BatchNorm + ReLU of the
@@ -781,6 +784,8 @@ def test_conv3x3_halo_dgrad(hip_lib, dt, geom, fused):
         pytest.skip("fp32 slabs are 16 channels")
     g = torch.Generator().manual_seed(22)
     d = kn.conv_desc(dt, N, H, W, Cc, K, 3, 3, 1, 1)
+    if W > 56 and not kn.conv3x3_stationary(d):
+        pytest.skip("rows wider than 56 pixels: stationary kernel (2-byte types) only")
     w = rnd((K, Cc, 3, 3), dt, g, 1.0 / math.sqrt(K * 9))
     dy = rnd((N, K, H, W), dt, g)
     resid = rnd((N, Cc, H, W), dt, g)
