@@ -241,9 +241,10 @@ __global__ __launch_bounds__(512, 4) void stem_ws_kernel(const StemParams prm) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same conv: dW[co][r][s][c] = sum over positions of dY[pos][co] * x[pos + (r-2)(W+2) + (s-2)][c],
-// OUTPUT-STATIONARY like wgrad_os_kernel (wgrad.hip): the 64 x 256 gradient is 16 MFMA tiles, wave w owns the two tiles
-// of k slab w (filter row w/2, tap pair w%2: 32 columns = 64 contiguous bytes of the halo per position) for both halves
-// of the output channels.  dY (256 positions x 128 B) and the activation halo (32 B per position) of a chunk of the
+// OUTPUT-STATIONARY like wgrad_os_kernel (wgrad.hip): the 64 x 256 gradient is 16 MFMA tiles; a workgroup has FOUR waves,
+// wave w owns the four tiles of k slabs 2w and 2w+1 (a slab = filter row, tap pair: 32 columns = 64 contiguous bytes of
+// the halo per position) for both halves of the output channels -- two transposed reads per MFMA (eight waves with two
+// tiles each needed three and were bound by them: 3.24 ms); two workgroups share a CU.  dY (256 positions x 128 B) and the activation halo (32 B per position) of a chunk of the
 // zero-padded raster are loaded once through registers; the fragments come from the transposed LDS read -- for the
 // activation with rows that OVERLAP (32-byte stride, 64 bytes wide), which the per-lane addresses of that read allow.
 // ---------------------------------------------------------------------------------------------------------------
@@ -258,19 +259,19 @@ struct StemWgParams {
 };
 
 struct StemWgCfg {
-    static constexpr int BP = 256, NW = 8;
+    static constexpr int BP = 256, NW = 4;
     static constexpr int HALO = StemCfg::HALO;
     static constexpr int DY_BYTES = BP * 128, A_BYTES = HALO * 32;
-    static constexpr int LDS_BYTES = DY_BYTES + A_BYTES;                       // 52 KiB: two workgroups per CU
-    static constexpr int DY_LOADS = BP * 8 / (64 * NW);                        // 4 chunks per thread
-    static constexpr int A_LOADS = (HALO * 2 + 64 * NW - 1) / (64 * NW);       // 3
+    static constexpr int LDS_BYTES = DY_BYTES + A_BYTES;                       // 54 KiB
+    static constexpr int DY_LOADS = BP * 8 / (64 * NW);                        // 8 chunks per thread
+    static constexpr int A_LOADS = (HALO * 2 + 64 * NW - 1) / (64 * NW);       // 6
 };
 
 // natural [row][128 B] image with the 64-byte block swizzle of wgrad.hip
 __device__ __forceinline__ int dy_off(int k, int cb) { return k * 128 + ((((cb >> 6) ^ ((k >> 1) & 1)) << 6) | (cb & 63)); }
 
 template <typename T>
-__global__ __launch_bounds__(512, 4) void stem_wgrad_os_kernel(const StemWgParams prm) {
+__global__ __launch_bounds__(256, 2) void stem_wgrad_os_kernel(const StemWgParams prm) {
     typedef StemWgCfg Cfg;
     constexpr int BP = Cfg::BP, NT = 64 * Cfg::NW, DL = Cfg::DY_LOADS, AL = Cfg::A_LOADS, VEC = 8;
     static_assert(sizeof(T) == 2, "2-byte storage types");
@@ -377,12 +378,15 @@ __global__ __launch_bounds__(512, 4) void stem_wgrad_os_kernel(const StemWgParam
         return __builtin_bit_cast(frag_t, both);
     };
 
-    f32x16 acc[2];
+    f32x16 acc[2][2];  // [slab 2w + s][output-channel half]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[a][j] = 0.f;
-    const int roff = (wave >> 1) * Wp + 2 * (wave & 1);  // halo position of an output position's tap (r, 2 sp) of slab `wave`
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
+    // halo position of an output position's tap (r, 2 sp) of slab sl = r*2 + sp: slabs 2w and 2w+1 share the filter row w
+    const int roff0 = wave * Wp, roff1 = wave * Wp + 2;
 
     load_chunk();
     for (int chunk = c_beg; chunk < c_end; ++chunk) {
@@ -394,33 +398,41 @@ __global__ __launch_bounds__(512, 4) void stem_wgrad_os_kernel(const StemWgParam
             if (a_lds[i] >= 0) *reinterpret_cast<uint4*>(As + a_lds[i]) = a_reg[i];
         __syncthreads();
         if (chunk + 1 < c_end) load_chunk();
-        frag_t af[2][2], bf[2];
+        frag_t af[2][2], bf[2][2];
         auto fetch_frags = [&](int ks, int s) {
             af[s][0] = read_dy(ks * 16, 0);
             af[s][1] = read_dy(ks * 16, 32);
-            bf[s] = read_x(ks * 16 + roff);
+            bf[s][0] = read_x(ks * 16 + roff0);
+            bf[s][1] = read_x(ks * 16 + roff1);
+        };
+        auto mma_step = [&](int s) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) mma32<T>(acc[sl][cb], af[s][cb], bf[s][sl]);
         };
         fetch_frags(0, 0);
 #pragma unroll 1
         for (int kk = 0; kk < BP / 32; ++kk) {
             fetch_frags(2 * kk + 1, 1);
-            mma32<T>(acc[0], af[0][0], bf[0]);
-            mma32<T>(acc[1], af[0][1], bf[0]);
+            mma_step(0);
             if (kk + 1 < BP / 32) fetch_frags(2 * kk + 2, 0);
-            mma32<T>(acc[0], af[1][0], bf[1]);
-            mma32<T>(acc[1], af[1][1], bf[1]);
+            mma_step(1);
         }
     }
 
-    // dW[co][256]: lane -> column (slab `wave`, 32 columns), registers -> co
-    const int j = wave * 32 + l31;
+    // dW[co][256]: lane -> column (slab 2w + sl, 32 columns), registers -> co
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int sl = 0; sl < 2; ++sl) {
+        const int j = (2 * wave + sl) * 32 + l31;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-            atomicAdd(prm.dw + (long)co * 256 + j, acc[cb][reg]);
-        }
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                atomicAdd(prm.dw + (long)co * 256 + j, acc[sl][cb][reg]);
+            }
+    }
 }
 
 template <typename T>
@@ -432,10 +444,10 @@ int launch_stem_wgrad(StemWgParams& prm, hipStream_t stream) {
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
         ncu = 256;
     (void)hipGetLastError();
-    const int slots = 2 * ncu;
+    const int slots = 2 * ncu;  // two four-wave workgroups per CU (registers: ~200 per lane)
     prm.chunks_per_wg = (prm.nchunks + slots - 1) / slots;
     const int nblk = (prm.nchunks + prm.chunks_per_wg - 1) / prm.chunks_per_wg;
-    hipLaunchKernelGGL(stem_wgrad_os_kernel<T>, dim3((unsigned)nblk), dim3(512), Cfg::LDS_BYTES, stream, prm);
+    hipLaunchKernelGGL(stem_wgrad_os_kernel<T>, dim3((unsigned)nblk), dim3(64 * Cfg::NW), Cfg::LDS_BYTES, stream, prm);
     return msfwsi_launch_status();
 }
 
