@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from msf_wsi_amd import _lib, kernels as kn  # noqa: E402
 
-SHAPES = [  # N, H, W, C, K, R, stride
+SHAPES = [  # N, H, W, C, K, R, stride   (N = int(os.environ.get("WGRAD_BENCH_N", 4096)) replaces the first field)
     (4096, 14, 14, 256, 256, 3, 1), (4096, 7, 7, 512, 512, 3, 1), (4096, 14, 14, 1024, 256, 1, 1),
     (4096, 14, 14, 256, 1024, 1, 1), (4096, 7, 7, 512, 2048, 1, 1), (4096, 7, 7, 2048, 512, 1, 1),
     (4096, 14, 14, 512, 1024, 1, 1), (4096, 28, 28, 256, 256, 3, 2), (4096, 28, 28, 256, 512, 1, 1),
@@ -21,6 +21,7 @@ def main():
     lib = _lib.load()
     dt = torch.bfloat16
     for N, H, W, Cc, K, R, st in SHAPES:
+        N = int(os.environ.get("WGRAD_BENCH_N", N))
         pad = R // 2
         d = kn.conv_desc(dt, N, H, W, Cc, K, R, R, st, pad)
         x = torch.randn(N * H * W * Cc, device="cuda").to(dt)
