@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL needs it on this driver); before any GPU call
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,6 +26,10 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = {"resnet18": 363.37e9, "resnet50": 848.8e9}  # SURVEY.md 8(d), fwd+bwd per tile pair
+# algorithmic minimum HBM bytes -- activations per tile pair (2-byte storage; x2 for fp32) and the
+# batch-independent Adam pass (28 B per parameter) per step
+ACT_BYTES_PER_PAIR_16BIT = {"resnet18": 1.01e9, "resnet50": 4.53e9}
+ADAM_BYTES_PER_STEP = {"resnet18": 3.46e9, "resnet50": 46.6e9}
 
 
 def pmc_entry(symbol):
@@ -43,6 +49,20 @@ def pmc_entry(symbol):
         return dict(hit[0][1], source=os.path.basename(paths[-1])) if hit else {}
     except (OSError, ValueError, KeyError):
         return {}
+
+
+def pmc_step():
+    """whole-step counter traffic (L2-miss bytes per step) of the newest committed PMC summary, with its file name"""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not paths:
+        return None, None
+    try:
+        with open(paths[-1]) as f:
+            return float(json.load(f)["hbm_bytes_per_step"]), os.path.basename(paths[-1])
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def hub_stub():
@@ -121,6 +141,12 @@ def cpu_baseline(arch, size, budget_s, threads):
     return out
 
 
+def dmabuf_ipc_env():
+    """the host driver only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL fails at
+    hipIpcGetMemHandle.  Set before the first GPU call of EVERY rank, whoever launched it."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
 def launch_ranks(n):
     """one child process per GPU on this node over 127.0.0.1 (the container hostname may not resolve)"""
     import socket
@@ -162,6 +188,7 @@ def main():
         # (torch.distributed.run, the reference's mp.spawn of tools/ssl_train.py:68), relays their output (rank 0
         # prints the JSON line) and exits with their return code
         raise SystemExit(launch_ranks(args.gpus))
+    dmabuf_ipc_env()  # the rank path too (a launcher other than launch_ranks may have started this process)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -251,7 +278,9 @@ def main():
                        "image_size": args.size, "parallelism": f"dp{world}",
                        "images_per_s": round(34 * pairs / dt, 1), "loss": float(loss),
                        "peak_mem_GiB": round(peak_mem, 1), "peak_reserved_GiB": round(peak_reserved, 1),
-                       "step_TFLOPs_algorithmic": round(FLOP_PER_PAIR.get(args.arch, 0) * pairs / dt / 1e12, 1)},
+                       "step_TFLOP_per_s_algorithmic": round(FLOP_PER_PAIR.get(args.arch, 0) * pairs / dt / 1e12, 1),
+                       "recompute_plan": ts.engine.last_plan, "collectives_per_step": ts.engine.collectives_last_step
+                       + (3 if world > 1 else 0)},
         }
         if timer is not None and args.layer_report:
             rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1][1])
@@ -272,15 +301,35 @@ def main():
             frac_m, frac_h = tf / PEAK_TFLOPS[args.dtype], gbs / PEAK_HBM_GBS
             bound = "mfma" if frac_m >= frac_h else "hbm"
             pmc = pmc_entry(dom)
+            nst = args.steps - timed_from
+            # the counters are per rocprofv3 launch; one timer entry can issue several launches (the stride-2 3x3 input
+            # gradient is four): compare per STEP, and quote `traffic` per timer entry like `achieved`
+            pmc_per_step = (pmc["hbm_bytes_per_launch"] * pmc["launches_in_pass"] / 2.0
+                            if pmc.get("hbm_bytes_per_launch") and pmc.get("launches_in_pass") else None)
+            step_bytes = (ACT_BYTES_PER_PAIR_16BIT.get(args.arch, 0) * (1 if args.dtype == "bf16" else 2) * args.batch
+                          + ADAM_BYTES_PER_STEP.get(args.arch, 0))
+            step_flop = FLOP_PER_PAIR.get(args.arch, 0) * args.batch
+            step_s = dt / args.steps
+            step_traffic, step_src = pmc_step()
             out["roofline"] = {
                 "kernel": dom, "family": s["family"], "bound": bound,
                 "achieved": round(tf if bound == "mfma" else gbs, 2),
                 "peak": PEAK_TFLOPS[args.dtype] if bound == "mfma" else PEAK_HBM_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                 "frac": round(max(frac_m, frac_h), 4),
-                "traffic": round(pmc.get("hbm_bytes_per_launch")) if pmc.get("hbm_bytes_per_launch") else None,
+                # replayed from the committed rocprofv3 --pmc summary of this same command (NOT measured in this run)
+                "traffic": round(pmc_per_step * nst / s["launches"]) if pmc_per_step else None,
+                "traffic_per_step": round(pmc_per_step) if pmc_per_step else None,
+                "algorithmic_bytes_per_step": round(s["bytes"] / nst),
                 "mfma_util": round(pmc["mfma_util"], 4) if pmc.get("mfma_util") is not None else None,
-                "pmc_source": pmc.get("source"),
+                "replayed_from": pmc.get("source"),
+                "whole_step": {
+                    "algorithmic_GB": round(step_bytes / 1e9, 1), "algorithmic_TFLOP": round(step_flop / 1e12, 1),
+                    "frac_hbm": round(step_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),
+                    "frac_mfma": round(step_flop / step_s / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+                    "traffic_GB": round(step_traffic / 1e9, 1) if step_traffic else None,
+                    "traffic_ratio": round(step_traffic / step_bytes, 3) if step_traffic and step_bytes else None,
+                    "traffic_replayed_from": step_src},
                 "launches": s["launches"], "avg_launch_ms": round(1e3 * s["seconds"] / s["launches"], 4),
                 "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                 "alt": {"TFLOP/s": round(tf, 2), "frac_mfma": round(frac_m, 4), "GB/s": round(gbs, 1),

@@ -329,6 +329,11 @@ int msfwsi_seg_stats(int logits_dtype, const void* logits, int nch, const long* 
  * accuracy on the counts summed over images; 0/0 -> zero_division (smp default 1.0).  scores: 3 + 3*C doubles. */
 int msfwsi_seg_scores(const long* tp, const long* fp, const long* fn, const long* tn, int N, int C, double zero_division,
                       double* scores, void* stream);
+/* smp's image-wise reductions (smp.metrics.f1_score(..., reduction="micro-imagewise"), tools/ssl_finetune.py:319):
+ * scores[0..2] = F1, IoU, accuracy computed per image on its counts summed over classes, averaged over images
+ * ("micro-imagewise"); scores[3..5] = the same scores per (image, class), averaged over both ("macro-imagewise"). */
+int msfwsi_seg_scores_imagewise(const long* tp, const long* fp, const long* fn, const long* tn, int N, int C,
+                                double zero_division, double* scores, void* stream);
 
 /* ---- fine-tune model: U-Net decoder pieces (row f2 of SURVEY.md 8f, BASELINE config 5) --------------------------------
  * The arithmetic of HookNet's decoders lives in segmentation_models_pytorch (third party, outside the reference tree,

@@ -87,6 +87,7 @@ SIGNATURES = {
     "msfwsi_zero_f64_2d": [_vp, _l, _i, _l, _vp],
     "msfwsi_seg_stats": [_i, _vp, _i, _vp, _vp, _i, _l, _i, _l, _l, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "msfwsi_seg_scores": [_vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp],
+    "msfwsi_seg_scores_imagewise": [_vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp],
     "msfwsi_tile_views": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp],
     "msfwsi_inverse_perm": [_vp, _vp, _l, _i, _vp],
     "msfwsi_set_tuning": [_i, _l],

@@ -103,6 +103,38 @@ __global__ void seg_scores_kernel(const long* __restrict__ tp, const long* __res
     }
 }
 
+// smp reductions "micro-imagewise" (out[0..2]: per image the counts summed over classes, score per image, mean over
+// images) and "macro-imagewise" (out[3..5]: score per (image, class), mean over both).  One workgroup.
+__global__ void seg_scores_imagewise_kernel(const long* __restrict__ tp, const long* __restrict__ fp,
+                                            const long* __restrict__ fn, const long* __restrict__ tn, int N, int C,
+                                            double zero_division, double* __restrict__ out) {
+    __shared__ double red[6][256];
+    auto div = [&](double num, double den) { return den == 0.0 ? zero_division : num / den; };
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        double a = 0, b = 0, d = 0, e = 0;
+        for (int k = 0; k < C; ++k) {
+            const double ta = (double)tp[i * C + k], tb = (double)fp[i * C + k], td = (double)fn[i * C + k],
+                         te = (double)tn[i * C + k];
+            a += ta; b += tb; d += td; e += te;
+            acc[3] += div(2.0 * ta, 2.0 * ta + td + tb);
+            acc[4] += div(ta, ta + tb + td);
+            acc[5] += div(ta + te, ta + tb + td + te);
+        }
+        acc[0] += div(2.0 * a, 2.0 * a + d + b);
+        acc[1] += div(a, a + b + d);
+        acc[2] += div(a + e, a + b + d + e);
+    }
+    for (int j = 0; j < 6; ++j) red[j][threadIdx.x] = acc[j];
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int j = 0; j < 6; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out[threadIdx.x] = red[threadIdx.x][0] / (threadIdx.x < 3 ? (double)N : (double)N * (double)C);
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -136,5 +168,13 @@ extern "C" int msfwsi_seg_scores(const long* tp, const long* fp, const long* fn,
                                  double zero_division, double* scores, void* stream) {
     MSFWSI_CHECK_ARG(tp && fp && fn && tn && scores && N > 0 && C > 0 && C <= kMaxClasses);
     hipLaunchKernelGGL(seg_scores_kernel, dim3(1), dim3(128), 0, ST(stream), tp, fp, fn, tn, N, C, zero_division, scores);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_seg_scores_imagewise(const long* tp, const long* fp, const long* fn, const long* tn, int N, int C,
+                                           double zero_division, double* scores, void* stream) {
+    MSFWSI_CHECK_ARG(tp && fp && fn && tn && scores && N > 0 && C > 0 && C <= kMaxClasses);
+    hipLaunchKernelGGL(seg_scores_imagewise_kernel, dim3(1), dim3(256), 0, ST(stream), tp, fp, fn, tn, N, C,
+                       zero_division, scores);
     return msfwsi_launch_status();
 }

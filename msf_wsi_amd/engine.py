@@ -244,6 +244,17 @@ class Engine:
         self.dual_stream: Optional[bool] = False if env is None else env != "0"
         self._side: Dict[str, torch.cuda.Stream] = {}
         self._bn_order: Optional[Tuple[str, dict]] = None
+        # bookkeeping a trainer / bench.py reports: the collectives this engine issued since `reset_counters`, and
+        # the recompute plan of the last forward ("keep-all", "recompute:t1", "recompute:t0,t1" [+ ",drop-c3"])
+        self.collectives = 0
+        self.collectives_last_step = 0
+        self.last_plan = "keep-all"
+
+    def reset_counters(self):
+        self.collectives = 0
+
+    def close_counters(self):
+        self.collectives_last_step = self.collectives
 
     def invalidate_weights(self):
         """Every derived copy of the parameters (16-bit / channel-padded casts, the stem's filter-row runs) is keyed on
@@ -339,6 +350,7 @@ class Engine:
             packed = self._msg_buf("fwd", 2 * Cn, dev)
             kn.shard_sum(stats, packed)
             sync_sums(packed, self.group, force=self.force_sync)  # RCCL sum of [sum, sumsq]; equal shards per rank
+            self.collectives += 1
             stats = packed.view(1, 2, Cn)
             total *= self._world()
         if bn.momentum is None:
@@ -376,6 +388,7 @@ class Engine:
                 kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count, bn.weight, st.mean, st.invstd,
                                    grads.get(bn.weight), grads.get(bn.bias), k[0], k[1], k[2])
             sync_sums(packed, self.group, force=self.force_sync)
+            self.collectives += 1
             kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count,
                                bn.weight if bn.affine else None, st.mean, st.invstd, None, None, k[0], k[1], k[2])
             return k
@@ -759,26 +772,33 @@ class Engine:
             self.update_running = keep
         return full
 
-    def _plan_recompute(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float = 0.0) -> set:
+    def _plan_recompute(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float = 0.0,
+                        shape_key: tuple = ()) -> set:
         """which encoder passes run features-only in forward, and whether bottleneck conv3 outputs are dropped
         (engine.recompute = off | c3 | t1 | targets | auto).  Sets self._drop_c3 for the remaining passes.
 
         With more than one rank the decision is COLLECTIVE: a rank that recomputes a pass issues forward SyncBatchNorm
         exchanges where its peers issue backward ones (same message sizes, so a mismatch would pair silently), and
         'auto' depends on each rank's free memory.  Every rank therefore adopts the most conservative local plan
-        (one all-reduce(MAX) of a plan code), once per (batch, model) shape -- the result is cached."""
+        (one all-reduce(MAX) of a plan code), once per (batch, model, image) shape -- the result is cached.  The cache
+        key holds RANK-INVARIANT values only (batch, tile count, image / model shape, mode): whether the plan
+        collective runs must never depend on a locally measured quantity, or one rank would issue it while its peers
+        issue BatchNorm all-reduces (`per_image_bytes` comes from this rank's allocator and only feeds the LOCAL
+        proposal that goes into the MAX)."""
         nosave, drop = self._plan_local(per_image_bytes, B, K, device, c3_fraction)
         if self._world() > 1:
-            key = (B, K, int(per_image_bytes), self._mode_override or self.recompute, self.fold_bn3)
+            key = (B, K, tuple(shape_key), self._mode_override or self.recompute, self.fold_bn3)
             hit = self._plan_cache.get(key)
             if hit is None:
                 code = torch.tensor([2 * len(nosave) + int(drop)], dtype=torch.int32, device=device)
                 dist.all_reduce(code, op=dist.ReduceOp.MAX, group=self.group)
+                self.collectives += 1
                 c = int(code.item())
                 hit = (frozenset([(), ("t1",), ("t0", "t1")][c // 2]), bool(c & 1))
                 self._plan_cache[key] = hit
             nosave, drop = set(hit[0]), hit[1]
         self._drop_c3 = drop
+        self.last_plan = ("recompute:" + ",".join(sorted(nosave)) if nosave else "keep-all") + (",drop-c3" if drop else "")
         return nosave
 
     def _plan_local(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float):
@@ -797,7 +817,9 @@ class Engine:
             return {"t0", "t1"}, False
         free, _ = torch.cuda.mem_get_info(device)
         avail = free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
-        budget = avail - (6 << 30)
+        # head room: 6 GiB for the allocator's fragmentation; with more than one rank another 4 GiB for RCCL's channel
+        # buffers and the IPC mappings of the peers, which are allocated outside torch's pool after this measurement
+        budget = avail - (6 << 30) - ((4 << 30) if self._world() > 1 else 0)
         # calibration (ResNet-50, 256 tile pairs, bf16): kept activations 180 GiB, measured peak 240.8 GiB with
         # 28 GiB of weights/optimizer -> backward transients (gradient tensors, re-normalised operands, the
         # recomputed conv3) are about a quarter of one full target pass
@@ -1228,7 +1250,9 @@ class Engine:
         # MSFWSI(..., use_checkpoint=True) (the reference's --use-ac, backbone.py:103-127): trade compute for activation
         # memory -- here: both target passes (16/17 of the images) run features-only and are re-run before their backward
         self._mode_override = "targets" if getattr(model, "use_checkpoint", False) else None
-        nosave = self._plan_recompute(per_image, B, K, dev, c3_frac) if need_backward else {"c1", "t0", "t1"}
+        shape_key = (tuple(x1[0].shape[1:]), tuple(x1[1].shape[1:]), sum(1 for _ in model.parameters()), str(dtype))
+        nosave = (self._plan_recompute(per_image, B, K, dev, c3_frac, shape_key) if need_backward
+                  else {"c1", "t0", "t1"})
         if not need_backward:
             rec.enc["c0"] = EncPass(model.context_encoder, B, 0, 0, None, None, None, None, [], rec.enc["c0"].feats,
                                     saved=False)

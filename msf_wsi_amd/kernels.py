@@ -211,15 +211,21 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
 
 
 def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = False, halo: bool = False,
-           dtype=None, symbol_override: Optional[str] = None, epi: int = 0, two: bool = False):
-    """extra_elems: elements of the additional activation-sized operands the launch reads in its epilogue
-    (residual / identity, the gate's activation) -- algorithmic bytes of the fused work, counted once each"""
+           dtype=None, symbol_override: Optional[str] = None, epi: int = 0, two: bool = False, extra_k: int = 0,
+           same_operand: bool = False):
+    """extra_elems: elements of the additional activation-sized operands the launch reads (residual / identity, the
+    gate's activation, the second source of a two-source launch) -- algorithmic bytes of the fused work, counted once
+    each.  extra_k: the second source's reduction range (its FLOPs and weight bytes).  same_operand: a Gram launch
+    conv_wgrad(d, a, a, A) reads ONE tensor (counted once; it was counted twice until round 3, which put the 56x56
+    64x64 Gram row of the layer report above the HBM peak)"""
     if TIMER is None:
         return fn()
     M = d.N * d.P * d.Q
-    flops = 2.0 * M * d.K * d.R * d.S * d.C
-    nbytes = float(esize) * (d.N * d.H * d.W * d.C + M * d.K + extra_elems) + float(
-        esize if kind != "conv_wgrad" else 4) * (d.K * d.R * d.S * d.C)
+    nout, rows = (d.C, d.N * d.H * d.W) if kind == "conv_dgrad" else (d.K, M)
+    flops = 2.0 * M * d.K * d.R * d.S * d.C + 2.0 * rows * nout * extra_k
+    act_in = 0 if same_operand else d.N * d.H * d.W * d.C
+    nbytes = float(esize) * (act_in + M * d.K + extra_elems) + float(
+        esize if kind != "conv_wgrad" else 4) * (d.K * d.R * d.S * d.C + nout * extra_k)
     tcode = "DF16_" if dtype == torch.float16 else _TCODE[esize]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -352,7 +358,7 @@ def conv_fwd_post2(d: ConvDesc, x, w_cat, y, src2, post_scale, post_shift, ident
             _lib.check(rc[0], "conv_fwd_post2")
 
     _timed("conv_fwd", d, x.element_size(), run, extra_elems=src2.numel() + (ident.numel() if ident is not None else 0),
-           dtype=dt, epi=1, two=True)
+           dtype=dt, epi=1, two=True, extra_k=int(C2))
     return rc[0] == 0
 
 
@@ -469,7 +475,7 @@ def conv_dgrad2(d: ConvDesc, dy, w_cat, dx, src2, bias=None, mask=None, sums=Non
             _lib.check(rc[0], "conv_dgrad2")
 
     _timed("conv_dgrad", d, dy.element_size(), run,
-           extra_elems=src2.numel() + (dx.numel() if mask is not None else 0), dtype=dt, two=True)
+           extra_elems=src2.numel() + (dx.numel() if mask is not None else 0), dtype=dt, two=True, extra_k=int(C2))
     return rc[0] == 0
 
 
@@ -492,7 +498,7 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=0):
         _req(psh, "pro_shift", torch.float32, d.C)
     _timed("conv_wgrad", d, x.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ps), _p(psh), int(target_blocks), _stream()),
-        "conv_wgrad"), pro=pro is not None, dtype=x.dtype)
+        "conv_wgrad"), pro=pro is not None, dtype=x.dtype, same_operand=x.data_ptr() == dy.data_ptr())
     return dw
 
 
@@ -1063,6 +1069,18 @@ def seg_scores(tp, fp, fn, tn, zero_division: float = 1.0):
     out = torch.empty(3 + 3 * Cn, dtype=torch.float64, device=tp.device)
     _lib.check(lib.msfwsi_seg_scores(_p(tp), _p(fp), _p(fn), _p(tn), N, Cn, float(zero_division), _p(out), _stream()),
                "seg_scores")
+    return out
+
+
+def seg_scores_imagewise(tp, fp, fn, tn, zero_division: float = 1.0):
+    """fp64 [6]: F1 / IoU / accuracy with smp's "micro-imagewise" reduction, then with "macro-imagewise""""
+    lib = _lib.load()
+    N, Cn = tp.shape
+    for nm, t in (("tp", tp), ("fp", fp), ("fn", fn), ("tn", tn)):
+        _req(t, nm, torch.int64, N * Cn)
+    out = torch.empty(6, dtype=torch.float64, device=tp.device)
+    _lib.check(lib.msfwsi_seg_scores_imagewise(_p(tp), _p(fp), _p(fn), _p(tn), N, Cn, float(zero_division), _p(out),
+                                               _stream()), "seg_scores_imagewise")
     return out
 
 

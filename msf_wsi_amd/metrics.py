@@ -7,6 +7,7 @@ Mirrors the calls the reference makes (tools/ssl_finetune.py:526-551, tools/eval
                                            ignore_index=-1, num_classes=len(class_names))
     smp.metrics.f1_score(tp, fp, fn, tn, reduction="micro")    iou_score(...)    accuracy(...)
     smp.metrics.f1_score(tp.sum(0), fp.sum(0), fn.sum(0), tn.sum(0), reduction=None)    ...
+    smp.metrics.f1_score(tp, fp, fn, tn, reduction="micro-imagewise")          (training epoch, ssl_finetune.py:319)
 
 with the same names and argument meaning, so `import msf_wsi_amd.metrics as metrics` stands in for `smp.metrics` in
 those loops.  `segmentation_models_pytorch` is a third-party dependency that is not part of the reference tree (and is
@@ -62,7 +63,14 @@ def _pick(which: int, tp, fp, fn, tn, reduction, zero_division):
         if tp.dim() != 1:
             raise NotImplementedError("reduction=None is used on per-class totals (tp.sum(0)) by the reference")
         return s[3 + which * C:3 + (which + 1) * C]
-    raise NotImplementedError(f"reduction={reduction!r} is not used by MSF-WSI")
+    if reduction in ("micro-imagewise", "macro-imagewise"):
+        if tp.dim() != 2:
+            raise ValueError(f"reduction={reduction!r} needs per-image counts [N, C]")
+        t4 = [t.long().contiguous() for t in (tp, fp, fn, tn)]
+        return kn.seg_scores_imagewise(*t4, zero_division)[which + (3 if reduction == "macro-imagewise" else 0)]
+    # smp also offers "macro", "weighted", "weighted-imagewise" (class_weights): no call site in the reference
+    raise NotImplementedError(f"reduction={reduction!r} is not used by MSF-WSI (implemented: 'micro', None / 'none' on "
+                              f"per-class totals, 'micro-imagewise', 'macro-imagewise')")
 
 
 def f1_score(tp, fp, fn, tn, reduction: Optional[str] = None, class_weights=None, zero_division: float = 1.0):

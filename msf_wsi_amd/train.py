@@ -170,6 +170,7 @@ class PretrainStep:
     def step(self, batch) -> torch.Tensor:
         """one optimisation step; returns the (device-resident, fp64) loss of this minibatch"""
         bs = batch[0][0].shape[0]
+        self.engine.reset_counters()
         self.flats.zero_grads()
         kn.ARENA.begin_step(self.device)  # one clear for all of this step's small zero-initialised accumulators
         try:
@@ -180,6 +181,7 @@ class PretrainStep:
         finally:
             kn.ARENA.end_step()
         self.reducer.wait()
+        self.engine.close_counters()
         self.optimizer_step()
         self.epoch_meter[0] += loss[0] * bs
         self.epoch_meter[1] += bs

@@ -2,7 +2,8 @@
 
 numpy restatement of the segmentation metrics the reference's fine-tune / evaluation loops call
 (tools/ssl_finetune.py:526-551, tools/evaluate.py:285-305):  smp.metrics.get_stats(mode="multiclass", ignore_index,
-num_classes) and f1_score / iou_score / accuracy with reduction "micro" and None.
+num_classes) and f1_score / iou_score / accuracy with reduction "micro", None and (ssl_finetune.py:319)
+"micro-imagewise" / "macro-imagewise".
 
 PARITY UNPINNED: the arithmetic lives in the third-party package `segmentation-models-pytorch>=0.3.2`
 (/root/reference/environment.yml:26; version not pinned exactly, source not under /root/reference, package absent from
@@ -50,9 +51,16 @@ def _div(num, den, zero_division=1.0):
 
 
 def scores(tp, fp, fn, tn, reduction, zero_division=1.0):
-    """(f1, iou, accuracy); reduction "micro": over everything; None: elementwise on the given counts"""
+    """(f1, iou, accuracy); reduction "micro": over everything; None: elementwise on the given counts;
+    "micro-imagewise": counts summed over classes per image, score per image, mean over images;
+    "macro-imagewise": score per (image, class), mean over classes and images  (smp functional._compute_metric)"""
     if reduction == "micro":
         tp, fp, fn, tn = (np.asarray(x).sum() for x in (tp, fp, fn, tn))
+    elif reduction == "micro-imagewise":
+        tp, fp, fn, tn = (np.asarray(x).sum(1) for x in (tp, fp, fn, tn))
     tp, fp, fn, tn = (np.asarray(x, dtype=np.float64) for x in (tp, fp, fn, tn))
-    return (_div(2 * tp, 2 * tp + fn + fp, zero_division), _div(tp, tp + fp + fn, zero_division),
-            _div(tp + tn, tp + fp + fn + tn, zero_division))
+    res = (_div(2 * tp, 2 * tp + fn + fp, zero_division), _div(tp, tp + fp + fn, zero_division),
+           _div(tp + tn, tp + fp + fn + tn, zero_division))
+    if reduction in ("micro-imagewise", "macro-imagewise"):
+        res = tuple(r.mean() for r in res)
+    return res

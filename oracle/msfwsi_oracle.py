@@ -238,16 +238,24 @@ class Adam:
 
 
 def train_step(sd: StateDict, batch, opt: Adam, scale: int = 4, mask_ratio: float = 0.5,
-               weights: Sequence[float] = FUSER_WEIGHTS, loss_scale: float = 1.0, loss_fn=None):
-    """one iteration of tools/ssl_train.py:425-474 (fp32, no autocast).  Returns loss, per-term losses,
-    the forward outputs and the (unscaled) gradients; updates `sd` in place."""
+               weights: Sequence[float] = FUSER_WEIGHTS, loss_scale: float = 1.0, loss_fn=None, autocast_dtype=None):
+    """one iteration of tools/ssl_train.py:425-474.  autocast_dtype=None: plain fp32 / fp64 arithmetic of the state
+    dict's dtype; torch.bfloat16 / torch.float16: forward and loss under `torch.autocast("cpu", dtype)` as the
+    reference loop runs them under --amp (ssl_train.py:441; master weights, gradients and Adam stay fp32) -- the
+    yardstick of the product's 16-bit runs.  Returns loss, per-term losses, the forward outputs and the (unscaled)
+    gradients; updates `sd` in place."""
     (c1, c2), (t1, t2), idx = batch
     params = {k: v for k, v in sd.items() if is_param(k)}
     for v in params.values():
         v.requires_grad_(True)
         v.grad = None
-    outputs = msfwsi_forward(sd, (c1, t1), (c2, t2), idx, scale, mask_ratio)
-    loss, terms = (loss_fn or loss_terms)(outputs, weights)
+    if autocast_dtype is None:
+        outputs = msfwsi_forward(sd, (c1, t1), (c2, t2), idx, scale, mask_ratio)
+        loss, terms = (loss_fn or loss_terms)(outputs, weights)
+    else:
+        with torch.autocast("cpu", dtype=autocast_dtype):
+            outputs = msfwsi_forward(sd, (c1, t1), (c2, t2), idx, scale, mask_ratio)
+            loss, terms = (loss_fn or loss_terms)(outputs, weights)
     (loss * loss_scale).backward()
     grads = {}
     for k, v in params.items():
@@ -258,6 +266,43 @@ def train_step(sd: StateDict, batch, opt: Adam, scale: int = 4, mask_ratio: floa
     if finite:
         opt.step(sd, grads)
     return loss.detach(), terms, outputs, grads
+
+
+def diverse_batch(B: int, size: int = 64, K: int = 16, seed: int = 0, dtype=torch.float32):
+    """Well-conditioned synthetic input with the same batch contract as `synthetic_batch`: every image is a smooth
+    random pattern (two scales of block-constant noise + mild pixel noise) with its OWN mean and contrast, as stained
+    tissue tiles differ from each other.  With i.i.d. N(0,1) pixels all pooled features of a batch are nearly equal,
+    the heads' BatchNorm1d divides by a vanishing batch deviation and the reference's own fp32 run sits 2e-2 from its
+    fp64 run; on these inputs the reference's fp32<->fp64 spread has a median of ~1e-5.
+    Only exactly reproducible operations (randn, repeat_interleave, one multiply, one add per element): the same
+    seed gives bit-identical tensors on every machine.  size must be a multiple of 8."""
+    g = torch.Generator().manual_seed(seed)
+    c1, c2, t1, t2 = (_diverse_images(g, n, size) for n in (B, B, B * K, B * K))
+    i1 = torch.stack([torch.argsort(torch.randperm(K, generator=g)) for _ in range(B)])
+    i2 = torch.stack([torch.argsort(torch.randperm(K, generator=g)) for _ in range(B)])
+    return (c1.to(dtype), c2.to(dtype)), (t1.to(dtype), t2.to(dtype)), [i1, i2]
+
+
+def _diverse_images(g: torch.Generator, n: int, size: int) -> Tensor:
+    if size % 8:
+        raise ValueError("diverse inputs: size must be a multiple of 8")
+    coarse = torch.randn(n, 3, 8, 8, generator=g).repeat_interleave(size // 8, 2).repeat_interleave(size // 8, 3)
+    fine = torch.randn(n, 3, size // 2, size // 2, generator=g).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    x = coarse + 0.5 * fine
+    x = x + 0.25 * torch.randn(n, 3, size, size, generator=g)
+    mean = 0.8 * torch.randn(n, 3, 1, 1, generator=g)
+    contrast = torch.exp(0.5 * torch.randn(n, 1, 1, 1, generator=g))
+    return x * contrast + mean
+
+
+def diverse_images(n: int, size: int = 64, seed: int = 0, dtype=torch.float32) -> Tensor:
+    """n images of the `diverse_batch` kind (encoder-only tests)"""
+    return _diverse_images(torch.Generator().manual_seed(seed), n, size).to(dtype)
+
+
+def make_batch(kind: str, B: int, size: int, K: int = 16, seed: int = 0, dtype=torch.float32):
+    """kind = "normal" (SURVEY 8(d) inputs) | "diverse" (well-conditioned parity inputs)"""
+    return (diverse_batch if kind == "diverse" else synthetic_batch)(B, size, K, seed, dtype)
 
 
 def synthetic_batch(B: int, size: int = 224, K: int = 16, seed: int = 0, dtype=torch.float32):

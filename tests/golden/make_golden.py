@@ -30,14 +30,21 @@ WEIGHTS = (0.1, 0.4, 0.7, 1.0)
 LR = 1e-3
 
 CASES = {
-    # name: (arch, B, image size, run adam?, run fp64?)
-    "r18_b2_s64": ("resnet18", 2, 64, True, True),
-    "r18_b8_s64": ("resnet18", 8, 64, True, True),
-    "r18_b8_s224": ("resnet18", 8, 224, True, True),   # BASELINE config 1 (fp64 reference: the noise floor at 224x224)
+    # name: (arch, B, image size, run adam?, run fp64?, input kind, 16-bit autocast runs of the reference)
+    "r18_b2_s64": ("resnet18", 2, 64, True, True, "normal", ()),
+    "r18_b8_s64": ("resnet18", 8, 64, True, True, "normal", ()),
+    "r18_b8_s224": ("resnet18", 8, 224, True, True, "normal", ()),   # BASELINE config 1 (fp64 reference: the noise floor at 224x224)
     # ResNet-50-derived model (1.665 B parameters): forward + loss + backward, no Adam (host RAM)
-    "r50_b2_s64": ("resnet50", 2, 64, False, False),
-    "r50_b8_s64": ("resnet50", 8, 64, False, True),
+    "r50_b2_s64": ("resnet50", 2, 64, False, False, "normal", ()),
+    "r50_b8_s64": ("resnet50", 8, 64, False, True, "normal", ()),
+    # WELL-CONDITIONED cases (oracle.diverse_batch: every image its own smooth pattern, mean and contrast): the
+    # reference's own fp32<->fp64 spread has a median of ~1e-5 here, so the 1e-3 gate bites; each also carries the
+    # reference run under torch.autocast("cpu", bfloat16 / float16) -- the yardstick of the product's 16-bit runs
+    "r18_b16_s64_div": ("resnet18", 16, 64, True, True, "diverse", ("bf16", "fp16")),
+    "r50_b8_s64_div": ("resnet50", 8, 64, False, True, "diverse", ("bf16",)),
 }
+LOWP = {"bf16": torch.bfloat16, "fp16": torch.float16}
+FP16_LOSS_SCALE = 1024.0  # a fixed power of two in place of the GradScaler's (ssl_train.py:100,472): exact to undo
 
 
 class _NoOpt:
@@ -104,8 +111,10 @@ def build_product(arch):
     return MSFWSI(my_resnet.__dict__[arch], 4)
 
 
-def reference_step(model, batch, B, do_adam):
-    """restates tools/ssl_train.py:281-310 (optimizer) and :441-474 (step) around the reference model"""
+def reference_step(model, batch, B, do_adam, autocast_dtype=None, loss_scale=1.0):
+    """restates tools/ssl_train.py:281-310 (optimizer) and :441-474 (step) around the reference model;
+    autocast_dtype: the forward and the loss run under torch.autocast("cpu", dtype) as under --amp (:441)"""
+    import contextlib
     import torch.nn as nn
 
     (c1, c2), (t1, t2), idx = batch
@@ -115,16 +124,26 @@ def reference_step(model, batch, B, do_adam):
     opt = torch.optim.Adam([{"params": g, "lr": lr} for g in groups], lr=lr)
     cos = nn.CosineSimilarity(dim=1)
     model.train()
-    out = model((c1, t1), (c2, t2), idx)
-    loss = 0
-    terms = []
-    for grp in out:
-        for i, (p1, p2, z1, z2) in enumerate(zip(*grp)):
-            t = -(cos(p1, z2).mean() + cos(p2, z1).mean()) * 0.5
-            terms.append(t.detach().clone())
-            loss = loss + t * WEIGHTS[i]
+    ctx = torch.autocast("cpu", dtype=autocast_dtype) if autocast_dtype is not None else contextlib.nullcontext()
+    with ctx:
+        out = model((c1, t1), (c2, t2), idx)
+        loss = 0
+        terms = []
+        for grp in out:
+            for i, (p1, p2, z1, z2) in enumerate(zip(*grp)):
+                if autocast_dtype is not None:
+                    # the reference runs on CUDA, whose autocast policy executes cosine_similarity in fp32 (it is on
+                    # the CUDA fp32 cast list, not on the CPU one): restate that here
+                    p1, p2, z1, z2 = p1.float(), p2.float(), z1.float(), z2.float()
+                t = -(cos(p1, z2).mean() + cos(p2, z1).mean()) * 0.5
+                terms.append(t.detach().clone())
+                loss = loss + t * WEIGHTS[i]
     opt.zero_grad()
-    loss.backward()
+    (loss * loss_scale).backward()
+    if loss_scale != 1.0:
+        for _, p in named:
+            if p.grad is not None:
+                p.grad.div_(loss_scale)
     if do_adam:
         grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in named}
         opt.step()
@@ -142,7 +161,7 @@ def rel(a, b):
 def run_case(name):
     from oracle import msfwsi_oracle as orc
 
-    arch, B, size, do_adam, do_f64 = CASES[name]
+    arch, B, size, do_adam, do_f64, kind, lowp = CASES[name]
     t0 = time.time()
     ref = build_reference(arch)
     sd0 = {k: v.detach().clone() for k, v in ref.state_dict().items()}
@@ -158,10 +177,10 @@ def run_case(name):
     del prod, psd
     print(f"[{name}] product init == reference init")
 
-    batch = orc.synthetic_batch(B, size, 16, DATA_SEED)
+    batch = orc.make_batch(kind, B, size, 16, DATA_SEED)
     vec = {}
     manifest = {"case": name, "arch": arch, "B": B, "size": size, "model_seed": MODEL_SEED, "hub_seed": HUB_SEED,
-                "data_seed": DATA_SEED, "lr": LR, "weights": WEIGHTS, "adam": do_adam,
+                "data_seed": DATA_SEED, "lr": LR, "weights": WEIGHTS, "adam": do_adam, "input_kind": kind,
                 "keys": [[k, list(v.shape), str(v.dtype)] for k, v in sd0.items()],
                 "provenance": "reference src/models imported from /root/reference"
                 + ("; resnet50 = derived oracle (width list x4), SURVEY.md 8c" if arch == "resnet50" else "")}
@@ -206,7 +225,7 @@ def run_case(name):
     if do_f64:
         del ref
         ref64 = build_reference(arch).double()
-        b64 = orc.synthetic_batch(B, size, 16, DATA_SEED, torch.float64)
+        b64 = orc.make_batch(kind, B, size, 16, DATA_SEED, torch.float64)
         loss64, terms64, out64, grads64 = reference_step(ref64, b64, B, do_adam)
         sd1_64 = {k: v.detach().clone() for k, v in ref64.state_dict().items() if do_adam or k.endswith(bn_keys)}
         gold_loss, gold_terms, gold_out, gold_grads, gold_sd1 = loss64, terms64, out64, grads64, sd1_64
@@ -220,6 +239,37 @@ def run_case(name):
         flat32 = [t for grp in out32 for tup in grp for t in tup]
         flat64 = [t for grp in out64 for tup in grp for t in tup]
         vec["spread_out"] = np.array([rel(a, b) for a, b in zip(flat32, flat64)])
+        del ref64
+        # ---- the reference under autocast (tools/ssl_train.py:96-100,441): distance of ITS 16-bit run from its fp64 run,
+        # per gradient tensor / output tensor / loss term
+        for tag in lowp:
+            refl = build_reference(arch)
+            scale = FP16_LOSS_SCALE if tag == "fp16" else 1.0
+            lossl, termsl, outl, gradsl = reference_step(refl, batch, B, False, LOWP[tag], scale)
+            fin = all(bool(torch.isfinite(g_).all()) for g_ in gradsl.values() if g_ is not None)
+            assert fin, f"{tag}: non-finite gradients at loss scale {scale}"
+            vec[f"spread_grad_{tag}"] = np.array([rel(gradsl[k], grads64[k]) if grads64[k] is not None else 0.0
+                                                  for k in grads64])
+            vec[f"spread_terms_{tag}"] = (termsl.double() - terms64).abs().numpy()
+            flatl = [t for grp in outl for tup in grp for t in tup]
+            vec[f"spread_out_{tag}"] = np.array([rel(a, b) for a, b in zip(flatl, flat64)])
+            vec[f"loss_{tag}"] = np.array([float(lossl)])
+            print(f"[{name}] reference under autocast({tag}): loss {float(lossl):.6f}; vs fp64: gradients median "
+                  f"{np.median(vec[f'spread_grad_{tag}']):.2e} max {vec[f'spread_grad_{tag}'].max():.2e}, outputs max "
+                  f"{vec[f'spread_out_{tag}'].max():.2e}, terms max {vec[f'spread_terms_{tag}'].max():.2e}")
+            if arch == "resnet18":  # pins the oracle's autocast mode to the reference's (skipped for the 1.665 B model: RAM)
+                osd = {k: v.clone() for k, v in sd0.items()}
+                ol, ot, oo, og = orc.train_step(osd, batch, _NoOpt(), 4, 0.5, WEIGHTS, loss_scale=scale,
+                                                autocast_dtype=LOWP[tag])
+                ro = np.array([rel(og[k], gradsl[k]) for k in gradsl if gradsl[k] is not None])
+                # same forward bit for bit; in backward the two accumulate the 16-bit gradient contributions of the
+                # weights used twice (two views) in a different order, so the gradients agree to a few 16-bit ulps
+                assert abs(float(ol) - float(lossl)) < 1e-6, (tag, float(ol), float(lossl))
+                assert np.median(ro) < 0.1 * np.median(vec[f"spread_grad_{tag}"]) and ro.max() < 5e-2, (tag, ro.max())
+                print(f"[{name}] oracle under autocast({tag}) vs reference under autocast: loss identical, gradients "
+                      f"median {np.median(ro):.1e} max {ro.max():.1e}")
+                del osd, og, oo
+            del refl, gradsl, outl
 
     vec["loss"] = np.array([float(gold_loss)])
     vec["loss_fp32"] = np.array([float(loss32)])
@@ -259,17 +309,99 @@ def run_case(name):
     print(f"[{name}] wrote fixtures ({time.time() - t0:.1f}s)")
 
 
+CURVE_SEED0 = 1000  # batch of step t: oracle.diverse_batch(seed = CURVE_SEED0 + t)
+FP16_STEPS = 6
+
+
+def run_curve_case(name="r18_b16_s64_curve", arch="resnet18", B=16, size=64, steps=30):
+    """Loss-curve pin ("bf16 runs: loss-curve parity"): `steps` iterations of the reference loop
+    (forward, loss, backward, torch.optim.Adam with the three prefix groups; tools/ssl_train.py:281-310,441-474) on
+    the REAL reference model, a fresh well-conditioned batch per step, in fp64, in fp32 and under
+    torch.autocast("cpu", bfloat16) / (float16 with a fixed loss scale).  The distance of the reference's own 16-bit
+    curve from its fp32 curve is the envelope the product's 16-bit curve is held to."""
+    import contextlib
+    import torch.nn as nn
+    from oracle import msfwsi_oracle as orc
+
+    cos = nn.CosineSimilarity(dim=1)
+    lr = LR * (B ** 0.5) / (32 ** 0.5)
+    vec = {}
+    t0 = time.time()
+    # fp16 convolutions have no fast path on this CPU (minutes per step): its curve stops after FP16_STEPS steps
+    for tag, wdt, ac, scale, nst in (("fp32", torch.float32, None, 1.0, steps), ("bf16", torch.float32, torch.bfloat16, 1.0, steps),
+                                     ("fp64", torch.float64, None, 1.0, steps),
+                                     ("fp16", torch.float32, torch.float16, FP16_LOSS_SCALE, FP16_STEPS)):
+        model = build_reference(arch)
+        if wdt == torch.float64:
+            model = model.double()
+        model.train()
+        named = list(model.named_parameters())
+        groups = [[p for n, p in named if n.startswith(pre)] for pre in ("context_", "target_", "inter_")]
+        opt = torch.optim.Adam([{"params": g, "lr": lr} for g in groups], lr=lr)
+        losses, terms_all = [], []
+        for t in range(nst):
+            (c1, c2), (t1, t2), idx = orc.diverse_batch(B, size, 16, CURVE_SEED0 + t, wdt)
+            ctx = torch.autocast("cpu", dtype=ac) if ac is not None else contextlib.nullcontext()
+            with ctx:
+                out = model((c1, t1), (c2, t2), idx)
+                loss, terms = 0, []
+                for grp in out:
+                    for i, (p1, p2, z1, z2) in enumerate(zip(*grp)):
+                        if ac is not None:  # CUDA autocast runs cosine_similarity in fp32 (see reference_step)
+                            p1, p2, z1, z2 = p1.float(), p2.float(), z1.float(), z2.float()
+                        tt = -(cos(p1, z2).mean() + cos(p2, z1).mean()) * 0.5
+                        terms.append(float(tt.detach()))
+                        loss = loss + tt * WEIGHTS[i]
+            opt.zero_grad()
+            (loss * scale).backward()
+            if scale != 1.0:
+                for _, p in named:
+                    p.grad.div_(scale)
+            assert all(bool(torch.isfinite(p.grad).all()) for _, p in named), (tag, t)
+            opt.step()
+            losses.append(float(loss))
+            terms_all.append(terms)
+        vec[f"loss_{tag}"] = np.array(losses)
+        vec[f"terms_{tag}"] = np.array(terms_all)
+        print(f"[{name}] {tag}: " + " ".join(f"{v:.4f}" for v in losses) + f"   ({time.time() - t0:.0f}s)")
+        if tag == "fp32":  # the oracle (its own Adam restatement) reproduces the reference's fp32 trajectory
+            osd = {k: v.detach().clone() for k, v in build_reference(arch).state_dict().items()}
+            oopt = orc.Adam(osd, [lr, lr, lr])
+            ol = []
+            for t in range(steps):
+                l_, _, _, _ = orc.train_step(osd, orc.diverse_batch(B, size, 16, CURVE_SEED0 + t), oopt, 4, 0.5, WEIGHTS)
+                ol.append(float(l_))
+            dev = np.abs(np.array(ol) - vec["loss_fp32"])
+            print(f"[{name}] oracle fp32 trajectory vs reference fp32: max |d| {dev.max():.2e}")
+            assert dev.max() < 2e-3, dev
+            vec["oracle_fp32_dev"] = dev
+    for tag in ("fp64", "bf16", "fp16"):
+        n = len(vec["loss_" + tag])
+        print(f"[{name}] max |{tag} - fp32| over the curve: {np.abs(vec['loss_' + tag] - vec['loss_fp32'][:n]).max():.4f}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **vec)
+    with open(os.path.join(HERE, name + ".json"), "w") as f:
+        json.dump({"case": name, "arch": arch, "B": B, "size": size, "steps": steps, "model_seed": MODEL_SEED,
+                   "hub_seed": HUB_SEED, "curve_seed0": CURVE_SEED0, "lr": LR, "weights": WEIGHTS,
+                   "input_kind": "diverse", "fp16_loss_scale": FP16_LOSS_SCALE, "fp16_steps": FP16_STEPS,
+                   "provenance": "reference src/models imported from /root/reference; loop statements of "
+                                 "tools/ssl_train.py:281-310,441-474 restated by make_golden.run_curve_case"}, f)
+
+
 def main():
     todo = sys.argv[1:] or ["r18_b2_s64", "r18_b8_s64", "r18_b8_s224", "encoder"]
     torch.set_num_threads(8)
     for c in todo:
         if c == "encoder":
             run_encoder_case()
+        elif c == "encoder_div":
+            run_encoder_case("r50enc_b16_s64_div", "resnet50", 16, 64, kind="diverse", lowp=("bf16", "fp16"))
+        elif c == "curve":
+            run_curve_case()
         else:
             run_case(c)
 
 
-def run_encoder_case(name="r50enc_b4_s64", arch="resnet50", B=4, size=64):
+def run_encoder_case(name="r50enc_b4_s64", arch="resnet50", B=4, size=64, kind="normal", lowp=()):
     """Bottleneck-path pin: the reference's ResNet-50 trunk alone (return_features=True), features of a seeded
     batch and the gradients of  L = sum_s <features_s, R_s>  for seeded random R_s (fp64 reference)."""
     from oracle import msfwsi_oracle as orc
@@ -288,7 +420,7 @@ def run_encoder_case(name="r50enc_b4_s64", arch="resnet50", B=4, size=64):
     msd = {k: v for k, v in mine.state_dict().items() if not k.startswith("fc.")}
     assert list(msd) == list(sd0) and all(torch.equal(msd[k], sd0[k]) for k in sd0), "init mismatch"
     g = torch.Generator().manual_seed(DATA_SEED)
-    x = torch.randn(B, 3, size, size, generator=g)
+    x = torch.randn(B, 3, size, size, generator=g) if kind == "normal" else orc.diverse_images(B, size, DATA_SEED)
     dims = [t.shape[1] for t in ref.double()(x.double())]
     Rs = [torch.randn(B, d, generator=g) for d in dims]
     ref = ref.double().train()
@@ -323,6 +455,22 @@ def run_encoder_case(name="r50enc_b4_s64", arch="resnet50", B=4, size=64):
     vec["spread_feat"] = np.array([rel(a, b) for a, b in zip(f32, feats)])
     print(f"[{name}] reference fp32<->fp64: features {vec['spread_feat'].max():.2e}, gradients median "
           f"{np.median(vec['spread_grad']):.2e} max {vec['spread_grad'].max():.2e}")
+    for tag in lowp:  # the reference trunk under autocast: distance of its 16-bit run from its fp64 run
+        torch.manual_seed(MODEL_SEED)
+        refl = ref_resnet.__dict__[arch](zero_init_residual=False, return_features=True)
+        refl.fc = torch.nn.Identity()
+        refl.load_state_dict({k: v for k, v in sd0.items()}, strict=False)
+        refl.train()
+        with torch.autocast("cpu", dtype=LOWP[tag]):
+            fl = refl(x)
+            ll = sum((f.float() * r).sum() for f, r in zip(fl, Rs))
+        ll.backward()
+        gl = {n: p.grad.detach() for n, p in refl.named_parameters() if not n.startswith("fc.")}
+        assert all(bool(torch.isfinite(v).all()) for v in gl.values()), tag
+        vec[f"spread_grad_{tag}"] = np.array([rel(gl[n], grads[n]) for n in grads])
+        vec[f"spread_feat_{tag}"] = np.array([rel(a, b) for a, b in zip(fl, feats)])
+        print(f"[{name}] reference under autocast({tag}) vs fp64: features {vec[f'spread_feat_{tag}'].max():.2e}, "
+              f"gradients median {np.median(vec[f'spread_grad_{tag}']):.2e} max {vec[f'spread_grad_{tag}'].max():.2e}")
     for s, f in enumerate(feats):
         vec[f"feat/{s}"] = f.detach().float().numpy()
     vec["grad_norm"] = np.array([float(g_.norm()) for g_ in grads.values()])
@@ -333,7 +481,7 @@ def run_encoder_case(name="r50enc_b4_s64", arch="resnet50", B=4, size=64):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **vec)
     with open(os.path.join(HERE, name + ".json"), "w") as f:
         json.dump({"case": name, "arch": arch, "B": B, "size": size, "model_seed": MODEL_SEED, "data_seed": DATA_SEED,
-                   "param_keys": list(grads), "feature_dims": dims,
+                   "param_keys": list(grads), "feature_dims": dims, "input_kind": kind,
                    "provenance": "reference src/models/resnet.py imported from /root/reference (trunk only)"}, f)
     print(f"[{name}] wrote fixtures, loss={float(loss):.9f}")
 

@@ -23,6 +23,13 @@ def test_oracle_on_a_hand_checked_case():
     assert abs(float(f1) - 8 / 11) < 1e-15 and abs(float(iou) - 4 / 7) < 1e-15 and abs(float(acc) - 15 / 18) < 1e-15
     f1c, iouc, accc = mo.scores(tp.sum(0), fp.sum(0), fn.sum(0), tn.sum(0), None)
     assert np.allclose(f1c, [4 / 5, 2 / 3, 2 / 3]) and np.allclose(iouc, [2 / 3, 1 / 2, 1 / 2])
+    # image-wise reductions (the training epoch's reduction="micro-imagewise", ssl_finetune.py:319) on two images
+    tp2 = np.array([[2, 1, 1], [0, 0, 3]]); fp2 = np.array([[0, 0, 1], [1, 0, 0]])
+    fn2 = np.array([[1, 1, 0], [0, 0, 1]]); tn2 = np.array([[3, 4, 4], [3, 4, 0]])
+    f1i, ioui, _ = mo.scores(tp2, fp2, fn2, tn2, "micro-imagewise")
+    assert abs(float(f1i) - 0.5 * (8 / 11 + 6 / 8)) < 1e-15 and abs(float(ioui) - 0.5 * (4 / 7 + 3 / 5)) < 1e-15
+    f1m, _, _ = mo.scores(tp2, fp2, fn2, tn2, "macro-imagewise")
+    assert abs(float(f1m) - (4 / 5 + 2 / 3 + 2 / 3 + 0 + 1 + 6 / 7) / 6) < 1e-15
     # a class that never occurs: 0/0 -> zero_division = 1.0 (smp default)
     tp0, fp0, fn0, tn0 = mo.get_stats_multiclass(np.array([[0, 0]]), np.array([[0, 0]]), 2)
     assert float(mo.scores(tp0.sum(0), fp0.sum(0), fn0.sum(0), tn0.sum(0), None)[0][1]) == 1.0
@@ -61,6 +68,10 @@ def test_seg_stats_match_oracle(hip_lib, dt, shape):
         assert abs(float(micro) - float(mo.scores(*want, "micro")[idx])) < 1e-14
         ref_c = mo.scores(*[w.sum(0) for w in want], None)[idx]
         assert np.allclose(per_class.cpu().numpy(), ref_c, rtol=0, atol=1e-14)
+        for red in ("micro-imagewise", "macro-imagewise"):
+            got_i = fn_(tp, fp, fn, tn, reduction=red)
+            torch.cuda.synchronize()
+            assert abs(float(got_i) - float(mo.scores(*want, red)[idx])) < 1e-13, red
 
 
 @pytest.mark.gpu

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (LR, WEIGHTS, build_product, flat_outputs, grad_rels, load_golden, other_spreads,
+from helpers import (LR, WEIGHTS, build_product, case_batch, flat_outputs, grad_rels, load_golden, other_spreads,
                      reference_loop_loss, rel, spread_gate, updated_weights_gate)
 
 pytestmark = pytest.mark.gpu
@@ -46,6 +46,7 @@ def run_reference_loop_case(case, check_golden_outputs=True):
 
     vec, man = load_golden(case)
     B, size = man["B"], man["size"]
+    diverse = man.get("input_kind", "normal") == "diverse"
     model = build_product(man["arch"])
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     # seeded construction reproduces the reference's initialisation (pinned by checksums)
@@ -53,7 +54,7 @@ def run_reference_loop_case(case, check_golden_outputs=True):
     got_sum = np.array([float(v.double().sum()) for v in sd0.values()])
     assert np.allclose(got_sum, vec["init_sum"], rtol=1e-9, atol=1e-9)
 
-    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
+    batch = case_batch(man)
     do_adam = bool(man["adam"])
     loss64, terms64, outs64, grads64, sd64 = oracle_step(sd0, batch, B, torch.float64, adam=do_adam)
     loss32, terms32, outs32, grads32, sd32 = oracle_step(sd0, batch, B, torch.float32, adam=do_adam)
@@ -98,7 +99,7 @@ def run_reference_loop_case(case, check_golden_outputs=True):
     box_spread = np.array([rel(grads32[n], grads64[n]) for n in names])
     fixture = [vec["spread_grad"]] if "spread_grad" in vec else []
     spread_gate(grad_rels(pg, grads64), names, fixture + [box_spread], f"{case} gradients vs fp64 oracle",
-                envelope=other_spreads("spread_grad", case))
+                envelope=() if diverse else other_spreads("spread_grad", case), strict_count=diverse)
     gold_norm = dict(zip(man["param_keys"], vec["grad_norm"]))
     rn = np.array([abs(float(g.double().norm()) - gold_norm[n]) / (gold_norm[n] + 1e-30) for n, g in pg])
     allow_n = np.maximum(1e-3, 2 * np.maximum(box_spread, fixture[0] if fixture else 0))
@@ -140,6 +141,18 @@ def test_step_parity_r50_b8_s64(hip_lib):
     """the ResNet-50-DERIVED model that configs 2-4 and bench.py run (heads at x4 widths, 1.665 B parameters, fuser
     GEMMs up to 18432 x 18432): forward, loss and every gradient against the derived oracle (SURVEY.md 8c)"""
     run_reference_loop_case("r50_b8_s64")
+
+
+def test_step_parity_r18_b16_s64_diverse(hip_lib):
+    """well-conditioned inputs (oracle.diverse_batch): the reference's own fp32<->fp64 spread has a median of ~1e-5
+    here and 3/4 of its gradient tensors sit below 1e-3, so the per-tensor gate bites at the north-star 1e-3 and rule 2's
+    count bound (2 x the reference's count) is below the number of tensors"""
+    run_reference_loop_case("r18_b16_s64_div")
+
+
+def test_step_parity_r50_b8_s64_diverse(hip_lib):
+    """the ResNet-50-derived model on well-conditioned inputs (see above; VERDICT r2 weak #2)"""
+    run_reference_loop_case("r50_b8_s64_div")
 
 
 def test_cpu_tensors_fail_loudly(hip_lib):

@@ -86,26 +86,6 @@ def test_fused_single_step_weights_fp32(hip_lib):
             assert torch.allclose(model.state_dict()[k].cpu().double(), v, rtol=1e-4, atol=1e-6), k
 
 
-def test_fused_step_bf16_tracks_fp32(hip_lib):
-    """bf16 storage / bf16 MFMA: loss-level agreement only (as for the reference under autocast)"""
-    from msf_wsi_amd.train import PretrainStep
-    from oracle import msfwsi_oracle as orc
-
-    vec, man = load_golden("r18_b8_s64")
-    B, size = man["B"], man["size"]
-    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
-    model = build_product("resnet18").cuda().train()
-    ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.bfloat16)
-    losses = [float(ts.step(_gpu_batch(batch))) for _ in range(3)]
-    torch.cuda.synchronize()
-    assert all(np.isfinite(losses))
-    assert abs(losses[0] - float(vec["loss"][0])) < 3e-2
-    assert ts.found_inf.item() == 0 and ts.scale.item() == 65536.0
-    # the bf16 compute copies follow the fp32 master weights
-    for gi in range(3):
-        assert torch.equal(ts.flats.w16[gi].float(), ts.flats.w[gi].bfloat16().float())
-
-
 def test_fused_step_fp16_with_loss_scaling(hip_lib):
     """fp16 storage / fp16 MFMA (the reference's default --amp dtype): the GradScaler protocol keeps the step
     finite -- a step is either applied, or skipped with the scale halved (tools/ssl_train.py:472-474)"""
@@ -208,56 +188,3 @@ def test_infonce_variant_matches_torch_restatement(hip_lib):
     rels = np.array([rel(ts.grads.logical(p), g64[n]) for n, p in named])
     box = np.array([rel(g32[n], g64[n]) for n in names])
     spread_gate(rels, names, [box], "InfoNCE gradients vs the torch restatement (fp64)")
-
-
-def test_stationary_kernels_agree_with_gather_kernels_bf16(hip_lib, monkeypatch):
-    """the shape-specialised persistent kernels of round 2 against the gather kernels they replace, on a whole bf16 step.
-    (a) output-stationary weight gradients (64->64 3x3 with the fused BatchNorm+ReLU prologue, stem): the forward is
-    untouched, so the gradients must agree to summation-order noise.  (b) the weights-stationary forward rounds an
-    output to the other bf16 neighbour now and then (3e-5 relative on a layer); at 8 tile pairs of 64x64 the heads'
-    BatchNorm1d over 8 samples amplifies that to tens of percent on the gradients -- for EVERY bf16 run: the gather
-    build is 0.4-0.5 away from the fp32 gradients itself.  So (b) asks that the stationary build is no further from the
-    fp32 gradients than the gather build (x 1.25), and that the loss agrees to 2e-3."""
-    from msf_wsi_amd import kernels as kn
-    from msf_wsi_amd.train import PretrainStep
-    from oracle import msfwsi_oracle as orc
-
-    vec, man = load_golden("r18_b8_s64")
-    B, size = man["B"], man["size"]
-    batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
-    d1 = kn.conv_desc(torch.bfloat16, B * 16, size // 4, size // 4, 64, 64, 3, 3, 1, 1)  # layer1 of the target pass
-
-    def run(k9, k10, k12, dtype=torch.bfloat16):
-        hip_lib.msfwsi_set_tuning(9, k9)
-        hip_lib.msfwsi_set_tuning(10, k10)
-        hip_lib.msfwsi_set_tuning(12, k12)
-        hip_lib.msfwsi_set_tuning(11, 0)   # no size thresholds: the small test batch takes the persistent kernels
-        hip_lib.msfwsi_set_tuning(13, 0)
-        monkeypatch.setenv("MSFWSI_FUSE_PRO3X3", str(int(bool(k9 or k10))))
-        assert kn.conv3x3_stationary(d1) == bool(k9) and kn.conv_wgrad_stationary(d1) == bool(k10)
-        model = build_product("resnet18").cuda().train()
-        ts = PretrainStep(model, lr=LR, global_batch=B, dtype=dtype)
-        loss = float(ts.step(_gpu_batch(batch)))
-        torch.cuda.synchronize()
-        return loss, [g.double() / ts.scale.item() for g in ts.flats.g]
-
-    def rels(a, b):
-        return [float((x - y).norm() / (y.norm() + 1e-30)) for x, y in zip(a, b)]
-
-    try:
-        l32, g32 = run(0, 0, 0, torch.float32)
-        lg, gg = run(0, 0, 0)
-        lw, gw = run(0, 1, 1)
-        ls, gs = run(1, 1, 1)
-    finally:
-        for key in (9, 10, 12):
-            hip_lib.msfwsi_set_tuning(key, 1)
-        hip_lib.msfwsi_set_tuning(11, 32 * 256 * 256)
-        hip_lib.msfwsi_set_tuning(13, 32 * 512 * 256)
-    ra = rels(gw, gg)
-    print("(a) output-stationary weight gradients vs gather, per group:", ra)
-    assert abs(lw - lg) < 1e-6 and max(ra) < 1e-3, (lw, lg, ra)
-    rg, rs = rels(gg, g32), rels(gs, g32)
-    print("(b) bf16 vs fp32 gradients, gather build:", rg, " stationary build:", rs, " losses", lg, ls, l32)
-    assert abs(ls - lg) <= 2e-3, (ls, lg)
-    assert all(s_ <= 1.25 * g_ + 1e-3 for s_, g_ in zip(rs, rg)), (rs, rg)
