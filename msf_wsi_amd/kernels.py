@@ -1073,7 +1073,7 @@ def seg_scores(tp, fp, fn, tn, zero_division: float = 1.0):
 
 
 def seg_scores_imagewise(tp, fp, fn, tn, zero_division: float = 1.0):
-    """fp64 [6]: F1 / IoU / accuracy with smp's "micro-imagewise" reduction, then with "macro-imagewise""""
+    """fp64 [6]: F1 / IoU / accuracy with smp's 'micro-imagewise' reduction, then with 'macro-imagewise'"""
     lib = _lib.load()
     N, Cn = tp.shape
     for nm, t in (("tp", tp), ("fp", fp), ("fn", fn), ("tn", tn)):
