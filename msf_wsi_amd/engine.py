@@ -214,6 +214,7 @@ class Engine:
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
         self.stem_s2d = os.environ.get("MSFWSI_STEM_S2D", "1") != "0"  # ... in space-to-depth form (4x4 / stride 1)
         self.pair_head_wgrad = os.environ.get("MSFWSI_PAIR_HEAD_WGRAD", "1") != "0"  # one dW launch for both views
+        self.pair_head_fwd = os.environ.get("MSFWSI_PAIR_HEAD_FWD", "1") != "0"  # ... and one forward GEMM per layer
         # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
         # stem_pool_bwd + bn_bwd_apply (the pool-backward window logic is VALU-bound, not byte-bound): off
         self.stem_two_pass = os.environ.get("MSFWSI_STEM_TWO_PASS", "0") != "0"
@@ -1143,6 +1144,68 @@ class Engine:
             raise NotImplementedError("a head must end in Linear or BatchNorm (no trailing ReLU)")
         return ChainRec(units, out.view(rows, -1))
 
+    def chain_forward_pair(self, seq: nn.Sequential, xs: Sequence[torch.Tensor], dtype) -> List[ChainRec]:
+        """chain_forward for the two views of one head at once: every Linear runs ONCE on the stacked rows of both
+        views (the 18432-wide fuser layers have 256 rows per view and are bound by reading their 680 MB weight matrix:
+        once instead of twice), while every BatchNorm keeps its per-view batch -- statistics, running-statistics
+        updates (view 0 then view 1, backbone.py:161-186) and the normalisation are per view on the row halves."""
+        rows = [x.shape[0] for x in xs]
+        tot = sum(rows)
+        offs = [0, rows[0]]
+        dev = xs[0].device
+        Cin0 = xs[0].shape[-1]
+        cur = torch.empty(tot, Cin0, dtype=dtype, device=dev)
+        for v, x in enumerate(xs):
+            kn.copy2d(x.reshape(rows[v], Cin0), 0, Cin0, cur, offs[v] * Cin0, Cin0, rows[v], Cin0)
+        units: List[List[Unit]] = [[], []]
+        pros: List[Optional[BNState]] = [None, None]
+        raw = cur  # per view: the raw operand of the current layer (rows of `raw`), normalised into `cur` when pro
+        outs: List[Optional[torch.Tensor]] = [None, None]
+        for lin, bn, relu in self._parse_chain(seq):
+            Cin, K = lin.in_features, lin.out_features
+            if pros[0] is not None:  # BatchNorm + ReLU of the previous layer, per view, into the stacked operand
+                cur = torch.empty(tot, Cin, dtype=dtype, device=dev)
+                for v in range(2):
+                    kn.bn_act(raw[offs[v]:offs[v] + rows[v]], pros[v].scale, pros[v].shift,
+                              cur[offs[v]:offs[v] + rows[v]], relu=True)
+            d = kn.conv_desc(dtype, tot, 1, 1, Cin, K, 1, 1, 1, 0)
+            w = self.weights.get(lin.weight, dtype)
+            c = torch.empty(tot, 1, 1, K, dtype=dtype, device=dev)
+            bias = getattr(lin, "bias", None)
+            kn.conv_fwd(d, cur.view(tot, 1, 1, Cin), w, c, bias=bias.data if bias is not None else None)
+            nxt_pro: List[Optional[BNState]] = [None, None]
+            for v in range(2):
+                cv = c[offs[v]:offs[v] + rows[v]]
+                xv = raw[offs[v]:offs[v] + rows[v]].view(rows[v], 1, 1, Cin)
+                dv = kn.conv_desc(dtype, rows[v], 1, 1, Cin, K, 1, 1, 1, 0)
+                u = Unit(lin, bn, relu, dv, xv, pros[v], cv)
+                if bn is not None:
+                    stats = kn.new_stats(K, 2, dev)
+                    kn.colstats(cv, stats)  # fp64 column statistics (see _unit_fwd: the heads' cancellation problem)
+                    u.st = self._bn_finalize(stats, rows[v], bn)
+                units[v].append(u)
+                if bn is not None and not relu:
+                    out = torch.empty(rows[v], K, dtype=dtype, device=dev)
+                    kn.bn_act(cv, u.st.scale, u.st.shift, out, relu=False)
+                    outs[v] = out
+                elif bn is not None:
+                    nxt_pro[v], outs[v] = u.st, None
+                else:
+                    outs[v] = cv.view(rows[v], K)
+            if nxt_pro[0] is not None:
+                raw, pros = c.view(tot, K), nxt_pro
+            else:  # the layer's output itself feeds the next layer (no BatchNorm + ReLU in between)
+                if outs[0].data_ptr() == c.data_ptr():
+                    raw = cur = c.view(tot, K)
+                else:
+                    raw = cur = torch.empty(tot, K, dtype=dtype, device=dev)
+                    for v in range(2):
+                        kn.copy2d(outs[v], 0, K, cur, offs[v] * K, K, rows[v], K)
+                pros = [None, None]
+        if outs[0] is None:
+            raise NotImplementedError("a head must end in Linear or BatchNorm (no trailing ReLU)")
+        return [ChainRec(units[v], outs[v].view(rows[v], -1)) for v in range(2)]
+
     def chain_backward(self, rec: ChainRec, d_out: torch.Tensor, grads: GradStore, dtype, need_dx=True):
         """d_out: engine-owned buffer (overwritten in place)."""
         cur = d_out
@@ -1210,8 +1273,12 @@ class Engine:
                 cs = torch.zeros(Kout, dtype=torch.float64, device=dev)
                 kn.colsum(dcat, cs)
                 kn.add_f64_to_f32(cs, grads.get(bias), 1.0)
-            for v, u in enumerate(us):
-                curs[v] = self._unit_dgrad(u, curs[v], dtype)
+            # ... and ONE input-gradient launch on the stacked rows (the weights are read once for both views)
+            dxcat = self._unit_dgrad(Unit(u0.op, None, False, dpair, xcat, None, None), dcat, dtype)
+            off = 0
+            for v in range(len(us)):
+                curs[v] = dxcat[off:off + rows[v]].view(rows[v], Cin)
+                off += rows[v]
         return [c.view(c.shape[0], -1) for c in curs]
 
     # ---- whole model -----------------------------------------------------------------------------
@@ -1285,6 +1352,7 @@ class Engine:
             proj = getattr(model, f"{grp}_projector")
             pred = getattr(model, f"{grp}_predictor")
             for s in range(4):
+                fs = []
                 for v in range(2):
                     cf = rec.enc[f"c{v}"].feats[s]
                     tf = rec.enc[f"t{v}"].feats[s]
@@ -1300,10 +1368,16 @@ class Engine:
                         f = torch.empty(B, D, dtype=dtype, device=dev)
                         kn.copy2d(cf, 0, Cs, f, 0, D, B, Cs)
                         kn.copy2d(tf, 0, K * Cs, f, Cs, D, B, n_keep * Cs)
-                    zrec = self.chain_forward(proj[s], f, dtype)
-                    prec = self.chain_forward(pred[s], zrec.out, dtype)
-                    rec.heads[(grp, s, v)] = (zrec, prec)
-                    outs[(grp, s, v)] = (prec.out, zrec.out)
+                    fs.append(f)
+                if self.pair_head_fwd:
+                    zrecs = self.chain_forward_pair(proj[s], fs, dtype)
+                    precs = self.chain_forward_pair(pred[s], [z.out for z in zrecs], dtype)
+                else:
+                    zrecs = [self.chain_forward(proj[s], f, dtype) for f in fs]
+                    precs = [self.chain_forward(pred[s], z.out, dtype) for z in zrecs]
+                for v in range(2):
+                    rec.heads[(grp, s, v)] = (zrecs[v], precs[v])
+                    outs[(grp, s, v)] = (precs[v].out, zrecs[v].out)
         result = []
         for grp in ("context", "target", "inter"):
             result.append((tuple(outs[(grp, s, 0)][0] for s in range(4)), tuple(outs[(grp, s, 1)][0] for s in range(4)),

@@ -12,9 +12,11 @@ WEIGHTS = (0.1, 0.4, 0.7, 1.0)
 LR = 1e-3
 
 
-def install_hub_stub():
+def install_hub_stub(residual_gain=1.0):
     """offline torch.hub stand-in: an un-pretrained net of the same arch under HUB_SEED, built with the
-    product's own factories; the caller's RNG stream is untouched (same protocol as make_golden.py)."""
+    product's own factories; the caller's RNG stream is untouched (same protocol as make_golden.py).
+    residual_gain: scale of every residual branch's closing BatchNorm gain (make_golden.hub_stub: the well-conditioned
+    cases stand in for the reference's TRAINED ImageNet weights with gain 0.1; manifest key stub_residual_gain)."""
     from msf_wsi_amd.models import resnet as my_resnet
 
     def fake(url, progress=True, **kw):
@@ -23,18 +25,28 @@ def install_hub_stub():
         torch.manual_seed(HUB_SEED)
         sd = my_resnet.__dict__[arch](pretrained=False).state_dict()
         torch.random.set_rng_state(state)
+        if residual_gain != 1.0:
+            last = ".bn2.weight" if arch in ("resnet18", "resnet34") else ".bn3.weight"
+            for k in sd:
+                if k.startswith("layer") and k.endswith(last):
+                    sd[k] = sd[k] * residual_gain
         return sd
 
     torch.hub.load_state_dict_from_url = fake
 
 
-def build_product(arch="resnet18", scale=4):
+def build_product(arch="resnet18", scale=4, residual_gain=1.0):
     from msf_wsi_amd.models import resnet as my_resnet
     from msf_wsi_amd.models.backbone import MSFWSI
 
-    install_hub_stub()
+    install_hub_stub(residual_gain)
     torch.manual_seed(MODEL_SEED)
     return MSFWSI(my_resnet.__dict__[arch], scale)
+
+
+def build_case(man):
+    """the product model of a golden case (architecture and hub-stub variant from its manifest)"""
+    return build_product(man["arch"], residual_gain=man.get("stub_residual_gain", 1.0))
 
 
 def case_batch(man, dtype=torch.float32):
@@ -162,7 +174,7 @@ def oracle_case(case):
 
     vec, man = load_golden(case)
     B, size = man["B"], man["size"]
-    model = build_product(man["arch"])
+    model = build_case(man)
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     names = [n for n, _ in model.named_parameters()]
     del model

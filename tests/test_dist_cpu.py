@@ -186,3 +186,35 @@ def test_bench_self_launcher_rendezvous():
                        capture_output=True, text=True, timeout=600)
     if not __import__("torch").cuda.is_available():
         assert r.returncode != 0
+
+
+def _plan_worker(rank, world, port, ret):
+    """two ranks whose LOCAL measurements differ (bytes per image, free memory -> local proposal) must issue the plan
+    collective on the same steps and adopt the same, most conservative, plan (the cache key used to hold
+    the locally measured bytes per image, so one rank could skip the collective while its peer issued it)"""
+    from msf_wsi_amd.engine import Engine
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        eng = Engine(sync_bn=True)
+        eng.recompute = "auto"
+        local = [(set(), False), ({"t1"}, False)][rank]        # rank 1 is short of memory
+        eng._plan_local = lambda *a, **k: (set(local[0]), local[1])
+        got = []
+        for step in range(3):
+            per_image = 22.5e6 + 4096 * rank + 512 * step       # allocator noise: differs per rank AND per step
+            nosave = eng._plan_recompute(per_image, 8, 16, torch.device("cpu"), 0.0, shape_key=((3, 64, 64), "r18"))
+            got.append((tuple(sorted(nosave)), eng.last_plan, eng.collectives))
+        nosave = eng._plan_recompute(1e6, 4, 16, torch.device("cpu"), 0.0, shape_key=((3, 64, 64), "r18"))  # a new shape
+        got.append((tuple(sorted(nosave)), eng.last_plan, eng.collectives))
+        ret[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_recompute_plan_is_rank_invariant():
+    ret = mp.Manager().dict()
+    mp.spawn(_plan_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == ret[1], (ret[0], ret[1])
+    assert [g[0] for g in ret[0]] == [("t1",)] * 4 and ret[0][0][1] == "recompute:t1"
+    assert [g[2] for g in ret[0]] == [1, 1, 1, 2]  # one plan collective per shape, on both ranks alike

@@ -110,3 +110,78 @@ def test_encoder_inference_mode_and_bf16(hip_lib):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):  # the reference's default --amp dtype
         h16 = enc(x)
     assert h16[0].dtype == torch.float16 and rel(h16[0].float(), f32[0]) < 5e-3
+
+
+def _trunk_case(man):
+    """product ResNet-50 trunk + fp64 oracle gradients of the well-conditioned trunk case on this machine"""
+    from msf_wsi_amd.models import resnet
+    from oracle import msfwsi_oracle as orc
+
+    B, size, gain = man["B"], man["size"], man["stub_residual_gain"]
+    torch.manual_seed(MODEL_SEED)
+    enc = resnet.resnet50(zero_init_residual=False, return_features=True)
+    enc.fc = torch.nn.Identity()
+    with torch.no_grad():  # trained-like residual gains, as make_golden.run_encoder_case
+        for k, v in enc.state_dict().items():
+            if k.startswith("layer") and k.endswith(".bn3.weight"):
+                v.mul_(gain)
+    sd0 = {k: v.detach().clone() for k, v in enc.state_dict().items() if not k.startswith("fc.")}
+    x = orc.diverse_images(B, size, man["data_seed"])
+    return enc, sd0, x
+
+
+def _trunk_oracle(man, vec, sd0, x, Rs):
+    from oracle import msfwsi_oracle as orc
+
+    osd = {"e." + k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    for k, v in osd.items():
+        if orc.is_param(k):
+            v.requires_grad_(True)
+    of = orc.encoder_forward(osd, "e.", x.double())
+    ol = sum((f * r.double()).sum() for f, r in zip(of, Rs))
+    ol.backward()
+    assert abs(float(ol) - float(vec["loss"][0])) <= 1e-9 * abs(float(vec["loss"][0]))  # pinned: the reference's fp64 loss
+    return [f.detach() for f in of], {k[2:]: v.grad for k, v in osd.items() if orc.is_param(k)}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
+def test_resnet50_trunk_well_conditioned(hip_lib, dtype):
+    """the Bottleneck trunk (folded tails, two-source launches, stationary kernels where the size gate allows) on the
+    well-conditioned trunk case r50enc_b16_s64_div: every gradient tensor of  L = sum_s <features_s, R_s>  against the
+    fp64 oracle of this machine (pinned to the reference's fp64 loss by the fixture).  fp32: max(1e-3, 2 x the
+    reference's own fp32<->fp64 spread) with a rule-2 count that can trip; 16-bit: the reference-under-autocast spread."""
+    from helpers import LOWP_FLOOR, LOWP_TAG, lowp_gate
+
+    vec, man = load_golden("r50enc_b16_s64_div")
+    from oracle import msfwsi_oracle as orc
+
+    enc, sd0, x = _trunk_case(man)
+    g = torch.Generator().manual_seed(man["data_seed"])
+    if man["input_kind"] == "normal":
+        torch.randn(man["B"], 3, man["size"], man["size"], generator=g)
+    Rs = [torch.randn(man["B"], d, generator=g) for d in man["feature_dims"]]
+    f64, g64 = _trunk_oracle(man, vec, sd0, x, Rs)
+    enc = enc.cuda().train()
+    scale = 1024.0 if dtype == torch.float16 else 1.0
+    if dtype == torch.float32:
+        feats = enc(x.cuda())
+        loss = sum((f * r.cuda()).sum() for f, r in zip(feats, Rs))
+    else:
+        with torch.autocast("cuda", dtype=dtype):
+            feats = enc(x.cuda())
+        loss = sum((f.float() * r.cuda()).sum() for f, r in zip(feats, Rs))
+    (loss * scale).backward()
+    torch.cuda.synchronize()
+    named = dict(enc.named_parameters())
+    names = man["param_keys"]
+    rels = np.array([rel(named[k].grad.double().cpu() / scale, g64[k]) for k in names])
+    fr = np.array([rel(f.float(), r) for f, r in zip(feats, f64)])
+    if dtype == torch.float32:
+        assert fr.max() < 1e-3, fr
+        spread_gate(rels, names, [vec["spread_grad"]], "resnet50 trunk (well-conditioned), fp32 gradients",
+                    strict_count=True)
+    else:
+        tag = LOWP_TAG[dtype]
+        print(f"[trunk {tag}] features rel {fr}, reference under autocast {vec[f'spread_feat_{tag}']}")
+        assert (fr <= np.maximum(LOWP_FLOOR[dtype], 2.0 * vec[f"spread_feat_{tag}"])).all(), fr
+        lowp_gate(rels, names, vec[f"spread_grad_{tag}"], LOWP_FLOOR[dtype], f"resnet50 trunk {tag}: gradients")

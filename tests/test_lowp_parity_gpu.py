@@ -13,11 +13,17 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (LOWP_FLOOR, LOWP_TAG, LR, build_product, case_batch, flat_outputs, load_golden, lowp_gate,
+from helpers import (LOWP_FLOOR, LOWP_TAG, LR, build_case, case_batch, flat_outputs, load_golden, lowp_gate,
                      oracle_case, reference_loop_loss, rel)
 
 pytestmark = pytest.mark.gpu
 FP16_LOSS_SCALE = 1024.0  # the fixed power of two the fixture's fp16 reference run used
+
+
+def term_scale(spread_terms):
+    """per loss term: max(its own reference distance, the RMS over the 4 scales of its group)"""
+    sp = np.asarray(spread_terms, dtype=np.float64).reshape(3, 4)
+    return np.maximum(sp, np.sqrt((sp ** 2).mean(axis=1, keepdims=True))).reshape(-1)
 
 
 def lowp_step(case, dtype, mutate=None):
@@ -25,7 +31,7 @@ def lowp_step(case, dtype, mutate=None):
     returns the gate inputs.  mutate(model): test hook applied before the step (fault injection)."""
     vec, man = load_golden(case)
     oc = oracle_case(case)
-    model = build_product(man["arch"]).cuda().train()
+    model = build_case(man).cuda().train()
     (c1, c2), (t1, t2), idx = case_batch(man)
     scale = FP16_LOSS_SCALE if dtype == torch.float16 else 1.0
     if mutate is not None:
@@ -51,12 +57,13 @@ def gate_lowp_step(case, dtype, what, mutate=None):
     assert all(fo[k].dtype == dtype for k in keys)
     lowp_gate([rel(fo[k].float(), fr[k]) for k in keys], ["/".join(map(str, k)) for k in keys], vec[f"spread_out_{tag}"],
               floor, f"{what}: outputs", max_violations=0.1)
-    # ---- the 12 loss terms
+    # ---- the 12 loss terms.  One reference sample's |d| of a single term can be near zero by chance: the allowance of a
+    # term is 2 x the larger of its own reference distance and the RMS distance over the 4 terms of its group
     d = (terms - oc["terms64"]).abs().numpy()
-    allow = np.maximum(1e-3 * np.maximum(oc["terms64"].abs().numpy(), 1e-2), 2.0 * vec[f"spread_terms_{tag}"])
+    allow = np.maximum(1e-3 * np.maximum(oc["terms64"].abs().numpy(), 1e-2), 2.0 * term_scale(vec[f"spread_terms_{tag}"]))
     print(f"[{what}] loss terms: max |d| {d.max():.2e}, allowance min {allow.min():.2e} max {allow.max():.2e}; "
           f"{int((d > allow).sum())}/12 beyond")
-    assert (d > allow).sum() <= 1 and d.max() <= 2.0 * allow.max(), (d, allow)
+    assert (d <= allow).all(), (d, allow)
     # ---- gradients
     lowp_gate([rel(g, oc["grads64"][n]) for n, g in grads], [n for n, _ in grads], vec[f"spread_grad_{tag}"], floor,
               f"{what}: gradients")
@@ -104,7 +111,7 @@ def test_fused_step_lowp_first_step(hip_lib, dtype):
     vec, man = load_golden(case)
     oc = oracle_case(case)
     tag, floor = LOWP_TAG[dtype], LOWP_FLOOR[dtype]
-    model = build_product(man["arch"]).cuda().train()
+    model = build_case(man).cuda().train()
     ts = PretrainStep(model, lr=LR, global_batch=man["B"], dtype=dtype,
                       init_scale=65536.0 if dtype == torch.bfloat16 else FP16_LOSS_SCALE)
     (c1, c2), (t1, t2), idx = case_batch(man)
@@ -115,7 +122,7 @@ def test_fused_step_lowp_first_step(hip_lib, dtype):
     torch.cuda.synchronize()
     w = np.tile(np.array([0.1, 0.4, 0.7, 1.0]), 3)
     allow = float((w * np.maximum(1e-3 * np.maximum(oc["terms64"].abs().numpy(), 1e-2),
-                                  2.0 * vec[f"spread_terms_{tag}"])).sum())
+                                  2.0 * term_scale(vec[f"spread_terms_{tag}"]))).sum())
     print(f"[fused {tag}] loss {loss:.6f} fp64 oracle {oc['loss64']:.6f} allowance {allow:.2e}")
     assert abs(loss - oc["loss64"]) <= allow
     named = list(model.named_parameters())
@@ -168,10 +175,15 @@ def test_loss_curve_tracks_reference(hip_lib, dtype):
     ref16 = vec[f"loss_{tag}"]
     steps = len(ref16)  # bf16: 30; fp16: the first few (fp16 has no fast CPU path for the reference run)
     ref32 = vec["loss_fp32"][:steps]
+    # envelope: the largest distance from the reference's fp32 curve that (a) the reference's own autocast curve, (b) its
+    # fp64 curve and (c) the ORACLE's fp32 curve have shown up to step t.  (c) is there because the trajectory is
+    # chaotic (Adam's first steps are sign-like): two fp32 implementations that agree to 1e-6 on one step are 1e-3
+    # apart after 5 steps and 1e-1 after 20 (fixture key oracle_fp32_dev)
     env = np.maximum.accumulate(np.abs(ref16 - ref32))
     env = np.maximum(env, np.maximum.accumulate(np.abs(vec["loss_fp64"][:steps] - ref32)))
+    env = np.maximum(env, np.maximum.accumulate(vec["oracle_fp32_dev"][:steps]))
     allow = np.maximum(2e-3, 2.0 * env)
-    model = build_product(man["arch"]).cuda().train()
+    model = build_case(man).cuda().train()
     ts = PretrainStep(model, lr=LR, global_batch=B, dtype=dtype,
                       init_scale=65536.0 if dtype == torch.bfloat16 else man["fp16_loss_scale"])
     losses = []
@@ -188,6 +200,12 @@ def test_loss_curve_tracks_reference(hip_lib, dtype):
     if steps >= 30:
         assert (ref32[-1] - ref32[0]) < -0.5, "the fixture's curve must move for this test to mean anything"
     assert (d <= allow).all(), (int(np.argmax(d / allow)), float((d / allow).max()))
+    if steps >= 30:  # the curve as a whole: mean loss of the last 10 steps within 2 x the reference's own deviation there
+        tail = lambda c: float(np.mean(c[-10:]))
+        dev_ref = max(abs(tail(ref16) - tail(ref32)), abs(tail(vec["loss_fp64"]) - tail(ref32)), 0.02)
+        print(f"[{tag} curve] mean of the last 10 steps: product {tail(losses):.4f} reference fp32 {tail(ref32):.4f} "
+              f"(reference {tag} {tail(ref16):.4f}, fp64 {tail(vec['loss_fp64']):.4f})")
+        assert abs(tail(losses) - tail(ref32)) <= 2.0 * dev_ref
     assert ts.found_inf.item() == 0
     for gi in range(3):  # the 16-bit compute copies follow the fp32 master weights
         assert torch.equal(ts.flats.w16[gi].float(), ts.flats.w[gi].to(dtype).float())

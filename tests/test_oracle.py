@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import LR, WEIGHTS, build_product, case_batch, load_golden, rel
+from helpers import LR, WEIGHTS, build_case, build_product, case_batch, load_golden, rel
 
 
 @pytest.fixture(scope="module", params=["r18_b8_s64", "r18_b16_s64_div"])
@@ -13,7 +13,7 @@ def case(request):
     from oracle import msfwsi_oracle as orc
 
     vec, man = load_golden(request.param)
-    model = build_product(man["arch"])
+    model = build_case(man)
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     B = man["B"]
     batch = case_batch(man)
@@ -150,7 +150,7 @@ def test_oracle_under_autocast_is_a_sample_of_the_reference_under_autocast():
     from oracle import msfwsi_oracle as orc
 
     vec, man = load_golden("r18_b16_s64_div")
-    model = build_product(man["arch"])
+    model = build_case(man)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     nop = type("NoOpt", (), {"step": lambda self, *a, **k: None})()
     loss, terms, _, grads = orc.train_step(sd, case_batch(man), nop, 4, 0.5, WEIGHTS, autocast_dtype=torch.bfloat16)

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (LR, WEIGHTS, build_product, case_batch, flat_outputs, grad_rels, load_golden, other_spreads,
+from helpers import (LR, WEIGHTS, build_case, build_product, case_batch, flat_outputs, grad_rels, load_golden, other_spreads,
                      reference_loop_loss, rel, spread_gate, updated_weights_gate)
 
 pytestmark = pytest.mark.gpu
@@ -47,7 +47,7 @@ def run_reference_loop_case(case, check_golden_outputs=True):
     vec, man = load_golden(case)
     B, size = man["B"], man["size"]
     diverse = man.get("input_kind", "normal") == "diverse"
-    model = build_product(man["arch"])
+    model = build_case(man)
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     # seeded construction reproduces the reference's initialisation (pinned by checksums)
     assert [k for k in sd0] == [k for k, _, _ in man["keys"]]
