@@ -132,6 +132,15 @@ int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* 
  * Replaces: convolution_backward(weight) / linear backward(weight), tools/ssl_train.py:472. */
 int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* pro_scale,
                       const float* pro_shift, int target_blocks, void* stream);
+/* The stem's weight gradient (space-to-depth form, 2-byte types) with the BatchNorm backward of bn1 applied on the
+ * fly: dw[64][4][4][16] += (k1*g + k2*c0 + k3)^T x, where g is the gated gradient of bn1's output, c0 the raw conv
+ * output and k1..k3 the coefficients of msfwsi_bn_bwd_finalize; the bracket is rounded to the storage type exactly as
+ * msfwsi_bn_bwd_apply rounds it, but is neither written nor re-read (-2 passes over the largest tensor of the network).
+ * MSFWSI_EUNSUPPORTED where the output-stationary stem kernel does not apply (other geometries / fp32 / small batches):
+ * the caller then runs msfwsi_bn_bwd_apply + msfwsi_conv_wgrad.
+ * Replaces: native_batch_norm_backward + convolution_backward(weight) of conv1/bn1, src/models/resnet.py:234-235. */
+int msfwsi_stem_wgrad_bnbwd(const msfwsi_conv_desc* d, const void* x, const void* g, const void* c0, const float* k1,
+                            const float* k2, const float* k3, float* dw, void* stream);
 /* 1 if msfwsi_conv_wgrad serves this geometry with the output-stationary persistent kernel (2-byte types, 64 -> 64
  * channels, 3x3 / stride 1 / pad 1): the whole gradient stays in one workgroup's accumulators, every activation element
  * is loaded once, and pro_scale / pro_shift cost nothing -- callers pass them instead of materialising the activation. */
@@ -380,7 +389,8 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * gradient, key 6 = 0 the 256x256 / 16-wave weight-gradient tile, key 9 = 0 the weights-stationary 3x3
  * kernel of the 64 -> 64 layers, key 10 = 0 their output-stationary weight-gradient kernel, key 11 = smallest
  * padded raster (positions) that kernel takes, key 12 = 0 the stationary stem kernels (forward and weight gradient), key 13 =
- * smallest padded raster the stem's weight-gradient kernel takes (A/B measurements, tests). */
+ * smallest padded raster the stem's weight-gradient kernel takes, key 14 = 1 the max-pool backward by 2x2 input
+ * patches (default 0: per pixel, measured faster) (A/B measurements, tests). */
 int msfwsi_set_tuning(int key, long value);
 
 /* library identification: returns the gfx target string the code objects were built for */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "msfwsi_conv_fwd": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_conv_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_conv_wgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_stem_wgrad_bnbwd": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "msfwsi_bn_finalize": [_vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "msfwsi_bn_eval_coeffs": [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
     "msfwsi_shard_sum": [_vp, _i, _i, _vp, _vp],
@@ -146,7 +147,7 @@ def load() -> C.CDLL:
                      (4, "MSFWSI_SMALL_GRID_BLOCKS"), (5, "MSFWSI_S2_PARITY"), (6, "MSFWSI_WGRAD_BIG"),
                      (9, "MSFWSI_C3_STATIONARY"),
                      (10, "MSFWSI_WGRAD_OS"),
-                     (12, "MSFWSI_STEM_WS")):  # A/B switches (see msfwsi_set_tuning)
+                     (12, "MSFWSI_STEM_WS"), (14, "MSFWSI_POOL_BWD_PATCH")):  # A/B switches (see msfwsi_set_tuning)
         if env in os.environ:
             lib.msfwsi_set_tuning(key, int(os.environ[env]))
     _lib = lib

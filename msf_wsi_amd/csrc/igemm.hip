@@ -1133,6 +1133,7 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os(long v
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_os_min(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_patch(long v);
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
@@ -1161,6 +1162,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 13) {
         msfwsi_stem_set_os_min(value);
+        return MSFWSI_OK;
+    }
+    if (key == 14) {
+        msfwsi_pool_bwd_set_patch(value);
         return MSFWSI_OK;
     }
     if (key == 4) {

@@ -252,6 +252,11 @@ struct StemWgParams {
     const void* x;   // [N][H][W][16]
     const void* dy;  // [N][H][W][64]
     float* dw;       // [64][4][4][16]
+    // BNBWD: dy is the GATED gradient g of the stem's BatchNorm output; the conv-output gradient the weight gradient
+    // needs, dc = k1*g + k2*c + k3 (BatchNorm backward, rounded to the storage type exactly as msfwsi_bn_bwd_apply
+    // rounds it), is formed on the way from the registers to LDS: neither written nor re-read
+    const void* c0;  // [N][H][W][64] raw conv output
+    const float *k1, *k2, *k3;
     int N, H, W;
     long npos;
     int nchunks, chunks_per_wg;
@@ -262,7 +267,8 @@ struct StemWgCfg {
     static constexpr int BP = 256, NW = 4;
     static constexpr int HALO = StemCfg::HALO;
     static constexpr int DY_BYTES = BP * 128, A_BYTES = HALO * 32;
-    static constexpr int LDS_BYTES = DY_BYTES + A_BYTES;                       // 54 KiB
+    static constexpr int K_BYTES = 3 * 64 * 4;                                 // BNBWD: k1, k2, k3 of the 64 channels
+    static constexpr int LDS_BYTES = DY_BYTES + A_BYTES + K_BYTES;             // 55 KiB
     static constexpr int DY_LOADS = BP * 8 / (64 * NW);                        // 8 chunks per thread
     static constexpr int A_LOADS = (HALO * 2 + 64 * NW - 1) / (64 * NW);       // 6
 };
@@ -270,7 +276,7 @@ struct StemWgCfg {
 // natural [row][128 B] image with the 64-byte block swizzle of wgrad.hip
 __device__ __forceinline__ int dy_off(int k, int cb) { return k * 128 + ((((cb >> 6) ^ ((k >> 1) & 1)) << 6) | (cb & 63)); }
 
-template <typename T>
+template <typename T, bool BNBWD>
 __global__ __launch_bounds__(256, 2) void stem_wgrad_os_kernel(const StemWgParams prm) {
     typedef StemWgCfg Cfg;
     constexpr int BP = Cfg::BP, NT = 64 * Cfg::NW, DL = Cfg::DY_LOADS, AL = Cfg::A_LOADS, VEC = 8;
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_os_kernel(const StemWgParam
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ds = smem;
     char* As = smem + Cfg::DY_BYTES;
+    float* Ks = reinterpret_cast<float*>(smem + Cfg::DY_BYTES + Cfg::A_BYTES);  // [3][64], BNBWD only
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,6 +294,12 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_os_kernel(const StemWgParam
     const int W = prm.W, H = prm.H, Wp = W + 2, Hp = H + 2;
     const T* __restrict__ x = reinterpret_cast<const T*>(prm.x);
     const T* __restrict__ dy = reinterpret_cast<const T*>(prm.dy);
+    const T* __restrict__ c0 = reinterpret_cast<const T*>(prm.c0);
+    if constexpr (BNBWD) {
+        // the coefficients live in LDS and are re-read per chunk: held in registers for the whole kernel they cost 24
+        // VGPRs of a budget that is exhausted (256 at two workgroups per CU) and the kernel spilled
+        if (tid < 192) Ks[tid] = (tid < 64 ? prm.k1 : (tid < 128 ? prm.k2 : prm.k3))[tid & 63];
+    }
 
     const int c_beg = blockIdx.x * prm.chunks_per_wg;
     const int c_end = min(prm.nchunks, c_beg + prm.chunks_per_wg);
@@ -337,12 +350,42 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_os_kernel(const StemWgParam
         locate((long)c_beg * BP - 2 * Wp - 2 + hr, a_img[i], a_y[i], a_x[i]);
     }
     uint4 d_reg[DL], a_reg[AL];
+    uint4 c_reg[BNBWD ? DL : 1];
+    unsigned d_ok = 0;  // BNBWD: bit i = chunk i lies inside an image (pad positions stay zero: no k3 there)
     auto load_chunk = [&]() {
+        d_ok = 0;
+        if constexpr (BNBWD) {
+            // register diet (this variant carries 8 more 16-byte loads): the raster position of load i is the one of
+            // load 0 plus 32 i -- derived here instead of carried as eight (image, row, column) triples
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                int xi = d_x[0] + (NT / 8) * i, yi = d_y[0], im = d_img[0];
+                while (xi >= Wp) {
+                    xi -= Wp;
+                    ++yi;
+                }
+                while (yi >= Hp) {
+                    yi -= Hp;
+                    ++im;
+                }
+                d_reg[i] = make_uint4(0, 0, 0, 0);
+                c_reg[i] = make_uint4(0, 0, 0, 0);
+                if ((unsigned)im < (unsigned)prm.N && yi < H && xi < W) {
+                    const long o = (((long)im * H + yi) * W + xi) * 64 + c8 * VEC;
+                    d_reg[i] = *reinterpret_cast<const uint4*>(dy + o);
+                    c_reg[i] = *reinterpret_cast<const uint4*>(c0 + o);
+                    d_ok |= 1u << i;
+                }
+            }
+            advance(d_img[0], d_y[0], d_x[0]);
+        } else
 #pragma unroll
         for (int i = 0; i < DL; ++i) {
             d_reg[i] = make_uint4(0, 0, 0, 0);
-            if ((unsigned)d_img[i] < (unsigned)prm.N && d_y[i] < H && d_x[i] < W)
-                d_reg[i] = *reinterpret_cast<const uint4*>(dy + (((long)d_img[i] * H + d_y[i]) * W + d_x[i]) * 64 + c8 * VEC);
+            if ((unsigned)d_img[i] < (unsigned)prm.N && d_y[i] < H && d_x[i] < W) {
+                const long o = (((long)d_img[i] * H + d_y[i]) * W + d_x[i]) * 64 + c8 * VEC;
+                d_reg[i] = *reinterpret_cast<const uint4*>(dy + o);
+            }
             advance(d_img[i], d_y[i], d_x[i]);
         }
 #pragma unroll
@@ -392,7 +435,20 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_os_kernel(const StemWgParam
     for (int chunk = c_beg; chunk < c_end; ++chunk) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < DL; ++i) *reinterpret_cast<uint4*>(Ds + d_lds[i]) = d_reg[i];
+        for (int i = 0; i < DL; ++i) {
+            if constexpr (BNBWD) {
+                if ((d_ok >> i) & 1u) {  // dc = k1*g + k2*c + k3 for this lane's 8 channels (c8 is fixed per thread)
+                    float g[VEC], cv[VEC];
+                    unpack16<T>(d_reg[i], g);
+                    unpack16<T>(c_reg[i], cv);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        g[e] = fmaf(Ks[c8 * VEC + e], g[e], fmaf(Ks[64 + c8 * VEC + e], cv[e], Ks[128 + c8 * VEC + e]));
+                    d_reg[i] = pack16<T>(g);
+                }
+            }
+            *reinterpret_cast<uint4*>(Ds + d_lds[i]) = d_reg[i];
+        }
 #pragma unroll
         for (int i = 0; i < AL; ++i)
             if (a_lds[i] >= 0) *reinterpret_cast<uint4*>(As + a_lds[i]) = a_reg[i];
@@ -447,7 +503,12 @@ int launch_stem_wgrad(StemWgParams& prm, hipStream_t stream) {
     const int slots = 2 * ncu;  // two four-wave workgroups per CU (registers: ~200 per lane)
     prm.chunks_per_wg = (prm.nchunks + slots - 1) / slots;
     const int nblk = (prm.nchunks + prm.chunks_per_wg - 1) / prm.chunks_per_wg;
-    hipLaunchKernelGGL(stem_wgrad_os_kernel<T>, dim3((unsigned)nblk), dim3(64 * Cfg::NW), Cfg::LDS_BYTES, stream, prm);
+    if (prm.c0 != nullptr)
+        hipLaunchKernelGGL((stem_wgrad_os_kernel<T, true>), dim3((unsigned)nblk), dim3(64 * Cfg::NW), Cfg::LDS_BYTES,
+                           stream, prm);
+    else
+        hipLaunchKernelGGL((stem_wgrad_os_kernel<T, false>), dim3((unsigned)nblk), dim3(64 * Cfg::NW), Cfg::LDS_BYTES,
+                           stream, prm);
     return msfwsi_launch_status();
 }
 
@@ -485,7 +546,9 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v)
 // weight gradient of the space-to-depth stem on the output-stationary kernel; MSFWSI_EUNSUPPORTED where it does not
 // apply (msfwsi_conv_wgrad then takes the gather kernel).  From ~32 chunks per workgroup (16 384 atomics each at the end).
 extern "C" __attribute__((visibility("hidden"))) int msfwsi_stem_os_wgrad(const msfwsi_conv_desc* d, const void* x,
-                                                                         const void* dy, float* dw, void* stream) {
+                                                                         const void* dy, float* dw, const void* c0,
+                                                                         const float* k1, const float* k2,
+                                                                         const float* k3, void* stream) {
     if (!g_stem_ws || d->dtype == MSFWSI_DT_F32 || d->C != 16 || d->K != 64 || d->R != 4 || d->S != 4 || d->stride != 1 ||
         d->pad != 2 || d->P != d->H || d->Q != d->W || d->W > StemCfg::MAXW || d->W < 2 || d->H < 2)
         return MSFWSI_EUNSUPPORTED;
@@ -493,6 +556,7 @@ extern "C" __attribute__((visibility("hidden"))) int msfwsi_stem_os_wgrad(const 
     if (npos > 0x7fffffffL || npos < g_stem_os_min_pos) return MSFWSI_EUNSUPPORTED;
     StemWgParams prm{};
     prm.x = x; prm.dy = dy; prm.dw = dw;
+    prm.c0 = c0; prm.k1 = k1; prm.k2 = k2; prm.k3 = k3;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.npos = npos;
     prm.div_img = make_fastdiv((unsigned)((d->H + 2) * (d->W + 2)));
     prm.div_wp = make_fastdiv((unsigned)(d->W + 2));

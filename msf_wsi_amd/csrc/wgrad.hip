@@ -771,7 +771,23 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(lo
 extern "C" int msfwsi_conv_wgrad_stationary(const msfwsi_conv_desc* d) { return d != nullptr && wgrad_os_ok(d) ? 1 : 0; }
 
 extern "C" __attribute__((visibility("hidden"))) int msfwsi_stem_os_wgrad(const msfwsi_conv_desc* d, const void* x,
-                                                                         const void* dy, float* dw, void* stream);
+                                                                         const void* dy, float* dw, const void* c0,
+                                                                         const float* k1, const float* k2,
+                                                                         const float* k3, void* stream);
+
+// Weight gradient of the space-to-depth stem with the BatchNorm backward of its output applied on the fly:
+// dw += (k1*g + k2*c0 + k3)^T x, the bracket rounded to the storage type as msfwsi_bn_bwd_apply rounds it.
+// MSFWSI_EUNSUPPORTED where the output-stationary stem kernel does not apply (the caller then runs msfwsi_bn_bwd_apply
+// + msfwsi_conv_wgrad).
+extern "C" int msfwsi_stem_wgrad_bnbwd(const msfwsi_conv_desc* d, const void* x, const void* g, const void* c0,
+                                       const float* k1, const float* k2, const float* k3, float* dw, void* stream) {
+    if (d == nullptr || x == nullptr || g == nullptr || c0 == nullptr || k1 == nullptr || k2 == nullptr || k3 == nullptr ||
+        dw == nullptr)
+        return MSFWSI_EINVAL;
+    if (!msfwsi_dtype_ok(d->dtype)) return MSFWSI_EUNSUPPORTED;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0) return MSFWSI_EINVAL;
+    return msfwsi_stem_os_wgrad(d, x, g, dw, c0, k1, k2, k3, stream);
+}
 
 extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw,
                                  const float* pro_scale, const float* pro_shift, int target_blocks,
@@ -784,7 +800,7 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
     if ((pro_scale == nullptr) != (pro_shift == nullptr)) return MSFWSI_EINVAL;
     if ((long)d->N * d->P * d->Q > 0x7fffffffL || (long)d->N * d->H * d->W > 0x7fffffffL) return MSFWSI_EINVAL;
     if (pro_scale == nullptr) {  // the space-to-depth stem (stem.hip)
-        const int rc = msfwsi_stem_os_wgrad(d, x, dy, dw, stream);
+        const int rc = msfwsi_stem_os_wgrad(d, x, dy, dw, nullptr, nullptr, nullptr, nullptr, stream);
         if (rc != MSFWSI_EUNSUPPORTED) return rc;
     }
     if (wgrad_os_ok(d)) {

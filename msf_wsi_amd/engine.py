@@ -213,6 +213,7 @@ class Engine:
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
         self.stem_s2d = os.environ.get("MSFWSI_STEM_S2D", "1") != "0"  # ... in space-to-depth form (4x4 / stride 1)
+        self.stem_fuse_bnbwd = os.environ.get("MSFWSI_STEM_FUSE_BNBWD", "1") != "0"  # bn1 backward inside the stem's dW
         self.pair_head_wgrad = os.environ.get("MSFWSI_PAIR_HEAD_WGRAD", "1") != "0"  # one dW launch for both views
         self.pair_head_fwd = os.environ.get("MSFWSI_PAIR_HEAD_FWD", "1") != "0"  # ... and one forward GEMM per layer
         # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
@@ -883,6 +884,13 @@ class Engine:
         else:
             kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, sums, ps.N, H0, W0, 64, dact=dstem)
             k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
+            if u.s2d and self.stem_fuse_bnbwd:
+                # dc0 = k1*g + k2*c0 + k3 formed inside the weight-gradient kernel's staging: the 6.6 GB gradient is
+                # neither rewritten nor re-read (-13 GB per target pass)
+                dw2 = kn.zeros((u.desc.K, 4, 4, 16), torch.float32, g0.device)
+                if kn.stem_wgrad_bnbwd(u.desc, u.x, g0, u.c, (k[0], k[1], k[2]), dw2):
+                    kn.stem_s2d_wfold(dw2, grads.get(u.op.weight))
+                    return
             kn.bn_bwd_apply(g0, u.c, k[0], k[1], k[2], g0)
         self._unit_wgrad(u, g0, grads, dtype)
 

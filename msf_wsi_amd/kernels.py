@@ -176,7 +176,7 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
     if kind == "conv_wgrad":
         if (es == 2 and d.C == 16 and d.K == 64 and (d.R, d.S, d.stride, d.pad) == (4, 4, 1, 2) and d.P == d.H
                 and d.N * (d.H + 2) * (d.W + 2) >= 32 * 512 * 256 and os.environ.get("MSFWSI_STEM_WS", "1") != "0"):
-            return f"stem_wgrad_os_kernelI{tcode}E"
+            return f"stem_wgrad_os_kernelI{tcode}Lb0EE"
         if (es == 2 and d.C == 64 and d.K == 64 and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1
                 and d.N * (d.H + 1) * (d.W + 1) >= 32 * 256 * 256 and os.environ.get("MSFWSI_WGRAD_OS", "1") != "0"):
             return f"wgrad_os_kernelI{tcode}E"
@@ -500,6 +500,31 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=0):
         lib.msfwsi_conv_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(ps), _p(psh), int(target_blocks), _stream()),
         "conv_wgrad"), pro=pro is not None, dtype=x.dtype, same_operand=x.data_ptr() == dy.data_ptr())
     return dw
+
+
+def stem_wgrad_bnbwd(d: ConvDesc, x, g, c0, k, dw) -> bool:
+    """dw += (k1*g + k2*c0 + k3)^T x for the space-to-depth stem: BatchNorm backward applied in the weight-gradient
+    kernel's staging (no msfwsi_bn_bwd_apply pass); False if the library has no such kernel for the shape"""
+    lib = _lib.load()
+    dt = x.dtype
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(g, "g", dt, d.N * d.P * d.Q * d.K)
+    _req(c0, "c0", dt, d.N * d.P * d.Q * d.K)
+    _req(dw, "dw", torch.float32, d.K * d.R * d.S * d.C)
+    for nm, t in zip(("k1", "k2", "k3"), k):
+        _req(t, nm, torch.float32, d.K)
+    rc = [0]
+
+    def run():
+        rc[0] = lib.msfwsi_stem_wgrad_bnbwd(C.byref(d), _p(x), _p(g), _p(c0), _p(k[0]), _p(k[1]), _p(k[2]), _p(dw),
+                                            _stream())
+        if rc[0] != -2:
+            _lib.check(rc[0], "stem_wgrad_bnbwd")
+
+    tc = "DF16_" if dt == torch.float16 else _TCODE[x.element_size()]
+    _timed("conv_wgrad", d, x.element_size(), run, extra_elems=c0.numel(), dtype=dt,
+           symbol_override=f"stem_wgrad_os_kernelI{tc}Lb1EE")
+    return rc[0] == 0
 
 
 # ------------------------------------------------------------------------------------------------

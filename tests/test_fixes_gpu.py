@@ -250,3 +250,49 @@ def test_stem_space_to_depth_equals_direct_form(hip_lib, dtype, hw):
         finally:
             hip_lib.msfwsi_set_tuning(13, 32 * 512 * 256)
         assert rel(grads2.logical(enc.conv1.weight).cpu(), refw) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hw", [(64, 64), (38, 50), (224, 224)])
+def test_stem_weight_gradient_with_fused_batchnorm_backward(hip_lib, dtype, hw):
+    """msfwsi_stem_wgrad_bnbwd: dW = (k1*g + k2*c0 + k3)^T x with the bracket formed in the kernel's staging (rounded to
+    the storage type like msfwsi_bn_bwd_apply) -- against torch fp64 on the same rounded bracket, and against the
+    two-kernel route it replaces (bn_bwd_apply + conv_wgrad) on the same operands"""
+    from msf_wsi_amd import kernels as kn
+
+    H, W = hw
+    N, H2, W2 = 3, H // 2, W // 2
+    g_ = torch.Generator().manual_seed(11)
+    xs = torch.randn(N, H2, W2, 16, generator=g_).to(dtype)
+    gg = (torch.randn(N, H2, W2, 64, generator=g_) * (torch.rand(N, H2, W2, 64, generator=g_) > 0.4)).to(dtype)
+    c0 = (torch.randn(N, H2, W2, 64, generator=g_) * 1.7 + 0.3).to(dtype)
+    k = [torch.randn(64, generator=g_) * s for s in (0.8, 0.05, 0.01)]
+    dc = (k[0] * gg.float() + k[1] * c0.float() + k[2]).to(dtype)  # fmaf chain vs separate ops: <= 1 ulp of the bracket
+    d = kn.conv_desc(dtype, N, H2, W2, 16, 64, 4, 4, 1, 2)
+    assert (d.P, d.Q) == (H2 + 1, W2 + 1)  # the formula's extent; the stem uses the cropped one:
+    from msf_wsi_amd._lib import ConvDesc
+
+    d = ConvDesc(kn.dt_of(xs), N, H2, W2, 16, H2, W2, 64, 4, 4, 1, 2)
+    # reference: dW[co][r][s][c] = sum_pos dc[pos][co] * x[pos + (r-2, s-2)][c]
+    xp = torch.nn.functional.pad(xs.double().permute(0, 3, 1, 2), (2, 2, 2, 2))
+    ref = torch.zeros(64, 4, 4, 16, dtype=torch.float64)
+    dcd = dc.double()
+    for r in range(4):
+        for s_ in range(4):
+            patch = xp[:, :, r:r + H2, s_:s_ + W2].permute(0, 2, 3, 1)  # [N,H2,W2,16]
+            ref[:, r, s_, :] = torch.einsum("nhwk,nhwc->kc", dcd, patch)
+    kc = [t.cuda() for t in k]
+    try:
+        hip_lib.msfwsi_set_tuning(13, 0)  # lift the size threshold of the output-stationary stem kernel
+        dw = torch.zeros(64, 4, 4, 16, dtype=torch.float32, device="cuda")
+        assert kn.stem_wgrad_bnbwd(d, xs.cuda(), gg.cuda(), c0.cuda(), kc, dw)
+        dc_gpu = torch.empty_like(gg.cuda())
+        kn.bn_bwd_apply(gg.cuda(), c0.cuda(), kc[0], kc[1], kc[2], dc_gpu)
+        dw2 = torch.zeros_like(dw)
+        kn.conv_wgrad(d, xs.cuda(), dc_gpu, dw2)
+        torch.cuda.synchronize()
+    finally:
+        hip_lib.msfwsi_set_tuning(13, 32 * 512 * 256)
+    assert rel(dw2.cpu(), ref) < 2e-3  # the bracket's rounding (1 ulp flips between fmaf and two roundings)
+    assert rel(dw.cpu(), dw2.cpu()) < 1e-5, rel(dw.cpu(), dw2.cpu())  # same bracket bit for bit: only the atomics' order differs
+    assert rel(dw.cpu(), ref) < 2e-3

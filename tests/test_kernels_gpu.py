@@ -480,9 +480,18 @@ def test_residual_block_end(hip_lib, dt):
     assert torch.allclose(s[2], (gd * cds.double()).sum(0), rtol=1e-5, atol=1e-4)
 
 
+@pytest.fixture
+def pool_bwd_kernel(request, hip_lib):
+    """msfwsi_set_tuning(14, .): 1 = the 2x2-patch max-pool backward kernel, 0 = the per-pixel one (default)"""
+    hip_lib.msfwsi_set_tuning(14, request.param)
+    yield request.param
+    hip_lib.msfwsi_set_tuning(14, 0)
+
+
+@pytest.mark.parametrize("pool_bwd_kernel", [1, 0], indirect=True, ids=["patch", "pixel"])
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("hw", [(16, 16), (15, 13)])
-def test_stem_pool(hip_lib, dt, hw):
+@pytest.mark.parametrize("hw", [(16, 16), (15, 13), (14, 17)])
+def test_stem_pool(hip_lib, dt, hw, pool_bwd_kernel):
     from msf_wsi_amd import kernels as kn
 
     N, Cn = 2, 64
