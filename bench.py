@@ -141,6 +141,212 @@ def cpu_baseline(arch, size, budget_s, threads):
     return out
 
 
+def build_roofline(timer, args, dt, timed_from, step_bytes, step_flop, use_pmc=True):
+    """the `roofline` object of the bench line from the HIP-event timings of the last (steps - timed_from) steps:
+    the dominant kernel symbol by time, its algorithmic FLOP/s and GB/s against the gfx950 peaks, the replayed counter
+    figures of the committed rocprofv3 --pmc summary (config 2 only), whole-step fractions (where SURVEY 8(d) gives the
+    step's algorithmic bytes / FLOPs), the top kernels and the per-family sums"""
+    fam = timer.summary()
+    summ = timer.summary(by_symbol=True)
+    dom = max(summ, key=lambda k: summ[k]["seconds"])  # the kernel (template instance) with the most time
+    s = summ[dom]
+    tf = s["flops"] / s["seconds"] / 1e12
+    gbs = s["bytes"] / s["seconds"] / 1e9
+    frac_m, frac_h = tf / PEAK_TFLOPS[args.dtype], gbs / PEAK_HBM_GBS
+    bound = "mfma" if frac_m >= frac_h else "hbm"
+    pmc = pmc_entry(dom) if use_pmc else {}
+    nst = args.steps - timed_from
+    # the counters are per rocprofv3 launch; one timer entry can issue several launches (the stride-2 3x3 input
+    # gradient is four): compare per STEP, and quote `traffic` per timer entry like `achieved`
+    pmc_per_step = (pmc["hbm_bytes_per_launch"] * pmc["launches_in_pass"] / 2.0
+                    if pmc.get("hbm_bytes_per_launch") and pmc.get("launches_in_pass") else None)
+    step_s = dt / args.steps
+    step_traffic, step_src = pmc_step() if use_pmc else (None, None)
+    roof = {
+        "kernel": dom, "family": s["family"], "bound": bound,
+        "achieved": round(tf if bound == "mfma" else gbs, 2),
+        "peak": PEAK_TFLOPS[args.dtype] if bound == "mfma" else PEAK_HBM_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": round(max(frac_m, frac_h), 4),
+        # replayed from the committed rocprofv3 --pmc summary of this same command (NOT measured in this run)
+        "traffic": round(pmc_per_step * nst / s["launches"]) if pmc_per_step else None,
+        "traffic_per_step": round(pmc_per_step) if pmc_per_step else None,
+        "algorithmic_bytes_per_step": round(s["bytes"] / nst),
+        "mfma_util": round(pmc["mfma_util"], 4) if pmc.get("mfma_util") is not None else None,
+        "replayed_from": pmc.get("source"),
+        "whole_step": None if not (step_bytes and step_flop) else {
+            "algorithmic_GB": round(step_bytes / 1e9, 1), "algorithmic_TFLOP": round(step_flop / 1e12, 1),
+            "frac_hbm": round(step_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),
+            "frac_mfma": round(step_flop / step_s / 1e12 / PEAK_TFLOPS[args.dtype], 4),
+            "traffic_GB": round(step_traffic / 1e9, 1) if step_traffic else None,
+            "traffic_ratio": round(step_traffic / step_bytes, 3) if step_traffic and step_bytes else None,
+            "traffic_replayed_from": step_src},
+        "launches": s["launches"], "avg_launch_ms": round(1e3 * s["seconds"] / s["launches"], 4),
+        "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
+        "alt": {"TFLOP/s": round(tf, 2), "frac_mfma": round(frac_m, 4), "GB/s": round(gbs, 1),
+                "frac_hbm": round(frac_h, 4)},
+        "kernels": {k: {"launches": v["launches"], "ms": round(1e3 * v["seconds"], 2),
+                        "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 2),
+                        "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)}
+                    for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:8]},
+        "families": {k: {"launches": v["launches"], "ms": round(1e3 * v["seconds"], 2),
+                         "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 2),
+                         "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in fam.items()},
+        "event_timed_steps": args.steps - timed_from,
+        "timed_fraction_of_step": round(sum(v["seconds"] for v in fam.values())
+                                        / (dt * (args.steps - timed_from) / args.steps), 3),
+    }
+    return roof
+
+
+def stock_gpu_baseline(arch, size, B, steps=2):
+    """A same-box yardstick beside cpu_baseline: the ORACLE (plain functional PyTorch: F.conv2d / F.batch_norm / F.linear,
+    torch autograd, its own Adam) run on cuda:0 by stock PyTorch-ROCm eager -- MIOpen / hipBLASLt kernels under
+    torch.autocast("cuda", bfloat16) -- at the largest batch that fits eager autograd's activation memory (stated).
+    Not the target and not the product: the product path never touches it."""
+    import gc
+
+    from oracle import msfwsi_oracle as orc
+    from msf_wsi_amd.models import resnet as R
+    from msf_wsi_amd.models.backbone import MSFWSI
+
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive kernel search on a fresh box
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hub_stub()
+    torch.manual_seed(3407)
+    model = MSFWSI(R.__dict__[arch], 4)
+    sd = {k: v.detach().to(dev) for k, v in model.state_dict().items()}
+    del model
+    gc.collect()
+    (c1, c2), (t1, t2), idx = orc.synthetic_batch(B, size, 16, 0)
+    batch = ((c1.to(dev), c2.to(dev)), (t1.to(dev), t2.to(dev)), [i.to(dev) for i in idx])
+    lr = orc.init_lr(1e-3, B)
+    opt = orc.Adam(sd, [lr, lr, lr])
+    torch.cuda.reset_peak_memory_stats()
+    orc.train_step(sd, batch, opt, autocast_dtype=torch.bfloat16)  # warm-up: MIOpen kernel selection, allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.train_step(sd, batch, opt, autocast_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(B * steps / dt, 3), "unit": "tile-pairs/s", "ms_per_step": round(1e3 * dt / steps, 1),
+            "batch": B, "kind": "oracle on cuda (PyTorch-ROCm eager: MIOpen / hipBLASLt, bf16 autocast)",
+            "sample": f"{steps} timed step(s) after 1 warm-up, {arch}, {B} tile pairs of {size}x{size} (eager autograd "
+                      f"keeps every activation: the bench batch of the product does not fit)",
+            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "torch": torch.__version__}
+
+
+def finetune_cpu_baseline(arch, classes, size, threads, budget_s):
+    """the oracle's fine-tune step (oracle/hooknet_oracle.py: HookNet forward + Dice + backward, a port of the reference
+    loop tools/ssl_finetune.py:431-458; smp's arithmetic restated, parity unpinned) on the host cores, fp32, 8 tile pairs"""
+    from msf_wsi_amd.models.hooknet import HookNet
+    from oracle import hooknet_oracle as ho
+    from oracle import msfwsi_oracle as orc
+
+    torch.set_num_threads(threads)
+    torch.manual_seed(3407)
+    model = HookNet(encoder_name=arch, encoder_weights=None, classes=classes + 1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    del model
+    B = 8
+    g = torch.Generator().manual_seed(0)
+    x1, x2 = torch.randn(B, 3, size, size, generator=g), torch.randn(B, 3, size, size, generator=g)
+    m1 = torch.randint(0, classes + 1, (B, size, size), generator=g)
+    m2 = torch.randint(0, classes + 1, (B, size, size), generator=g)
+    params = [v for k, v in sd.items() if orc.is_param(k)]
+    for v in params:
+        v.requires_grad_(True)
+    opt = torch.optim.Adam(params, 1e-3)
+
+    def step():
+        loss, _ = ho.finetune_loss(sd, x1, x2, m1, m2, list(range(1, classes + 1)), 1.0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()
+    n, t0 = 0, time.time()
+    while n < 3:
+        step()
+        n += 1
+        if time.time() - t0 > budget_s:
+            break
+    return {"value": round(B * n / (time.time() - t0), 4), "unit": "tile-pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n} timed step(s) after 1 warm-up of the oracle's fine-tune step (HookNet {arch}, Dice, torch Adam) on "
+                      f"8 tile pairs of {size}x{size}, fp32", "cpu_model": _cpu_model(), "torch": torch.__version__}
+
+
+def run_finetune(args, world, rank, dev, dtype):
+    """BASELINE config 5: one fine-tune step = HookNet forward (context U-Net, hook, target U-Net), Dice loss on both
+    logit maps, confusion counts of the target prediction, backward, gradient averaging, GradScaler + Adam
+    (tools/ssl_finetune.py:422-462) on synthetic 256x256 tile pairs resident in HBM"""
+    import torch.distributed as dist
+
+    from msf_wsi_amd import kernels as kn
+    from msf_wsi_amd.finetune import FinetuneStep
+    from msf_wsi_amd.models.hooknet import HookNet
+
+    torch.manual_seed(3407)
+    with torch.device(dev):
+        model = HookNet(encoder_name=args.arch, encoder_weights=None, classes=args.classes + 1).train()
+    ts = FinetuneStep(model, lr=1e-3, batch_size=args.batch * world, dtype=dtype)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    B, S = args.batch, args.size
+    images = (torch.randn(B, 3, S, S, generator=g, device=dev), torch.randn(B, 3, S, S, generator=g, device=dev))
+    masks = (torch.randint(0, args.classes + 1, (B, S, S), generator=g, device=dev),
+             torch.randint(0, args.classes + 1, (B, S, S), generator=g, device=dev))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(images, masks)
+    timer = None if args.no_kernel_timer else kn.KernelTimer(streams=False)
+    sync()
+    timed_from = max(0, args.steps - 2)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        kn.TIMER = timer if i >= timed_from else None
+        loss, _ = ts.step(images, masks)
+    sync()
+    dt = time.perf_counter() - t0
+    kn.TIMER = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank != 0:
+        return
+    pairs = B * world * args.steps
+    out = {"metric": "fine-tune tile-pairs/sec per step (HookNet, Dice, Adam)", "value": round(pairs / dt, 3),
+           "unit": "tile-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"BASELINE config 5: HookNet ({args.arch} encoders, trainable) fine-tune step, {B} tile "
+                                  f"pairs/GPU of {S}x{S}x3 (context + target), {args.classes} classes + background, "
+                                  f"{args.dtype}, Dice + Adam + GradScaler, DP over {world} GPU(s)",
+                      "arch": args.arch, "batch_per_gpu": B, "image_size": S, "parallelism": f"dp{world}",
+                      "loss": float(loss), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                      "note": "the reference supports 256x256 inputs only (hooknet.py:29-32) and trains the encoders "
+                              "(ssl_finetune.py:289): BASELINE.json's '512x512 / frozen encoder' wording does not "
+                              "match the code (SURVEY D5)"}}
+    if timer is not None:
+        out["roofline"] = build_roofline(timer, args, dt, timed_from, 0, 0, use_pmc=False)
+    if world == 1 and not args.no_cpu_baseline:
+        del ts, model
+        torch.cuda.empty_cache()
+        threads = max(1, (os.cpu_count() or 2) // 2)
+        try:
+            threads = min(threads, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            pass
+        out["cpu_baseline"] = finetune_cpu_baseline(args.arch, args.classes, S, threads, args.cpu_budget)
+    print(json.dumps(out), flush=True)
+
+
 def dmabuf_ipc_env():
     """the host driver only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL fails at
     hipIpcGetMemHandle.  Set before the first GPU call of EVERY rank, whoever launched it."""
@@ -169,11 +375,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--arch", default="resnet50")
-    ap.add_argument("--batch", type=int, default=256, help="tile pairs per GPU")
-    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5],
+                    help="BASELINE.json config: 2 = the headline (pre-train step, default); 5 = the fine-tune step "
+                         "(HookNet + Dice + Adam, tools/ssl_finetune.py; defaults resnet18, 64 tile pairs of 256x256)")
+    ap.add_argument("--arch", default=None)
+    ap.add_argument("--batch", type=int, default=None, help="tile pairs per GPU")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--classes", type=int, default=5, help="config 5: segmentation classes (+1 background channel)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stock-batch", type=int, default=32,
+                    help="tile pairs of the stock-PyTorch GPU yardstick (0 = skip it); it runs with the CPU baseline")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--layer-report", default=None,
@@ -182,6 +394,10 @@ def main():
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, form the process group, run the collective probe and exit (launcher test)")
     args = ap.parse_args()
+    dflt = {2: ("resnet50", 256, 224), 5: ("resnet18", 64, 256)}[args.config]  # config 5: scripts/bcss.sh:27 (-b 64)
+    args.arch = args.arch or dflt[0]
+    args.batch = args.batch or dflt[1]
+    args.size = args.size or dflt[2]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process has made no GPU call yet; it starts one fresh rank per GPU
@@ -234,6 +450,12 @@ def main():
     _lib.load()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = torch.device("cuda", local)
+    if args.config == 5:
+        run_finetune(args, world, rank, dev, dtype)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     model = build(args.arch, dev)
     ts = PretrainStep(model, lr=1e-3, global_batch=args.batch * world, dtype=dtype, arch=args.arch)
     ts.engine.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")
@@ -292,59 +514,10 @@ def main():
                     f.write(f"{kind}\t{1e3 * sec / nst:.3f}\t{n / nst:.1f}\t{fl / sec / 1e12:.1f}\t{by / sec / 1e9:.0f}\t"
                             f"{shape}\t{sym if kind != 'stream' else ''}\n")
         if timer is not None:
-            fam = timer.summary()
-            summ = timer.summary(by_symbol=True)
-            dom = max(summ, key=lambda k: summ[k]["seconds"])  # the kernel (template instance) with the most time
-            s = summ[dom]
-            tf = s["flops"] / s["seconds"] / 1e12
-            gbs = s["bytes"] / s["seconds"] / 1e9
-            frac_m, frac_h = tf / PEAK_TFLOPS[args.dtype], gbs / PEAK_HBM_GBS
-            bound = "mfma" if frac_m >= frac_h else "hbm"
-            pmc = pmc_entry(dom)
-            nst = args.steps - timed_from
-            # the counters are per rocprofv3 launch; one timer entry can issue several launches (the stride-2 3x3 input
-            # gradient is four): compare per STEP, and quote `traffic` per timer entry like `achieved`
-            pmc_per_step = (pmc["hbm_bytes_per_launch"] * pmc["launches_in_pass"] / 2.0
-                            if pmc.get("hbm_bytes_per_launch") and pmc.get("launches_in_pass") else None)
             step_bytes = (ACT_BYTES_PER_PAIR_16BIT.get(args.arch, 0) * (1 if args.dtype == "bf16" else 2) * args.batch
                           + ADAM_BYTES_PER_STEP.get(args.arch, 0))
-            step_flop = FLOP_PER_PAIR.get(args.arch, 0) * args.batch
-            step_s = dt / args.steps
-            step_traffic, step_src = pmc_step()
-            out["roofline"] = {
-                "kernel": dom, "family": s["family"], "bound": bound,
-                "achieved": round(tf if bound == "mfma" else gbs, 2),
-                "peak": PEAK_TFLOPS[args.dtype] if bound == "mfma" else PEAK_HBM_GBS,
-                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                "frac": round(max(frac_m, frac_h), 4),
-                # replayed from the committed rocprofv3 --pmc summary of this same command (NOT measured in this run)
-                "traffic": round(pmc_per_step * nst / s["launches"]) if pmc_per_step else None,
-                "traffic_per_step": round(pmc_per_step) if pmc_per_step else None,
-                "algorithmic_bytes_per_step": round(s["bytes"] / nst),
-                "mfma_util": round(pmc["mfma_util"], 4) if pmc.get("mfma_util") is not None else None,
-                "replayed_from": pmc.get("source"),
-                "whole_step": {
-                    "algorithmic_GB": round(step_bytes / 1e9, 1), "algorithmic_TFLOP": round(step_flop / 1e12, 1),
-                    "frac_hbm": round(step_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),
-                    "frac_mfma": round(step_flop / step_s / 1e12 / PEAK_TFLOPS[args.dtype], 4),
-                    "traffic_GB": round(step_traffic / 1e9, 1) if step_traffic else None,
-                    "traffic_ratio": round(step_traffic / step_bytes, 3) if step_traffic and step_bytes else None,
-                    "traffic_replayed_from": step_src},
-                "launches": s["launches"], "avg_launch_ms": round(1e3 * s["seconds"] / s["launches"], 4),
-                "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
-                "alt": {"TFLOP/s": round(tf, 2), "frac_mfma": round(frac_m, 4), "GB/s": round(gbs, 1),
-                        "frac_hbm": round(frac_h, 4)},
-                "kernels": {k: {"launches": v["launches"], "ms": round(1e3 * v["seconds"], 2),
-                                "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 2),
-                                "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)}
-                            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:8]},
-                "families": {k: {"launches": v["launches"], "ms": round(1e3 * v["seconds"], 2),
-                                 "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 2),
-                                 "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in fam.items()},
-                "event_timed_steps": args.steps - timed_from,
-                "timed_fraction_of_step": round(sum(v["seconds"] for v in fam.values())
-                                                / (dt * (args.steps - timed_from) / args.steps), 3),
-            }
+            out["roofline"] = build_roofline(timer, args, dt, timed_from, step_bytes,
+                                             FLOP_PER_PAIR.get(args.arch, 0) * args.batch)
         if world == 1 and not args.no_cpu_baseline:
             del ts, model, batch
             torch.cuda.empty_cache()
@@ -354,6 +527,11 @@ def main():
             except AttributeError:
                 pass
             out["cpu_baseline"] = cpu_baseline(args.arch, args.size, args.cpu_budget, threads)
+            if args.stock_batch > 0:
+                try:
+                    out["stock_gpu_baseline"] = stock_gpu_baseline(args.arch, args.size, args.stock_batch)
+                except Exception as e:  # noqa: BLE001 -- a yardstick must never take the bench line down
+                    out["stock_gpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

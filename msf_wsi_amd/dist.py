@@ -88,16 +88,21 @@ def probe_collectives(group=None, device=None):
 class FlatGroups:
     """Flat storage of the model parameters by optimizer group."""
 
-    def __init__(self, model: nn.Module, with_bf16: bool = False, device=None, lowp_dtype=None):
+    def __init__(self, model: nn.Module, with_bf16: bool = False, device=None, lowp_dtype=None,
+                 prefixes: Sequence[str] = GROUP_PREFIXES):
+        """prefixes: name prefixes of the optimizer groups, in order (the pre-train loop's three, ssl_train.py:281-300;
+        ("",) = one group with every parameter, as the fine-tune loop's optim.Adam(model.parameters()),
+        ssl_finetune.py:289)"""
         if with_bf16 and lowp_dtype is None:
             lowp_dtype = torch.bfloat16
         with_bf16 = lowp_dtype is not None
         named = list(model.named_parameters())
-        self.names: List[List[str]] = [[n for n, _ in named if n.startswith(p)] for p in GROUP_PREFIXES]
-        self.params: List[List[nn.Parameter]] = [[p for n, p in named if n.startswith(pre)] for pre in GROUP_PREFIXES]
+        self.prefixes = tuple(prefixes)
+        self.names: List[List[str]] = [[n for n, _ in named if n.startswith(p)] for p in self.prefixes]
+        self.params: List[List[nn.Parameter]] = [[p for n, p in named if n.startswith(pre)] for pre in self.prefixes]
         covered = sum(len(g) for g in self.params)
         if covered != len(named):
-            raise ValueError("every parameter must belong to one of the context_/target_/inter_ groups")
+            raise ValueError("every parameter must belong to exactly one of the optimizer groups " + repr(self.prefixes))
         self.offsets: List[List[int]] = []
         self.sizes: List[int] = []
         self.w: List[torch.Tensor] = []
@@ -173,7 +178,7 @@ class GradReducer:
     def launch(self, group_name: str):
         if not self.active:
             return
-        gi = {"context": 0, "target": 1, "inter": 2}[group_name]
+        gi = group_name if isinstance(group_name, int) else {"context": 0, "target": 1, "inter": 2}[group_name]
         buf = self.flats.g[gi]
         work = dist.all_reduce(buf, op=self.op, group=self.group, async_op=True)
         self.pending.append((-1 if self.op == dist.ReduceOp.AVG else gi, work))

@@ -46,7 +46,115 @@ class _FlatGradStore(GradStore):
         return b.permute(0, 3, 1, 2) if param.dim() == 4 else b
 
 
-class PretrainStep:
+class FlatAdamScaler:
+    """The optimizer half of a fused step, shared by PretrainStep and finetune.FinetuneStep: flat per-group fp32
+    master weights / gradients / Adam moments (dist.FlatGroups), Adam's step count and the GradScaler state resident on
+    the device, one Adam launch per group, state dicts in torch.optim.Adam / torch.amp.GradScaler format.
+    Subclasses set: flats, lrs, eps, betas, dtype, device, engine, init_lr."""
+
+    def _init_optimizer_state(self, use_scaler: Optional[bool], init_scale: float):
+        dev, dtype = self.device, self.dtype
+        # Adam's step count lives on the device: it advances only on steps the GradScaler does not skip
+        # (scaler.step(optimizer), ssl_train.py:473), and the kernel forms the bias corrections from it
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        # GradScaler state, resident on the device (the reference enables it whenever --amp, also for bf16)
+        self.use_scaler = (dtype != torch.float32) if use_scaler is None else bool(use_scaler)
+        self.scale = torch.full((1,), init_scale if self.use_scaler else 1.0, dtype=torch.float32, device=dev)
+        self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def _register_lowp_weights(self):
+        """16-bit compute copies live in the flat buffers and are refreshed by the Adam kernel in the same pass"""
+        if self.dtype == torch.float32:
+            return
+        for plist in self.flats.params:
+            for p in plist:
+                if p.dim() >= 2 and not (p.dim() == 4 and p.shape[1] == 3):  # stem: padded copy, cached
+                    self.engine.weights.register(p, self.dtype, self.flats.w16_view(p))
+        for gi in range(len(self.flats.w)):
+            kn.cast_lowp(self.flats.w[gi], self.flats.w16[gi])
+
+
+    @property
+    def t(self) -> int:
+        """Adam's step count (host read-back: synchronises; used by checkpointing and tests only)"""
+        return int(self.step_dev.item())
+
+    def optimizer_step(self):
+        found = None
+        ls = None
+        if self.use_scaler:
+            self.found_inf.zero_()
+            for g in self.flats.g:
+                kn.nonfinite_check(g, self.found_inf)
+            found, ls = self.found_inf, self.scale
+        kn.adam_step_advance(self.step_dev, found)
+        for gi in range(len(self.flats.w)):
+            kn.adam(self.flats.w[gi], self.flats.g[gi], self.flats.m[gi], self.flats.v[gi], self.lrs[gi],
+                    self.betas[0], self.betas[1], self.eps[gi], self.step_dev, loss_scale=ls, found=found,
+                    p_lowp=self.flats.w16[gi])
+        if self.use_scaler:
+            kn.scaler_update(self.scale, self.growth_tracker, self.found_inf, self.growth_factor,
+                             self.backoff_factor, self.growth_interval)
+        # padded / cast copies (and the stem's filter-row runs) keyed on torch's version counter do not see
+        # raw-pointer updates
+        self.engine.invalidate_weights()
+
+    # ---------------------------------------------------------------------------------------
+    # checkpoint interop (reference dict layout)
+    # ---------------------------------------------------------------------------------------
+    def _torch_adam(self) -> torch.optim.Adam:
+        groups = [{"params": plist, "lr": lr, "eps": eps} for plist, lr, eps in zip(self.flats.params, self.lrs, self.eps)]
+        return torch.optim.Adam(groups, lr=self.init_lr)
+
+    def optimizer_state_dict(self) -> dict:
+        opt = self._torch_adam()
+        t = self.t
+        if t > 0:
+            for gi, plist in enumerate(self.flats.params):
+                for pi, p in enumerate(plist):
+                    m, v = self.flats.state_views(gi, pi)
+                    opt.state[p] = {"step": torch.tensor(float(t)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        return opt.state_dict()
+
+    def load_optimizer_state_dict(self, sd: dict):
+        opt = self._torch_adam()
+        opt.load_state_dict(sd)
+        steps = set()
+        for gi, plist in enumerate(self.flats.params):
+            grp = opt.param_groups[gi]
+            self.lrs[gi], self.eps[gi] = float(grp["lr"]), float(grp["eps"])
+            for pi, p in enumerate(plist):
+                st = opt.state.get(p)
+                if not st:
+                    continue
+                m, v = self.flats.state_views(gi, pi)
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ; not a checkpoint of this training loop")
+        self.step_dev.fill_(steps.pop() if steps else 0)
+
+    def scaler_state_dict(self) -> dict:
+        if not self.use_scaler:
+            return {}
+        return {"scale": float(self.scale.item()), "growth_factor": self.growth_factor,
+                "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
+                "_growth_tracker": int(self.growth_tracker.item())}
+
+    def load_scaler_state_dict(self, sd: dict):
+        if not sd:
+            return
+        self.scale.fill_(float(sd["scale"]))
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+        self.growth_tracker.fill_(int(sd["_growth_tracker"]))
+
+
+class PretrainStep(FlatAdamScaler):
     def __init__(self, model: nn.Module, lr: float = 1e-3, global_batch: int = 32, ms_lr: Sequence[float] = (1, 1, 1),
                  fuser_weights: Sequence[float] = FUSER_WEIGHTS, dtype: torch.dtype = torch.bfloat16,
                  use_scaler: Optional[bool] = None, init_scale: float = 65536.0, process_group=None,
@@ -73,19 +181,10 @@ class PretrainStep:
         self.lrs = [self.init_lr * float(m) for m in ms_lr]
         self.betas = (0.9, 0.999)
         self.eps = [1e-8, 1e-8, 1e-8]
-        # Adam's step count lives on the device: it advances only on steps the GradScaler does not skip
-        # (scaler.step(optimizer), ssl_train.py:473), and the kernel forms the bias corrections from it
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.flats = FlatGroups(model, lowp_dtype=None if dtype == torch.float32 else dtype)
         self.engine = Engine(process_group=process_group, sync_bn=sync_bn)
         model._engine = self.engine
-        if dtype != torch.float32:
-            for plist in self.flats.params:
-                for p in plist:
-                    if p.dim() >= 2 and not (p.dim() == 4 and p.shape[1] == 3):  # stem: padded copy, cached
-                        self.engine.weights.register(p, dtype, self.flats.w16_view(p))
-            for gi in range(3):
-                kn.cast_lowp(self.flats.w[gi], self.flats.w16[gi])
+        self._register_lowp_weights()
         self.grads = _FlatGradStore(self.flats)
         # gradients travel on their OWN communicator: the multi-GB all-reduce of the head group must not sit in
         # front of the latency-bound SyncBN exchanges of the encoder backward that is still running
@@ -101,13 +200,7 @@ class PretrainStep:
 
             grad_group = dist.new_group(backend=dist.get_backend())
         self.reducer = GradReducer(self.flats, grad_group)
-        # GradScaler state, resident on the device (the reference enables it whenever --amp, also for bf16)
-        self.use_scaler = (dtype != torch.float32) if use_scaler is None else bool(use_scaler)
-        self.scale = torch.full((1,), init_scale if self.use_scaler else 1.0, dtype=torch.float32, device=dev)
-        self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.found_inf = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
-        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._init_optimizer_state(use_scaler, init_scale)
         # epoch meter of ssl_train.py:421,467-468,483-486: [sum loss*bs, sum bs], kept on the device
         self.epoch_meter = torch.zeros(2, dtype=torch.float64, device=dev)
 
@@ -187,31 +280,6 @@ class PretrainStep:
         self.epoch_meter[1] += bs
         return loss
 
-    @property
-    def t(self) -> int:
-        """Adam's step count (host read-back: synchronises; used by checkpointing and tests only)"""
-        return int(self.step_dev.item())
-
-    def optimizer_step(self):
-        found = None
-        ls = None
-        if self.use_scaler:
-            self.found_inf.zero_()
-            for g in self.flats.g:
-                kn.nonfinite_check(g, self.found_inf)
-            found, ls = self.found_inf, self.scale
-        kn.adam_step_advance(self.step_dev, found)
-        for gi in range(3):
-            kn.adam(self.flats.w[gi], self.flats.g[gi], self.flats.m[gi], self.flats.v[gi], self.lrs[gi],
-                    self.betas[0], self.betas[1], self.eps[gi], self.step_dev, loss_scale=ls, found=found,
-                    p_lowp=self.flats.w16[gi])
-        if self.use_scaler:
-            kn.scaler_update(self.scale, self.growth_tracker, self.found_inf, self.growth_factor,
-                             self.backoff_factor, self.growth_interval)
-        # padded / cast copies (and the stem's filter-row runs) keyed on torch's version counter do not see
-        # raw-pointer updates
-        self.engine.invalidate_weights()
-
     def epoch_loss(self) -> float:
         """sample-weighted mean loss over ranks (ssl_train.py:483-486); syncs once per epoch"""
         m = self.epoch_meter.clone()
@@ -221,57 +289,6 @@ class PretrainStep:
             dist.all_reduce(m, group=self.group)
         self.epoch_meter.zero_()
         return float(m[0] / m[1])
-
-    # ---------------------------------------------------------------------------------------
-    # checkpoint interop (reference dict layout)
-    # ---------------------------------------------------------------------------------------
-    def _torch_adam(self) -> torch.optim.Adam:
-        groups = [{"params": plist, "lr": lr, "eps": eps} for plist, lr, eps in zip(self.flats.params, self.lrs, self.eps)]
-        return torch.optim.Adam(groups, lr=self.init_lr)
-
-    def optimizer_state_dict(self) -> dict:
-        opt = self._torch_adam()
-        t = self.t
-        if t > 0:
-            for gi, plist in enumerate(self.flats.params):
-                for pi, p in enumerate(plist):
-                    m, v = self.flats.state_views(gi, pi)
-                    opt.state[p] = {"step": torch.tensor(float(t)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
-        return opt.state_dict()
-
-    def load_optimizer_state_dict(self, sd: dict):
-        opt = self._torch_adam()
-        opt.load_state_dict(sd)
-        steps = set()
-        for gi, plist in enumerate(self.flats.params):
-            grp = opt.param_groups[gi]
-            self.lrs[gi], self.eps[gi] = float(grp["lr"]), float(grp["eps"])
-            for pi, p in enumerate(plist):
-                st = opt.state.get(p)
-                if not st:
-                    continue
-                m, v = self.flats.state_views(gi, pi)
-                m.copy_(st["exp_avg"])
-                v.copy_(st["exp_avg_sq"])
-                steps.add(int(float(st["step"])))
-        if len(steps) > 1:
-            raise ValueError("per-parameter Adam step counts differ; not a checkpoint of this training loop")
-        self.step_dev.fill_(steps.pop() if steps else 0)
-
-    def scaler_state_dict(self) -> dict:
-        if not self.use_scaler:
-            return {}
-        return {"scale": float(self.scale.item()), "growth_factor": self.growth_factor,
-                "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
-                "_growth_tracker": int(self.growth_tracker.item())}
-
-    def load_scaler_state_dict(self, sd: dict):
-        if not sd:
-            return
-        self.scale.fill_(float(sd["scale"]))
-        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
-        self.growth_interval = int(sd["growth_interval"])
-        self.growth_tracker.fill_(int(sd["_growth_tracker"]))
 
     def checkpoint(self, epoch: int) -> dict:
         """the dict the reference passes to save_checkpoint (ssl_train.py:375-386); DDP's "module." prefix kept"""
@@ -290,7 +307,7 @@ class PretrainStep:
         self.eps = [0.1, 0.1, 0.1]
         self.load_scaler_state_dict(ckpt.get("scaler", {}))
         if self.dtype != torch.float32:
-            for gi in range(3):
+            for gi in range(len(self.flats.w)):
                 kn.cast_lowp(self.flats.w[gi], self.flats.w16[gi])
         self.engine.invalidate_weights()
         return int(ckpt["epoch"])

@@ -129,7 +129,7 @@ def msfwsi_forward(sd: StateDict, x1, x2, jigsaw_idx, scale: int = 4, mask_ratio
     tf2 = encoder_forward(sd, prefix + "target_encoder.", x2[1])
     tf1s = [t.reshape(B, K, -1) for t in tf1]
     tf2s = [t.reshape(B, K, -1) for t in tf2]
-    bidx = torch.arange(B).repeat(K, 1).t()
+    bidx = torch.arange(B, device=jigsaw_idx[0].device).repeat(K, 1).t()
     assert bidx.shape == jigsaw_idx[0].shape == jigsaw_idx[1].shape
     t1 = [t[bidx, jigsaw_idx[0], :].flatten(0, 1) for t in tf1s]
     t2 = [t[bidx, jigsaw_idx[1], :].flatten(0, 1) for t in tf2s]
@@ -253,7 +253,7 @@ def train_step(sd: StateDict, batch, opt: Adam, scale: int = 4, mask_ratio: floa
         outputs = msfwsi_forward(sd, (c1, t1), (c2, t2), idx, scale, mask_ratio)
         loss, terms = (loss_fn or loss_terms)(outputs, weights)
     else:
-        with torch.autocast("cpu", dtype=autocast_dtype):
+        with torch.autocast(c1.device.type, dtype=autocast_dtype):  # "cpu" here; "cuda" for bench.py's stock-GPU yardstick
             outputs = msfwsi_forward(sd, (c1, t1), (c2, t2), idx, scale, mask_ratio)
             loss, terms = (loss_fn or loss_terms)(outputs, weights)
     (loss * loss_scale).backward()

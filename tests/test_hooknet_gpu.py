@@ -143,3 +143,106 @@ def test_hooknet_bf16_autocast_and_eval(hip_lib, arch):
     with torch.no_grad():
         _, t = model(x1, x2)
     assert torch.isfinite(t).all() and tuple(t.shape) == (2, CLASSES + 1, 256, 256)
+
+
+@pytest.mark.parametrize("lam", [1.0, 0.75])
+def test_fused_finetune_step_matches_oracle(hip_lib, lam):
+    """msf_wsi_amd.finetune.FinetuneStep (Dice kernels on the NHWC logits, flat Adam, device GradScaler) in fp32 against
+    the oracle's finetune_loss + Adam on the same seeded weights and inputs: loss 1e-3, every updated weight tensor by
+    the rule of the pre-train tests (Adam's first step is sign-like: helpers.updated_weights_gate).  lam = 1 is the
+    reference's default (ssl_finetune.py:690): the context logits get no direct loss, only the hook's gradient.
+    parity unpinned: smp absent (see oracle/hooknet_oracle.py)"""
+    from helpers import updated_weights_gate
+    from msf_wsi_amd.finetune import FinetuneStep
+    from oracle import msfwsi_oracle as orc
+
+    B = 4
+    model = _build()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    inputs = _inputs(B=B)
+    x1, x2, m1, m2 = inputs
+    lr = 1e-3 * (B ** 0.5) / (64 ** 0.5)
+    res = {}
+    for tag, dt in (("64", torch.float64), ("32", torch.float32)):
+        loss, c, t, grads, sd = _oracle(sd0, inputs, dt, lam=lam)
+        names = [k for k in sd if orc.is_param(k)]
+        for k in names:
+            sd[k].requires_grad_(False)
+        opt = _OneGroupAdam(sd, names, lr)
+        opt.step(sd, grads)
+        res[tag] = (loss, grads, sd)
+    loss64, g64, sd64 = res["64"]
+    _, g32, sd32 = res["32"]
+    model = model.cuda().train()
+    ts = FinetuneStep(model, lr=1e-3, batch_size=B, lam=lam, dtype=torch.float32, use_scaler=False)
+    loss, (tp, fp, fn, tn) = ts.step((x1.cuda(), x2.cuda()), (m1.cuda(), m2.cuda()))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - loss64) <= 1e-3 * max(abs(loss64), 1e-2), (float(loss), loss64)
+    named = list(model.named_parameters())
+    names = [n for n, _ in named]
+    box_step = np.array([rel(sd32[n], sd64[n]) for n in names])
+    box_grad = np.array([rel(g32[n], g64[n]) if g64[n] is not None and float(g64[n].norm()) > 0 else 0.0 for n in names])
+    g64z = {n: (g64[n] if g64[n] is not None else torch.zeros_like(sd0[n], dtype=torch.float64)) for n in names}
+    updated_weights_gate(named, sd0, sd64, g64z, lr, [box_step], [box_grad], f"fused fine-tune step, lam {lam}")
+    # the per-step confusion counts of the target prediction (ssl_finetune.py:440-447) against the oracle's logits
+    from oracle import hooknet_oracle as ho
+    from oracle import metrics_oracle as mo
+
+    _, (c0_, t0_) = ho.finetune_loss({k: v.double() if v.is_floating_point() else v for k, v in sd0.items()},
+                                      x1.double(), x2.double(), m1, m2, list(range(1, CLASSES + 1)), lam)
+    want = mo.get_stats_multiclass(t0_.argmax(1).numpy() - 1, m2.numpy() - 1, CLASSES, ignore_index=-1)
+    got = [v.cpu().numpy() for v in (tp, fp, fn, tn)]
+    # an argmax can differ where two logits tie to rounding: allow a handful of pixels out of B * 65536
+    assert sum(int(np.abs(a - b).sum()) for a, b in zip(got, want)) <= 64
+    assert ts.t == 1 and int(model.state_dict()["context_branch.encoder.bn1.num_batches_tracked"]) == 1
+
+
+class _OneGroupAdam:
+    """torch.optim.Adam(model.parameters(), lr) restated on a state dict (one group: ssl_finetune.py:289)"""
+
+    def __init__(self, sd, names, lr, eps=1e-8):
+        self.names, self.lr, self.eps, self.t = names, lr, eps, 0
+        self.m = {k: torch.zeros_like(sd[k]) for k in names}
+        self.v = {k: torch.zeros_like(sd[k]) for k in names}
+
+    @torch.no_grad()
+    def step(self, sd, grads):
+        import math
+
+        self.t += 1
+        b1, b2 = 0.9, 0.999
+        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+        for k in self.names:
+            g = grads.get(k)
+            if g is None:
+                continue
+            self.m[k].lerp_(g, 1 - b1)
+            self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            sd[k].addcdiv_(self.m[k], (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps), value=-(self.lr / bc1))
+
+
+def test_fused_finetune_step_bf16_and_validate(hip_lib):
+    """bf16 storage with the GradScaler protocol: finite, the loss tracks the fp32 oracle's to bf16 accuracy, the 16-bit
+    weight copies follow the master weights; then the evaluation loop's arithmetic (chunks, eval-mode BatchNorm)"""
+    from msf_wsi_amd.finetune import FinetuneStep
+
+    B = 4
+    model = _build()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x1, x2, m1, m2 = _inputs(B=B)
+    loss32, _, _, _, _ = _oracle(sd0, (x1, x2, m1, m2), torch.float32, lam=1.0)
+    model = model.cuda().train()
+    ts = FinetuneStep(model, lr=1e-3, batch_size=B, dtype=torch.bfloat16)
+    losses = [float(ts.step((x1.cuda(), x2.cuda()), (m1.cuda(), m2.cuda()))[0]) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and abs(losses[0] - loss32) <= 2e-2 * abs(loss32), (losses, loss32)
+    assert losses[2] < losses[0]  # the same batch three times: the loss falls
+    assert ts.found_inf.item() == 0 and ts.scale.item() == 65536.0 and ts.t == 3
+    assert torch.equal(ts.flats.w16[0].float(), ts.flats.w[0].bfloat16().float())
+    tp, fp, fn, tn = ts.validate(x1.cuda().repeat(3, 1, 1, 1), x2.cuda().repeat(3, 1, 1, 1), m2.cuda().repeat(3, 1, 1),
+                                 chunk=5)
+    torch.cuda.synchronize()
+    assert tuple(tp.shape) == (12, CLASSES) and not model.training
+    assert torch.equal(tp[:4], tp[4:8]) and torch.equal(fn[:4], fn[8:12])  # eval mode: chunking does not change a tile
+    valid = (m2 > 0).sum(dim=(1, 2))
+    assert torch.equal((tp + fn).sum(1).cpu()[:4], valid)  # every labelled pixel is a tp or a fn of its class
