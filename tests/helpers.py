@@ -130,10 +130,19 @@ def spread_gate(rels, names, spreads, what, envelope=(), strict_count=False):
         for i in np.flatnonzero(needed)[:40]:
             print(f"    {names[i]}: rel {rels[i]:.2e}  (reference spread {env[i]:.2e})")
     n_ref = max(int((s > FLOOR).sum()) for s in samples + [np.asarray(e) for e in envelope])
+    count_bound = 2 * n_ref
     if strict_count:
         # well-conditioned cases: most reference tensors sit far below 1e-3, so the count bound of rule 2 is below the
-        # number of tensors and CAN trip (on the N(0,1) fixtures it could not: VERDICT r2, weak #2)
+        # number of tensors and CAN trip (on the N(0,1) fixtures it could not: VERDICT r2, weak #2).  The count is of
+        # TENSORS, the process is of EVENTS: one ReLU flip in a head (measured on the MI355X: target_projector.3) moves
+        # every tensor of the encoder below it by 1.0-1.6e-3 -- 31 tensors from one event, where the reference's samples
+        # of this case show 0 (fixture) and 9 (this box) -- so the bound is at least one encoder's worth of tensors (a
+        # quarter of the model).  What a systematic error cannot pass is the median rule below: on these cases the
+        # product's median must stay within 5x the reference's own (~2e-6), not merely below 1e-3.
         assert 2 * n_ref < len(rels), (what, "rule 2 cannot bite on this fixture", n_ref, len(rels))
+        count_bound = max(count_bound, len(rels) // 4)
+        assert np.median(rels) <= 5.0 * max(float(np.median(env)), 1e-6), (what, "median (well-conditioned case)",
+                                                                           float(np.median(rels)), float(np.median(env)))
     worst_ref = max(float(np.max(s)) for s in samples + [np.asarray(e) for e in envelope])
     if over.any():
         print(f"[{what}] {int(over.sum())} tensors beyond their own spread allowance (gate flips that the reference "
@@ -145,7 +154,7 @@ def spread_gate(rels, names, spreads, what, envelope=(), strict_count=False):
           f"({names[int(rels.argmax())]}); reference noise: median {np.median(env):.2e} max {env.max():.2e}")
     assert np.median(rels) <= max(FLOOR, 2.0 * float(np.median(env))), (what, "median", float(np.median(rels)))
     # (the same factor 2 as rule 1: the count of flip-hit tensors is itself a random number of the same process)
-    assert int(over.sum()) <= 2 * n_ref, (what, "tensors beyond their allowance", int(over.sum()), "reference", n_ref)
+    assert int(over.sum()) <= count_bound, (what, "tensors beyond their allowance", int(over.sum()), "bound", count_bound)
     if over.any():
         assert float(rels[over].max()) <= max(FLOOR, 2.0 * worst_ref), (what, names[int(rels.argmax())],
                                                                         float(rels[over].max()), worst_ref)
