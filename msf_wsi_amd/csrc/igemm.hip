@@ -910,20 +910,31 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     int tap_r = 0, tap_s = 0, tap_c = 0, tap_t = 0, k0 = 0;
     int soff_tap = 0;
     int voff_eff[A_IT];
-    auto fetch = [&](int buf) {
+    // (always_inline: with the second source's early return hipcc left this lambda OUT of line in every TWO instance --
+    //  a call per slab and its by-reference captures k0 / tap_c / soff_tap in scratch, 12 bytes per lane)
+    auto fetch = [&](int buf) __attribute__((always_inline)) {
         if constexpr (TWO) {
-            if (k0 >= prm.C) {  // second source: channel slab k0 - C of src2, weight rows k0 .. k0+BK
-                char* Ab2 = As + buf * Cfg::A_BYTES + wave * 1024;
-                char* Bb2 = Bs + buf * Cfg::B_BYTES + wave * 1024;
+            // two-source launches are 1x1 / stride 1: ONE tap, no tap state.  Source 1 holds k in [0, C), source 2 (its own
+            // row pitch C2) k in [C, C + C2); the weight rows follow k.  (Written with the tap counters of the general path
+            // and an early return, hipcc kept those counters in a dynamically indexed scratch slot -- 12 bytes per lane and a
+            // scratch read-modify-write behind `s_waitcnt vmcnt(0)`, i.e. a drained DMA pipeline, once per tile.)
+            char* Ab2 = As + buf * Cfg::A_BYTES + wave * 1024;
+            char* Bb2 = Bs + buf * Cfg::B_BYTES + wave * 1024;
+            if (k0 >= prm.C) {
                 const int soff2 = (k0 - prm.C) * ES;
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) dma16_buf(srd_a2, Ab2 + i * NW * 1024, a_voff2[i], soff2);
-                const int soffb2 = DGRAD ? (int)((long)k0 * prm.Nout * ES) : k0 * ES;  // [k][n] rows / [n][k] columns
+            } else {
+                const int soff1 = k0 * ES;
 #pragma unroll
-                for (int i = 0; i < NB; ++i) dma16_buf(srd_b, Bb2 + i * NW * 1024, b_voff[i], soffb2);
-                k0 += BK;
-                return;
+                for (int i = 0; i < A_IT; ++i)
+                    dma16_buf(srd_a, Ab2 + i * NW * 1024, (a_mask[i] & 1u) ? a_voff[i] : OOB, soff1);
             }
+            const int soffb2 = DGRAD ? (int)((long)k0 * prm.Nout * ES) : k0 * ES;  // [k][n] rows / [n][k] columns
+#pragma unroll
+            for (int i = 0; i < NB; ++i) dma16_buf(srd_b, Bb2 + i * NW * 1024, b_voff[i], soffb2);
+            k0 += BK;
+            return;
         }
         if (RUN || tap_c == 0) {  // new filter tap: which rows have a source pixel, and the tap's scalar shift
             tap_t = RUN ? tap_r * (prm.C / BK) + tap_c / BK : tap_r * prm.S + tap_s;
@@ -945,11 +956,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         for (int i = 0; i < NB; ++i) dma16_buf(srd_b, Bb + i * NW * 1024, b_voff[i], soff_b);
         k0 += BK;
         tap_c += BK;
-        if (tap_c >= prm.C) {
-            tap_c = 0;
-            if (++tap_s == prm.S) {
-                tap_s = 0;
-                ++tap_r;
+        // (two-source launches are 1x1: one tap, tap_c simply runs on to C.  With the wrap below compiled in, hipcc turned
+        //  the two counters of those instances into a dynamically indexed scratch slot -- 12 bytes per lane, a
+        //  scratch_load / add / scratch_store behind an `s_waitcnt vmcnt(0)` that drained the LDS-DMA pipeline once per tile)
+        if constexpr (!TWO) {
+            if (tap_c >= prm.C) {
+                tap_c = 0;
+                if (++tap_s == prm.S) {
+                    tap_s = 0;
+                    ++tap_r;
+                }
             }
         }
     };
@@ -962,7 +978,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const char* Ab = As + buf * Cfg::A_BYTES;
         const char* Bb = Bs + buf * Cfg::B_BYTES;
 #pragma unroll

@@ -408,6 +408,57 @@ def run_curve_case(name="r18_b16_s64_curve", arch="resnet18", B=16, size=64, ste
                                  "tools/ssl_train.py:281-310,441-474 restated by make_golden.run_curve_case"}, f)
 
 
+def add_curve_samples(name="r18_b16_s64_curve"):
+    """More samples of the reference's own trajectories for the loss-curve envelope: the same runs as run_curve_case with
+    other intra-op thread counts.  oneDNN blocks its sums by thread count, so every count is a different rounding of the
+    same arithmetic -- and the trajectory is chaotic (Adam's early steps are sign-like): measured here and on the GPU
+    box's host, the reference-under-autocast(bf16) ends 30 steps anywhere between -0.74 and -0.81 (mean of the last ten
+    losses), its fp32 run between -0.77 and -0.81.  One sample per precision (round 3's first fixture) made an envelope
+    that the reference's own second sample left."""
+    import contextlib
+    import torch.nn as nn
+    from oracle import msfwsi_oracle as orc
+
+    path = os.path.join(HERE, name + ".npz")
+    vec = dict(np.load(path))
+    with open(os.path.join(HERE, name + ".json")) as f:
+        man = json.load(f)
+    arch, B, size, steps = man["arch"], man["B"], man["size"], man["steps"]
+    cos = nn.CosineSimilarity(dim=1)
+    lr = LR * (B ** 0.5) / (32 ** 0.5)
+    for tag, ac, threads in (("bf16_t4", torch.bfloat16, 4), ("bf16_t6", torch.bfloat16, 6), ("fp32_t4", None, 4),
+                             ("bf16_t3", torch.bfloat16, 3), ("fp32_t6", None, 6)):
+        if "loss_" + tag in vec:
+            continue
+        torch.set_num_threads(threads)
+        t0 = time.time()
+        model = build_reference(arch, RESIDUAL_GAIN).train()
+        named = list(model.named_parameters())
+        groups = [[p for n, p in named if n.startswith(pre)] for pre in ("context_", "target_", "inter_")]
+        opt = torch.optim.Adam([{"params": g, "lr": lr} for g in groups], lr=lr)
+        losses = []
+        for t in range(steps):
+            (c1, c2), (t1, t2), idx = orc.diverse_batch(B, size, 16, man["curve_seed0"] + t)
+            ctx = torch.autocast("cpu", dtype=ac) if ac is not None else contextlib.nullcontext()
+            with ctx:
+                out = model((c1, t1), (c2, t2), idx)
+                loss = 0
+                for grp in out:
+                    for i, (p1, p2, z1, z2) in enumerate(zip(*grp)):
+                        if ac is not None:
+                            p1, p2, z1, z2 = p1.float(), p2.float(), z1.float(), z2.float()
+                        loss = loss + (-(cos(p1, z2).mean() + cos(p2, z1).mean()) * 0.5) * WEIGHTS[i]
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        vec["loss_" + tag] = np.array(losses)
+        print(f"[{name}] {tag} ({threads} threads): last-10 mean {np.mean(losses[-10:]):.4f}, max |d| vs fp64 "
+              f"{np.abs(vec['loss_' + tag] - vec['loss_fp64']).max():.4f}   ({time.time() - t0:.0f}s)", flush=True)
+        np.savez_compressed(path, **vec)
+    torch.set_num_threads(8)
+
+
 def main():
     todo = sys.argv[1:] or ["r18_b2_s64", "r18_b8_s64", "r18_b8_s224", "encoder"]
     torch.set_num_threads(8)
@@ -418,6 +469,8 @@ def main():
             run_encoder_case("r50enc_b16_s64_div", "resnet50", 16, 64, kind="diverse", lowp=("bf16", "fp16"))
         elif c == "curve":
             run_curve_case()
+        elif c == "curve_samples":
+            add_curve_samples()
         else:
             run_case(c)
 

@@ -161,31 +161,43 @@ def test_wrong_epilogue_scale_is_caught(hip_lib, monkeypatch, dtype, factor):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_loss_curve_tracks_reference(hip_lib, dtype):
     """SURVEY.md 8(d) "bf16 runs: loss-curve parity": 30 steps of the fused step (HIP loss + backward + Adam +
-    GradScaler) in 16-bit storage on a fresh well-conditioned batch per step, against the REAL reference's fp32 curve
-    (fixture r18_b16_s64_curve).  Envelope at step t = the largest distance the reference's own autocast curve of that
-    dtype has shown from its fp32 curve up to t (the trajectories separate as training proceeds): the product must stay
-    within max(floor, 2 x envelope), floor = 2e-3 (the 1e-3 * max(|term|, 1e-2) term tolerance summed with the loss
-    weights 3 x 2.2 would be 6.6e-5 .. ; 2e-3 is the fp16 reference's own distance after a few steps)"""
+    GradScaler) in 16-bit storage on a fresh well-conditioned batch per step, against the REAL reference's curves
+    (fixture r18_b16_s64_curve: fp64, fp32 and autocast runs of the reference, several samples each).
+
+    The trajectory is chaotic -- Adam's early steps are sign-like, so two fp32 implementations that agree to 1e-6 on a
+    step are 1e-3 apart after 5 steps and 5e-2 after 25; the reference-under-autocast(bf16) ends anywhere between
+    -0.74 and -0.81 (mean of the last ten losses; samples of the fixture and the oracle re-run on the GPU box's host,
+    tools/curve_diag.py) -- so the yardstick is the SPREAD OF THE REFERENCE'S OWN SAMPLES around its fp64 curve:
+      per step   |product - fp64| <= max(2e-3, 2 x the largest |sample - fp64| any reference sample has shown up to
+                 that step)   (samples: fp32 runs, the oracle's fp32 run, the autocast runs of this dtype);
+      as a whole the mean of the last ten losses within 2 x the largest deviation of a reference sample's mean from
+                 the fp64 mean."""
     from msf_wsi_amd.train import PretrainStep
     from oracle import msfwsi_oracle as orc
 
     vec, man = load_golden("r18_b16_s64_curve")
     tag = LOWP_TAG[dtype]
     B, size = man["B"], man["size"]
-    ref16 = vec[f"loss_{tag}"]
-    steps = len(ref16)  # bf16: 30; fp16: the first few (fp16 has no fast CPU path for the reference run)
-    ref32 = vec["loss_fp32"][:steps]
-    # envelope: the largest distance from the reference's fp32 curve that (a) the reference's own autocast curve, (b) its
-    # fp64 curve and (c) the ORACLE's fp32 curve have shown up to step t.  (c) is there because the trajectory is
-    # chaotic (Adam's first steps are sign-like): two fp32 implementations that agree to 1e-6 on one step are 1e-3
-    # apart after 5 steps and 1e-1 after 20 (fixture key oracle_fp32_dev)
-    env = np.maximum.accumulate(np.abs(ref16 - ref32))
-    env = np.maximum(env, np.maximum.accumulate(np.abs(vec["loss_fp64"][:steps] - ref32)))
-    env = np.maximum(env, np.maximum.accumulate(vec["oracle_fp32_dev"][:steps]))
-    # x3, not x2: the envelope is the maximum over THREE sample trajectories of a chaotic process (measured: the product's
-    # bf16 curve left 2 x envelope by 15 % at one step of 30 while ending inside it; the reference's own bf16 and fp64
-    # curves differ from each other by more than that)
-    allow = np.maximum(2e-3, 3.0 * env)
+    steps = len(vec[f"loss_{tag}"])  # bf16: 30; fp16: the first few (fp16 has no fast CPU path for the reference run)
+    ref64 = vec["loss_fp64"][:steps]
+    samples = {k[5:]: v[:steps] for k, v in vec.items() if k.startswith("loss_") and k != "loss_fp64"
+               and (k.startswith("loss_fp32") or k.startswith(f"loss_{tag}")) and len(v) >= steps}
+    samples["oracle_fp32"] = vec["loss_fp32"][:steps] + vec["oracle_fp32_dev"][:steps]  # |dev| stored: one side suffices
+    assert len(samples) >= (5 if steps >= 30 else 3), sorted(samples)
+    if dtype == torch.bfloat16:
+        # ... and the ORACLE under torch.autocast("cpu", bfloat16) on THIS machine: bf16 kernels differ by CPU (the build
+        # container's samples end at -0.81 .. -0.84, an EPYC 9575F with native AVX512-BF16 at -0.74), and the oracle's
+        # autocast mode is pinned to the reference's (make_golden.py: same forward bit for bit in one process)
+        osd = {k: v.detach().clone() for k, v in build_case(man).state_dict().items()}
+        oopt = orc.Adam(osd, [orc.init_lr(LR, B)] * 3)
+        here = []
+        for t in range(steps):
+            l_, _, _, _ = orc.train_step(osd, orc.diverse_batch(B, size, 16, man["curve_seed0"] + t), oopt,
+                                         autocast_dtype=torch.bfloat16)
+            here.append(float(l_))
+        samples["oracle_bf16_this_machine"] = np.array(here)
+    env = np.max(np.stack([np.maximum.accumulate(np.abs(v - ref64)) for v in samples.values()]), axis=0)
+    allow = np.maximum(2e-3, 2.0 * env)
     model = build_case(man).cuda().train()
     ts = PretrainStep(model, lr=LR, global_batch=B, dtype=dtype,
                       init_scale=65536.0 if dtype == torch.bfloat16 else man["fp16_loss_scale"])
@@ -194,21 +206,20 @@ def test_loss_curve_tracks_reference(hip_lib, dtype):
         (c1, c2), (t1, t2), idx = orc.diverse_batch(B, size, 16, man["curve_seed0"] + t)
         losses.append(ts.step(((c1.cuda(), c2.cuda()), (t1.cuda(), t2.cuda()), idx)))
     losses = torch.stack(losses).cpu().numpy().ravel()
-    d = np.abs(losses - ref32)
+    d = np.abs(losses - ref64)
     print(f"[{tag} curve] product " + " ".join(f"{v:.4f}" for v in losses))
-    print(f"[{tag} curve] ref32   " + " ".join(f"{v:.4f}" for v in ref32))
+    print(f"[{tag} curve] ref fp64" + " ".join(f"{v:.4f}" for v in ref64))
     print(f"[{tag} curve] |d|     " + " ".join(f"{v:.4f}" for v in d))
-    print(f"[{tag} curve] allow   " + " ".join(f"{v:.4f}" for v in allow))
+    print(f"[{tag} curve] allow   " + " ".join(f"{v:.4f}" for v in allow) + f"   ({len(samples)} reference samples)")
     assert np.isfinite(losses).all()
-    if steps >= 30:
-        assert (ref32[-1] - ref32[0]) < -0.5, "the fixture's curve must move for this test to mean anything"
     assert (d <= allow).all(), (int(np.argmax(d / allow)), float((d / allow).max()))
-    if steps >= 30:  # the curve as a whole: mean loss of the last 10 steps within 2 x the reference's own deviation there
+    if steps >= 30:
+        assert (ref64[-1] - ref64[0]) < -0.5, "the fixture's curve must move for this test to mean anything"
         tail = lambda c: float(np.mean(c[-10:]))
-        dev_ref = max(abs(tail(ref16) - tail(ref32)), abs(tail(vec["loss_fp64"]) - tail(ref32)), 0.02)
-        print(f"[{tag} curve] mean of the last 10 steps: product {tail(losses):.4f} reference fp32 {tail(ref32):.4f} "
-              f"(reference {tag} {tail(ref16):.4f}, fp64 {tail(vec['loss_fp64']):.4f})")
-        assert abs(tail(losses) - tail(ref32)) <= 2.0 * dev_ref
-    assert ts.found_inf.item() == 0
+        dev_ref = max(abs(tail(v) - tail(ref64)) for v in samples.values())
+        print(f"[{tag} curve] mean of the last 10 steps: product {tail(losses):.4f}, reference fp64 {tail(ref64):.4f}, "
+              f"reference samples {min(tail(v) for v in samples.values()):.4f} .. {max(tail(v) for v in samples.values()):.4f}")
+        assert abs(tail(losses) - tail(ref64)) <= 2.0 * dev_ref
+    assert ts.found_inf.item() == 0 and ts.t == steps  # no step was skipped by the GradScaler
     for gi in range(3):  # the 16-bit compute copies follow the fp32 master weights
         assert torch.equal(ts.flats.w16[gi].float(), ts.flats.w[gi].to(dtype).float())
