@@ -256,3 +256,34 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned hw_id, unsigned nwg) {
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16 bytes per lane global -> LDS through a buffer descriptor without touching VGPRs (`buffer_load_dwordx4 ... lds`):
+// per-lane byte offset `voff` + wave-uniform byte offset `soff`, out-of-range -> zeros; lds_wave_base is wave-uniform,
+// lane l lands at base + 16 l.
+//
+// Issued as INLINE ASM, not through __builtin_amdgcn_raw_ptr_buffer_load_lds: with the builtin hipcc (ROCm 7.2) knows of
+// the pending LDS write and puts an `s_waitcnt vmcnt(0)` in front of the first `ds_read_b64_tr_b16` after every barrier
+// (it does not for plain ds_read_b128) -- in every kernel whose fragments come from the transposed read (all input-
+// gradient and weight-gradient kernels) the hand-counted `s_waitcnt vmcnt(N)` pipeline was thereby drained each slab:
+// the DMA of slab kt+1 never overlapped the MFMAs of slab kt inside a wave.  The asm statement is opaque to that pass;
+// completion is tracked by the kernels' own counted waits (they already were).  M0 (the LDS base of the DMA) is written
+// in the same statement that uses it; `s_nop 4` covers an operand fresh from v_readfirstlane (VALU-written SGPR ->
+// VMEM: 5 wait states), `s_nop 0` the M0 write -> LDS-DMA wait state.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef MSFWSI_ASM_DMA
+#define MSFWSI_ASM_DMA 1
+#endif
+__device__ __forceinline__ void lds_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
+#if MSFWSI_ASM_DMA
+    const unsigned lds = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+#else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
+                                             0, 0);
+#endif
+}
+

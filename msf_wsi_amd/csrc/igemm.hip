@@ -30,7 +30,7 @@
 #include "../../include/msfwsi_hip.h"
 
 #ifndef MSFWSI_FETCH_FIRST
-#define MSFWSI_FETCH_FIRST 0  // 1 = the round-1 order (A/B builds: make EXTRA=-DMSFWSI_FETCH_FIRST=1)
+#define MSFWSI_FETCH_FIRST 1  // DMA requests of slab kt+2 before the MFMAs of slab kt (0: after them; A/B: make EXTRA=-DMSFWSI_FETCH_FIRST=0)
 #endif
 
 namespace {
@@ -759,8 +759,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 // measured 13 SALU + 6 VALU per MFMA -- which, not the MFMA pipe or HBM, bounded it.)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff,
-                                             soff, 0, 0);
+    lds_dma16_buf(rsrc, lds_wave_base, voff, soff);  // inline asm: see common.h
 }
 
 // RUN (stem): the S filter taps of one filter row are contiguous in NHWC memory when the channel count is one chunk
@@ -1042,10 +1041,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         }
         __builtin_amdgcn_s_barrier();  // slab kt visible to all waves; stage st_f (read in kt-1) is free
         asm volatile("" ::: "memory");
-        // The MFMAs of slab kt go first, the DMA requests of slab kt+2 after them: a wave that issues
-        // `buffer_load ... lds` stalls in the issue while earlier pieces are still landing, and with the requests ahead of
-        // the MFMAs every wave of the workgroup sat in that stall at the same time, the matrix pipe idle (measured on the
-        // weight-gradient kernel: DMA-only time + MFMA-only time = total; in this order 704 -> 845 TFLOP/s).
+        // Order of the DMA requests of slab kt+2 and the MFMAs of slab kt.  Round 2 measured "MFMAs first" faster (704 ->
+        // 845 TFLOP/s on the weight-gradient kernel) -- but that was with hipcc's hidden `s_waitcnt vmcnt(0)` in front of the
+        // transposed reads draining the pipeline every slab (common.h, lds_dma16_buf): a request issued before the MFMAs
+        // then only delayed them.  With the requests in inline asm two slabs really are in flight, and requests first is
+        // the faster order again (whole step 547.5 -> 545.3 ms, A/B on one box, two rounds).
 #if MSFWSI_FETCH_FIRST
         if (kt + 2 < nk) fetch(st_f);
         compute(st_c);

@@ -24,7 +24,7 @@
 #define MSFWSI_WGRAD_BIG_STAGES 3  // LDS stages of the 256 x 256 tile (32 KiB each)
 #endif
 #ifndef MSFWSI_FETCH_FIRST
-#define MSFWSI_FETCH_FIRST 0  // 1 = the round-1 order (A/B builds: make EXTRA=-DMSFWSI_FETCH_FIRST=1)
+#define MSFWSI_FETCH_FIRST 1  // DMA requests of slab kt+2 before the MFMAs of slab kt (0: after them; A/B: make EXTRA=-DMSFWSI_FETCH_FIRST=0)
 #endif
 
 namespace {
@@ -87,8 +87,7 @@ __device__ __forceinline__ void wdma16(const void* gsrc, void* lds_wave_base) {
 // same through a buffer descriptor: per-lane byte offset + wave-uniform byte offset, out-of-range -> zeros.
 // (kept in a __device__ helper: the builtin does not exist for the host pass of a __global__ template)
 __device__ __forceinline__ void wdma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff,
-                                             soff, 0, 0);
+    lds_dma16_buf(rsrc, lds_wave_base, voff, soff);  // inline asm: see common.h
 }
 
 template <int N>
@@ -372,10 +371,9 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            // MFMAs of slab kt first, then the DMA requests of slab kt+NST-1 (its stage was read in kt-1, every wave is
-            // past this iteration's barrier): a wave stalls in the issue of `buffer_load ... lds` while earlier pieces
-            // land, and with the requests ahead of the MFMAs all waves of the workgroup sat in that stall together --
-            // measured DMA-only + MFMA-only = total; in this order 704 -> 845 TFLOP/s (128 x 128), 759 -> 997 (256 x 256).
+            // DMA requests of slab kt+NST-1 (its stage was read in kt-1, every wave is past this iteration's barrier) and the
+            // MFMAs of slab kt: requests first since the DMA is issued from inline asm (see igemm.hip's main loop and
+            // common.h lds_dma16_buf; round 2's "MFMAs first" belonged to the drained pipeline)
 #if MSFWSI_FETCH_FIRST
             if (kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
             compute(st_c);
