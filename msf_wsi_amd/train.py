@@ -243,19 +243,27 @@ class PretrainStep(FlatAdamScaler):
             dist.all_gather_into_tensor(z_all, z.contiguous(), group=self.group)
             label0 = dist.get_rank(self.group) * rows
         n = z_all.shape[0]
+        if n % 4 or dd % 4:
+            raise ValueError(f"InfoNCE: the negative set ({n} rows = world x per-rank rows) and the embedding width ({dd}) "
+                             f"must be multiples of 4 (16-byte fp32 chunks of the logit matrix)")
         ph, zh = torch.empty_like(p), torch.empty_like(z_all)
         pinv = torch.empty(rows, dtype=torch.float32, device=dev)
         zinv = torch.empty(n, dtype=torch.float32, device=dev)
         kn.row_l2norm(p, ph, pinv)
         kn.row_l2norm(z_all, zh, zinv)
-        d = kn.conv_desc(self.dtype, rows, 1, 1, dd, n, 1, 1, 1, 0)
-        logits = torch.empty(rows, n, dtype=self.dtype, device=dev)
-        kn.conv_fwd(d, ph, zh, logits)                      # logits[i][j] = <p_hat_i, z_hat_j>
+        # the logit matrix and its gradient stay in fp32 whatever the storage type: a cosine in [-1, 1] rounded to bf16
+        # (4e-3) times 1/tau = 5 would put 2e-2 of error on every logit before the softmax
+        ph32 = ph if self.dtype == torch.float32 else kn.upcast_f32(ph)
+        zh32 = zh if self.dtype == torch.float32 else kn.upcast_f32(zh)
+        d = kn.conv_desc(torch.float32, rows, 1, 1, dd, n, 1, 1, 1, 0)
+        logits = torch.empty(rows, n, dtype=torch.float32, device=dev)
+        kn.conv_fwd(d, ph32, zh32, logits)                  # logits[i][j] = <p_hat_i, z_hat_j>
         kn.softmax_ce(logits, label0, 1.0 / self.temperature, coef, self.loss_accum, ls, write_grad=want_grad)
         if not want_grad:
             return None
-        dph = torch.empty_like(p)
-        kn.conv_dgrad(d, logits, zh, dph)                   # d p_hat = dlogits . z_hat
+        dph32 = torch.empty(rows, dd, dtype=torch.float32, device=dev)
+        kn.conv_dgrad(d, logits, zh32, dph32)               # d p_hat = dlogits . z_hat
+        dph = dph32 if self.dtype == torch.float32 else kn.cast_lowp(dph32, torch.empty_like(p))
         dp = torch.empty_like(p)
         kn.row_l2norm_bwd(ph, dph, pinv, dp)
         return dp

@@ -112,55 +112,44 @@ def test_encoder_inference_mode_and_bf16(hip_lib):
     assert h16[0].dtype == torch.float16 and rel(h16[0].float(), f32[0]) < 5e-3
 
 
-def _trunk_case(man):
-    """product ResNet-50 trunk + fp64 oracle gradients of the well-conditioned trunk case on this machine"""
+def _trunk_case(man, seed=None):
+    """product ResNet-50 trunk (trained-like residual gains, as make_golden.run_encoder_case) + the seeded inputs of the
+    well-conditioned trunk case (seed = the fixture's data seed unless given)"""
     from msf_wsi_amd.models import resnet
     from oracle import msfwsi_oracle as orc
 
     B, size, gain = man["B"], man["size"], man["stub_residual_gain"]
+    seed = man["data_seed"] if seed is None else seed
     torch.manual_seed(MODEL_SEED)
     enc = resnet.resnet50(zero_init_residual=False, return_features=True)
     enc.fc = torch.nn.Identity()
-    with torch.no_grad():  # trained-like residual gains, as make_golden.run_encoder_case
+    with torch.no_grad():
         for k, v in enc.state_dict().items():
             if k.startswith("layer") and k.endswith(".bn3.weight"):
                 v.mul_(gain)
     sd0 = {k: v.detach().clone() for k, v in enc.state_dict().items() if not k.startswith("fc.")}
-    x = orc.diverse_images(B, size, man["data_seed"])
-    return enc, sd0, x
+    x = orc.diverse_images(B, size, seed)
+    g = torch.Generator().manual_seed(seed)
+    Rs = [torch.randn(B, d, generator=g) for d in man["feature_dims"]]
+    return enc, sd0, x, Rs
 
 
-def _trunk_oracle(man, vec, sd0, x, Rs):
+def _trunk_oracle(sd0, x, Rs, dt=torch.float64, want_loss=None):
     from oracle import msfwsi_oracle as orc
 
-    osd = {"e." + k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    osd = {"e." + k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
     for k, v in osd.items():
         if orc.is_param(k):
             v.requires_grad_(True)
-    of = orc.encoder_forward(osd, "e.", x.double())
-    ol = sum((f * r.double()).sum() for f, r in zip(of, Rs))
+    of = orc.encoder_forward(osd, "e.", x.to(dt))
+    ol = sum((f * r.to(dt)).sum() for f, r in zip(of, Rs))
     ol.backward()
-    assert abs(float(ol) - float(vec["loss"][0])) <= 1e-9 * abs(float(vec["loss"][0]))  # pinned: the reference's fp64 loss
+    if want_loss is not None:  # pinned: the reference's fp64 loss of the fixture
+        assert abs(float(ol) - want_loss) <= 1e-9 * abs(want_loss)
     return [f.detach() for f in of], {k[2:]: v.grad for k, v in osd.items() if orc.is_param(k)}
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["fp32", "bf16", "fp16"])
-def test_resnet50_trunk_well_conditioned(hip_lib, dtype):
-    """the Bottleneck trunk (folded tails, two-source launches, stationary kernels where the size gate allows) on the
-    well-conditioned trunk case r50enc_b16_s64_div: every gradient tensor of  L = sum_s <features_s, R_s>  against the
-    fp64 oracle of this machine (pinned to the reference's fp64 loss by the fixture).  fp32: max(1e-3, 2 x the
-    reference's own fp32<->fp64 spread) with a rule-2 count that can trip; 16-bit: the reference-under-autocast spread."""
-    from helpers import LOWP_FLOOR, LOWP_TAG, lowp_gate
-
-    vec, man = load_golden("r50enc_b16_s64_div")
-    from oracle import msfwsi_oracle as orc
-
-    enc, sd0, x = _trunk_case(man)
-    g = torch.Generator().manual_seed(man["data_seed"])
-    if man["input_kind"] == "normal":
-        torch.randn(man["B"], 3, man["size"], man["size"], generator=g)
-    Rs = [torch.randn(man["B"], d, generator=g) for d in man["feature_dims"]]
-    f64, g64 = _trunk_oracle(man, vec, sd0, x, Rs)
+def _trunk_product(enc, x, Rs, dtype):
     enc = enc.cuda().train()
     scale = 1024.0 if dtype == torch.float16 else 1.0
     if dtype == torch.float32:
@@ -173,15 +162,59 @@ def test_resnet50_trunk_well_conditioned(hip_lib, dtype):
     (loss * scale).backward()
     torch.cuda.synchronize()
     named = dict(enc.named_parameters())
+    return feats, {k: named[k].grad.double().cpu() / scale for k in named if named[k].grad is not None}
+
+
+def test_resnet50_trunk_well_conditioned_fp32(hip_lib):
+    """the Bottleneck trunk (folded tails, two-source launches) on the well-conditioned trunk case r50enc_b16_s64_div,
+    fp32: every gradient tensor of  L = sum_s <features_s, R_s>  against the fp64 oracle of this machine (pinned to the
+    reference's fp64 loss by the fixture).
+
+    ONE ReLU gate flip near the top of a trunk moves every gradient below it (measured: layer4.0.bn1, 9e-3 there and 7e-4
+    on the 130 tensors below, everything above at 3e-6 = 1.4 x the reference's own fp32 run), so a single run cannot
+    tell a flip from a small arithmetic error.  A flip moves with the input, an error does not: the case is run on
+    THREE input seeds; per seed the flip-tolerant gate applies (max(1e-3, 2 x the reference's spread), outliers bounded),
+    and per tensor the SMALLEST of the three distances must be at the reference's own noise level (median <= 5 x the
+    reference's 2e-6) -- which a 1e-4 error in any kernel on the path fails."""
+    vec, man = load_golden("r50enc_b16_s64_div")
     names = man["param_keys"]
-    rels = np.array([rel(named[k].grad.double().cpu() / scale, g64[k]) for k in names])
-    fr = np.array([rel(f.float(), r) for f, r in zip(feats, f64)])
-    if dtype == torch.float32:
+    per_seed = []
+    for seed in (man["data_seed"], 1, 2):
+        enc, sd0, x, Rs = _trunk_case(man, seed)
+        f64, g64 = _trunk_oracle(sd0, x, Rs, want_loss=float(vec["loss"][0]) if seed == man["data_seed"] else None)
+        _, g32 = _trunk_oracle(sd0, x, Rs, torch.float32)  # the oracle's own fp32 run on this machine: reference noise
+        feats, grads = _trunk_product(enc, x, Rs, torch.float32)
+        fr = np.array([rel(f.float(), r) for f, r in zip(feats, f64)])
         assert fr.max() < 1e-3, fr
-        spread_gate(rels, names, [vec["spread_grad"]], "resnet50 trunk (well-conditioned), fp32 gradients",
-                    strict_count=True)
-    else:
-        tag = LOWP_TAG[dtype]
-        print(f"[trunk {tag}] features rel {fr}, reference under autocast {vec[f'spread_feat_{tag}']}")
-        assert (fr <= np.maximum(LOWP_FLOOR[dtype], 2.0 * vec[f"spread_feat_{tag}"])).all(), fr
-        lowp_gate(rels, names, vec[f"spread_grad_{tag}"], LOWP_FLOOR[dtype], f"resnet50 trunk {tag}: gradients")
+        rels = np.array([rel(grads[k], g64[k]) for k in names])
+        box = np.array([rel(g32[k], g64[k]) for k in names])
+        spreads = [box] + ([vec["spread_grad"]] if seed == man["data_seed"] else [])
+        spread_gate(rels, names, spreads, f"resnet50 trunk (well-conditioned, seed {seed}), fp32 gradients",
+                    strict_count=True, tight_median=False)
+        per_seed.append(rels)
+    best = np.min(np.stack(per_seed), axis=0)
+    ref_med = float(np.median(vec["spread_grad"]))
+    print(f"[trunk fp32] per-tensor minimum over 3 seeds: median {np.median(best):.2e} p90 {np.quantile(best, .9):.2e} "
+          f"max {best.max():.2e}; reference median {ref_med:.2e}; per-seed medians "
+          + ", ".join(f"{np.median(r):.2e}" for r in per_seed))
+    assert np.median(best) <= 5.0 * max(ref_med, 1e-6), float(np.median(best))
+    assert np.quantile(best, 0.9) <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_resnet50_trunk_well_conditioned_lowp(hip_lib, dtype):
+    """the same trunk in 16-bit storage (stationary kernels where the size gate allows): features and every gradient
+    tensor within 2 x the distance of the REFERENCE UNDER AUTOCAST from its fp64 run (fixture spread_*_bf16 / _fp16)"""
+    from helpers import LOWP_FLOOR, LOWP_TAG, lowp_gate
+
+    vec, man = load_golden("r50enc_b16_s64_div")
+    enc, sd0, x, Rs = _trunk_case(man)
+    f64, g64 = _trunk_oracle(sd0, x, Rs, want_loss=float(vec["loss"][0]))
+    feats, grads = _trunk_product(enc, x, Rs, dtype)
+    names = man["param_keys"]
+    rels = np.array([rel(grads[k], g64[k]) for k in names])
+    fr = np.array([rel(f.float(), r) for f, r in zip(feats, f64)])
+    tag = LOWP_TAG[dtype]
+    print(f"[trunk {tag}] features rel {fr}, reference under autocast {vec[f'spread_feat_{tag}']}")
+    assert (fr <= np.maximum(LOWP_FLOOR[dtype], 2.0 * vec[f"spread_feat_{tag}"])).all(), fr
+    lowp_gate(rels, names, vec[f"spread_grad_{tag}"], LOWP_FLOOR[dtype], f"resnet50 trunk {tag}: gradients")
