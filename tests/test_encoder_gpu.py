@@ -174,11 +174,12 @@ def test_resnet50_trunk_well_conditioned_fp32(hip_lib):
     on the 130 tensors below, everything above at 3e-6 = 1.4 x the reference's own fp32 run), so a single run cannot
     tell a flip from a small arithmetic error.  A flip moves with the input, an error does not: the case is run on
     THREE input seeds; per seed the flip-tolerant gate applies (max(1e-3, 2 x the reference's spread), outliers bounded),
-    and per tensor the SMALLEST of the three distances must be at the reference's own noise level (median <= 5 x the
-    reference's 2e-6) -- which a 1e-4 error in any kernel on the path fails."""
+    and per tensor the SMALLEST of the three distances must be at the level of the reference's own fp32 runs treated the
+    same way (the oracle in fp32 on this machine, per tensor the smallest of its three distances: median <= 5 x) -- which
+    a 1e-4 error in any kernel on the path fails."""
     vec, man = load_golden("r50enc_b16_s64_div")
     names = man["param_keys"]
-    per_seed = []
+    per_seed, per_seed_ref = [], []
     for seed in (man["data_seed"], 1, 2):
         enc, sd0, x, Rs = _trunk_case(man, seed)
         f64, g64 = _trunk_oracle(sd0, x, Rs, want_loss=float(vec["loss"][0]) if seed == man["data_seed"] else None)
@@ -189,16 +190,18 @@ def test_resnet50_trunk_well_conditioned_fp32(hip_lib):
         rels = np.array([rel(grads[k], g64[k]) for k in names])
         box = np.array([rel(g32[k], g64[k]) for k in names])
         spreads = [box] + ([vec["spread_grad"]] if seed == man["data_seed"] else [])
-        spread_gate(rels, names, spreads, f"resnet50 trunk (well-conditioned, seed {seed}), fp32 gradients",
-                    strict_count=True, tight_median=False)
+        # (the reference's own fp32 run of a seed can carry a flip at the top as well -- measured: 153 of 159 tensors above
+        #  1e-3 for seed 2 on the EPYC host -- so no fixture-quality assertion here: strict_count=False)
+        spread_gate(rels, names, spreads, f"resnet50 trunk (well-conditioned, seed {seed}), fp32 gradients")
         per_seed.append(rels)
-    best = np.min(np.stack(per_seed), axis=0)
-    ref_med = float(np.median(vec["spread_grad"]))
-    print(f"[trunk fp32] per-tensor minimum over 3 seeds: median {np.median(best):.2e} p90 {np.quantile(best, .9):.2e} "
-          f"max {best.max():.2e}; reference median {ref_med:.2e}; per-seed medians "
-          + ", ".join(f"{np.median(r):.2e}" for r in per_seed))
-    assert np.median(best) <= 5.0 * max(ref_med, 1e-6), float(np.median(best))
-    assert np.quantile(best, 0.9) <= 1e-3
+        per_seed_ref.append(np.min(np.stack(spreads), axis=0))
+    best, best_ref = np.min(np.stack(per_seed), axis=0), np.min(np.stack(per_seed_ref), axis=0)
+    print(f"[trunk fp32] per-tensor minimum over 3 seeds: product median {np.median(best):.2e} p90 {np.quantile(best, .9):.2e}"
+          f" max {best.max():.2e}; the reference's own fp32 runs: median {np.median(best_ref):.2e} p90 "
+          f"{np.quantile(best_ref, .9):.2e}; per-seed medians product " + ", ".join(f"{np.median(r):.2e}" for r in per_seed)
+          + " reference " + ", ".join(f"{np.median(r):.2e}" for r in per_seed_ref))
+    assert np.median(best) <= 5.0 * max(float(np.median(best_ref)), 1e-6), float(np.median(best))
+    assert np.quantile(best, 0.9) <= max(1e-3, 5.0 * float(np.quantile(best_ref, 0.9)))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])

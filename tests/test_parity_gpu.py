@@ -24,21 +24,6 @@ from helpers import (LR, WEIGHTS, build_case, build_product, case_batch, flat_ou
 pytestmark = pytest.mark.gpu
 
 
-def oracle_step(sd0, batch, B, dt, adam=True):
-    from oracle import msfwsi_oracle as orc
-
-    osd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}  # never alias sd0
-    (c1, c2), (t1, t2), idx = batch
-    b = ((c1.to(dt), c2.to(dt)), (t1.to(dt), t2.to(dt)), idx)
-    lr = orc.init_lr(LR, B)
-    if adam:
-        opt = orc.Adam(osd, [lr, lr, lr])
-    else:
-        opt = type("NoOpt", (), {"step": lambda self, *a, **k: None})()
-    loss, terms, outs, grads = orc.train_step(osd, b, opt, 4, 0.5, WEIGHTS)
-    return loss, torch.stack([t for row in terms for t in row]), outs, grads, osd
-
-
 def run_reference_loop_case(case, check_golden_outputs=True):
     """the reference loop's own statements (tools/ssl_train.py:442-474, fp32) on the product, checked against the
     fp64 / fp32 oracle of this machine and the golden vectors of `case`"""
@@ -56,10 +41,13 @@ def run_reference_loop_case(case, check_golden_outputs=True):
 
     batch = case_batch(man)
     do_adam = bool(man["adam"])
-    loss64, terms64, outs64, grads64, sd64 = oracle_step(sd0, batch, B, torch.float64, adam=do_adam)
-    loss32, terms32, outs32, grads32, sd32 = oracle_step(sd0, batch, B, torch.float32, adam=do_adam)
-    # the oracle on this machine is pinned to the real reference by the golden vectors
-    assert torch.allclose(terms64, torch.as_tensor(vec["terms"]), rtol=0, atol=1e-7)
+    # one fp64 and one fp32 oracle step of this case on this machine, shared with the other tests of the session
+    # (helpers.oracle_case; it asserts the oracle's fp64 loss terms against the fixture of the real reference)
+    from helpers import oracle_case
+
+    oc = oracle_case(case)
+    loss64, terms64, outs64, grads64, sd64 = oc["loss64"], oc["terms64"], oc["outs64"], oc["grads64"], oc["sd64"]
+    grads32, sd32 = oc["grads32"], oc["sd32"]
     assert abs(float(loss64) - float(vec["loss"][0])) < 1e-7
 
     model = model.cuda().train()
@@ -139,12 +127,6 @@ def test_step_parity_r18_b8_s224_config1(hip_lib):
     run_reference_loop_case("r18_b8_s224")
 
 
-def test_step_parity_r50_b8_s64(hip_lib):
-    """the ResNet-50-DERIVED model that configs 2-4 and bench.py run (heads at x4 widths, 1.665 B parameters, fuser
-    GEMMs up to 18432 x 18432): forward, loss and every gradient against the derived oracle"""
-    run_reference_loop_case("r50_b8_s64")
-
-
 def test_step_parity_r18_b16_s64_diverse(hip_lib):
     """well-conditioned inputs (oracle.diverse_batch): the reference's own fp32<->fp64 spread has a median of ~1e-5
     here and 3/4 of its gradient tensors sit below 1e-3, so the per-tensor gate bites at the north-star 1e-3 and rule 2's
@@ -153,7 +135,11 @@ def test_step_parity_r18_b16_s64_diverse(hip_lib):
 
 
 def test_step_parity_r50_b8_s64_diverse(hip_lib):
-    """the ResNet-50-derived model on well-conditioned inputs (see above; VERDICT r2 weak #2)"""
+    """the ResNet-50-DERIVED model that configs 2-4 and bench.py run (heads at x4 widths, 1.665 B parameters, fuser GEMMs
+    up to 18432 x 18432) on well-conditioned inputs: forward, loss and every gradient against the derived
+    oracle.  (The round-2 case on N(0,1) pixels, r50_b8_s64, is retired from the GPU suite: on it the reference's own
+    fp32 run sits 2e-2 from its fp64 run and the gate could not fail -- VERDICT r2 weak #2; its fixture remains for
+    tests/test_oracle.py.)"""
     run_reference_loop_case("r50_b8_s64_div")
 
 
