@@ -414,7 +414,7 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
 // r*3+s of the four pixels:
 //   (2i,2j): (i,j)=4 | (2i,2j+1): (i,j)=5, (i,j+1)=3 | (2i+1,2j): (i,j)=7, (i+1,j)=1 | (2i+1,2j+1): 8, 6, 2, 0
 template <typename T>
-__global__ void stem_pool_bwd_patch_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ amax,
+__global__ __launch_bounds__(256) void stem_pool_bwd_patch_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ amax,
                                            const T* __restrict__ c0, const float* __restrict__ scale,
                                            const float* __restrict__ shift, T* __restrict__ g0, double* sums, int nshard,
                                            const float* __restrict__ k1, const float* __restrict__ k2,
@@ -447,19 +447,19 @@ __global__ void stem_pool_bwd_patch_kernel(const T* __restrict__ dp, const unsig
             const int j = (int)(mu - t * (unsigned)Wh);
             const int n = (int)(t / (unsigned)Hh);
             const int i = (int)(t - (unsigned)n * (unsigned)Hh);
-            // the four windows (i + a, j + b)
-            float d[2][2][VEC];
+            // the four windows (i + a, j + b): gradient chunks kept PACKED (16 bytes each) and unpacked per use -- held as
+            // 4 x 8 floats the kernel needed ~170 VGPRs and spilled at the 128 a 256-thread streaming kernel gets
+            uint4 dpk[2][2];
             unsigned long long ab[2][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     ab[a][b] = ~0ull;  // no position code matches 0xff
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) d[a][b][e] = 0.f;
+                    dpk[a][b] = make_uint4(0, 0, 0, 0);
                     if (i + a < P && j + b < Q) {
                         const long o = (((long)n * P + i + a) * Q + j + b) * C + ch;
-                        unpack16<T>(*reinterpret_cast<const uint4*>(dp + o), d[a][b]);
+                        dpk[a][b] = *reinterpret_cast<const uint4*>(dp + o);
                         if constexpr (VEC == 8) ab[a][b] = *reinterpret_cast<const unsigned long long*>(amax + o);
                         else ab[a][b] = *reinterpret_cast<const unsigned*>(amax + o);
                     }
@@ -479,9 +479,11 @@ __global__ void stem_pool_bwd_patch_kernel(const T* __restrict__ dp, const unsig
 #pragma unroll
                         for (int b = 0; b <= dw; ++b) {
                             const unsigned code = (unsigned)((dh + 1 - 2 * a) * 3 + (dw + 1 - 2 * b));
+                            float d[VEC];
+                            unpack16<T>(dpk[a][b], d);
 #pragma unroll
                             for (int e = 0; e < VEC; ++e)
-                                if (((unsigned)(ab[a][b] >> (8 * e)) & 0xffu) == code) g[e] += d[a][b][e];
+                                if (((unsigned)(ab[a][b] >> (8 * e)) & 0xffu) == code) g[e] += d[e];
                         }
                     const long m = ((long)n * H + h) * W + w;
                     float x[VEC];
@@ -504,6 +506,9 @@ __global__ void stem_pool_bwd_patch_kernel(const T* __restrict__ dp, const unsig
                         for (int e = 0; e < VEC; ++e) g[e] = fmaf(k1[ch + e], g[e], fmaf(k2[ch + e], x[e], k3[ch + e]));
                     }
                     if (g0 != nullptr) *reinterpret_cast<uint4*>(g0 + m * C + ch) = pack16<T>(g);
+                    // one pixel after the other: scheduled together, the four pixels' loads and unpacked vectors need
+                    // ~180 VGPRs (two waves per SIMD, or spills at the 128 of four) -- other waves cover the latency
+                    __builtin_amdgcn_sched_barrier(0);
                 }
         }
     }
@@ -1174,7 +1179,8 @@ extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scal
 
 // msfwsi_set_tuning(14, .): 1 = the 2x2-patch kernel.  Measured on the bench workload (A/B on one box, two rounds):
 // 568-571 ms/step with it against 563.6 without -- fewer bytes through the vector memory path, but four pixels per
-// thread leave too few waves in flight; the per-pixel kernel stays the default
+// thread need ~180 VGPRs (hipcc schedules them together: two waves per SIMD, or 150-300 bytes of scratch when capped at
+// 128 / 96 registers), too few waves in flight for a streaming kernel; the per-pixel kernel (109 VGPRs) stays the default
 static long g_pool_bwd_patch = 0;
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_patch(long v) { g_pool_bwd_patch = v; }
 
