@@ -23,7 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = {"resnet18": 363.37e9, "resnet50": 848.8e9}  # SURVEY.md 8(d), fwd+bwd per tile pair
 # algorithmic minimum HBM bytes -- activations per tile pair (2-byte storage; x2 for fp32) and the
@@ -382,7 +382,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="tile pairs per GPU")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--classes", type=int, default=5, help="config 5: segmentation classes (+1 background channel)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="storage / MFMA input type (bf16: BASELINE config 2; fp16: the reference's default --amp dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stock-batch", type=int, default=32,
                     help="tile pairs of the stock-PyTorch GPU yardstick (0 = skip it); it runs with the CPU baseline")
@@ -448,7 +449,7 @@ def main():
     from msf_wsi_amd.train import PretrainStep, synthetic_batch
 
     _lib.load()
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     dev = torch.device("cuda", local)
     if args.config == 5:
         run_finetune(args, world, rank, dev, dtype)
@@ -514,7 +515,7 @@ def main():
                     f.write(f"{kind}\t{1e3 * sec / nst:.3f}\t{n / nst:.1f}\t{fl / sec / 1e12:.1f}\t{by / sec / 1e9:.0f}\t"
                             f"{shape}\t{sym if kind != 'stream' else ''}\n")
         if timer is not None:
-            step_bytes = (ACT_BYTES_PER_PAIR_16BIT.get(args.arch, 0) * (1 if args.dtype == "bf16" else 2) * args.batch
+            step_bytes = (ACT_BYTES_PER_PAIR_16BIT.get(args.arch, 0) * (2 if args.dtype == "fp32" else 1) * args.batch
                           + ADAM_BYTES_PER_STEP.get(args.arch, 0))
             out["roofline"] = build_roofline(timer, args, dt, timed_from, step_bytes,
                                              FLOP_PER_PAIR.get(args.arch, 0) * args.batch)

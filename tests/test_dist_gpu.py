@@ -218,3 +218,53 @@ def test_infonce_all_gather_negatives_two_ranks(hip_lib):
     torch.cuda.synchronize()
     assert abs(ret["loss0"] - ret["loss1"]) < 1e-12            # epoch_loss is the all-reduced sample-weighted mean
     assert abs(ret["loss0"] - loss) <= 1e-4 * max(1.0, abs(loss)), (ret["loss0"], loss)
+
+
+def _ft_worker(rank, world, port, ret):
+    from msf_wsi_amd.dist import shard_range
+    from msf_wsi_amd.finetune import FinetuneStep
+    from test_hooknet_gpu import _build, _inputs
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        model = _build().cuda().train()
+        x1, x2, m1, m2 = _inputs(B=4)
+        lo, hi = shard_range(4, world, rank)
+        ts = FinetuneStep(model, lr=1e-3, batch_size=4, lam=0.75, dtype=torch.float32, use_scaler=False, sync_bn=True)
+        loss, _ = ts.step((x1[lo:hi].cuda(), x2[lo:hi].cuda()), (m1[lo:hi].cuda(), m2[lo:hi].cuda()))
+        torch.cuda.synchronize()
+        if rank == 0:
+            ret["sd"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            ret["collectives"] = ts.engine.collectives_last_step
+    finally:
+        dist.destroy_process_group()
+
+
+def test_finetune_step_two_ranks_match_single_process(hip_lib):
+    """the fused fine-tune step data-parallel (tools/ssl_finetune.py:183-193: SyncBatchNorm + DDP): 2 ranks x 2 tile pairs
+    == 1 rank x 4 -- BatchNorm running statistics and updated weights.  (The Dice loss is a ratio of batch sums, so the
+    per-rank LOSS VALUES differ from the full-batch one also in the reference; the gradients are what DDP averages.)"""
+    from msf_wsi_amd.finetune import FinetuneStep
+    from test_hooknet_gpu import _build, _inputs
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_ft_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["collectives"] > 100
+    sd2 = ret["sd"]
+    for k, v in sd2.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 1
+    # SyncBatchNorm: the running statistics of the 2-rank run are those of the full batch
+    model = _build().cuda().train()
+    x1, x2, m1, m2 = _inputs(B=4)
+    ts = FinetuneStep(model, lr=1e-3, batch_size=4, lam=0.75, dtype=torch.float32, use_scaler=False)
+    ts.step((x1.cuda(), x2.cuda()), (m1.cuda(), m2.cuda()))
+    torch.cuda.synchronize()
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            assert torch.allclose(sd2[k].double(), v.detach().cpu().double(), rtol=1e-3, atol=1e-5), k
