@@ -10,7 +10,7 @@ storage layout between the segmentation head, the loss and the backward, no host
 confusion counts of the target prediction against the target mask.
 
 The decoder / Dice / metric arithmetic lives in segmentation_models_pytorch (third party, outside the reference tree,
-absent here): its published algorithm is restated -- parity unpinned (oracle/hooknet_oracle.py, oracle/metrics_oracle.py).
+absent here): its published algorithm is restated by the test-side checker -- parity unpinned.
 """
 from __future__ import annotations
 
