@@ -18,6 +18,7 @@ There is no CPU / eager-torch fallback: CPU tensors raise.
 from __future__ import annotations
 
 import os
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -115,14 +116,25 @@ def chan_pad(dtype: torch.dtype) -> int:
 class WeightStore:
     """Compute-dtype operand views of the parameters.  fp32 uses the parameter storage in place
     (channels_last == [K][R][S][C]); bf16 copies are cast by the HIP cast kernel and cached per parameter
-    version.  A trainer may pre-register externally maintained copies (`register`)."""
+    version.  A trainer may pre-register externally maintained copies (`register`).
+
+    Every entry is keyed on the `id` of the tensor it derives from AND carries a weak reference to it: an entry whose
+    source object has died never answers for a new object that happens to get the same id, version counter and device
+    address (the process-wide default engine outlives the models it serves -- without the check a second model built
+    after the first was dropped could be multiplied with the first one's weights)."""
 
     def __init__(self):
-        self._cache: Dict[int, Tuple[int, int, torch.Tensor]] = {}
-        self._ext: Dict[int, torch.Tensor] = {}
+        self._cache: Dict[tuple, tuple] = {}    # (id(param), dtype, pad) -> (weakref(param), version key, copy)
+        self._ext: Dict[tuple, tuple] = {}      # (id(param), dtype)      -> (weakref(param), copy)
+        self._derived: Dict[tuple, tuple] = {}  # (kind, id(source))      -> (weakref(source), tensor)
 
     def register(self, param: torch.Tensor, dtype: torch.dtype, tensor: torch.Tensor):
-        self._ext[(id(param), dtype)] = tensor
+        self._ext[(id(param), dtype)] = (weakref.ref(param), tensor)
+
+    def clear(self):
+        """drop every derived copy (not the registered ones: their owner keeps them current)"""
+        self._cache.clear()
+        self._derived.clear()
 
     @staticmethod
     def physical(param: torch.Tensor) -> torch.Tensor:
@@ -140,16 +152,16 @@ class WeightStore:
 
     def get(self, param: torch.Tensor, dtype: torch.dtype, pad_to: int = 0) -> torch.Tensor:
         ext = self._ext.get((id(param), dtype))
-        if ext is not None:
-            return ext
+        if ext is not None and ext[0]() is param:
+            return ext[1]
         phys = self.physical(param)
         if dtype == torch.float32 and not pad_to:
             return phys
-        key = (id(param), dtype)
+        key = (id(param), dtype, pad_to)
         ver = (param._version, phys.data_ptr())
         hit = self._cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+        if hit is not None and hit[0]() is param and hit[1] == ver:
+            return hit[2]
         if pad_to:
             rows = phys.numel() // phys.shape[-1]
             out = torch.empty(*phys.shape[:-1], pad_to, dtype=dtype, device=phys.device)
@@ -157,7 +169,22 @@ class WeightStore:
         else:
             out = torch.empty(phys.shape, dtype=dtype, device=phys.device)
             kn.cast_lowp(phys, out)
-        self._cache[key] = (ver, out)
+        self._cache[key] = (weakref.ref(param), ver, out)
+        if len(self._cache) > 4096:  # entries of dead parameters (models dropped while the engine lives on)
+            self._cache = {k: v for k, v in self._cache.items() if v[0]() is not None}
+        return out
+
+    def derived(self, kind: str, src: torch.Tensor, make) -> torch.Tensor:
+        """a tensor computed from `src` (a cached or registered copy), kept while that very object lives and until
+        `clear`: owners that rewrite `src` through raw pointers (the flat Adam kernel) call `clear` after each update"""
+        key = (kind, id(src))
+        hit = self._derived.get(key)
+        if hit is not None and hit[0]() is src:
+            return hit[1]
+        out = make(src)
+        self._derived[key] = (weakref.ref(src), out)
+        if len(self._derived) > 4096:
+            self._derived = {k: v for k, v in self._derived.items() if v[0]() is not None}
         return out
 
 
@@ -262,7 +289,7 @@ class Engine:
         """Every derived copy of the parameters (16-bit / channel-padded casts, the stem's filter-row runs) is keyed on
         torch's version counter and data pointer, which an optimizer that updates the storage through raw pointers
         (the flat Adam kernel) or `load_state_dict` into views does not move: trainers call this after every update."""
-        self.weights._cache.clear()
+        self.weights.clear()
         self._stem_cache.clear()
 
     # ---- configuration ---------------------------------------------------------------------
@@ -460,10 +487,10 @@ class Engine:
         key = (id(op.weight), dtype, "s2d")
         ver = (op.weight._version, op.weight.data_ptr())
         hit = self._stem_cache.get(key)
-        if hit is None or hit[0] != ver:
+        if hit is None or hit[0] != ver or hit[2]() is not op.weight:
             w2 = torch.empty(op.out_channels, 4, 4, 16, dtype=dtype, device=op.weight.device)
             kn.stem_s2d_weights(WeightStore.physical(op.weight), w2)
-            hit = (ver, w2)
+            hit = (ver, w2, weakref.ref(op.weight))
             self._stem_cache[key] = hit
         return hit[1]
 
@@ -494,14 +521,14 @@ class Engine:
         key = (id(op.weight), dtype, "run")
         ver = (op.weight._version, op.weight.data_ptr())
         hit = self._stem_cache.get(key)
-        if hit is None or hit[0] != ver:
+        if hit is None or hit[0] != ver or hit[2]() is not op.weight:
             phys = WeightStore.physical(op.weight)  # fp32 [K][R][S][Cin]
             Cin = phys.shape[-1]
             wp = torch.empty(K * R * S, CP, dtype=torch.float32, device=phys.device)
             kn.pad_cast(phys, wp, K * R * S, Cin, CP)          # channels -> one 16-byte chunk
             w_run = torch.empty(K, R, run, dtype=dtype, device=phys.device)
             kn.pad_cast(wp, w_run, K * R, S * CP, run)         # filter row -> whole k slabs, storage type
-            hit = (ver, w_run)
+            hit = (ver, w_run, weakref.ref(op.weight))
             self._stem_cache[key] = hit
         return hit[1]
 
@@ -523,12 +550,7 @@ class Engine:
 
     def _f32_of(self, w16: torch.Tensor) -> torch.Tensor:
         """fp32 copy of a 16-bit weight tensor, shared by the passes of one step (dropped by invalidate_weights)"""
-        key = ("f32", w16.data_ptr(), w16.numel())
-        hit = self.weights._cache.get(key)
-        if hit is None:
-            hit = (None, kn.upcast_f32(w16))
-            self.weights._cache[key] = hit
-        return hit[1]
+        return self.weights.derived("f32", w16, kn.upcast_f32)
 
     def _ds_tail_fwd(self, conv3, bn3, dconv, dbn, c2: torch.Tensor, pro: BNState, x: torch.Tensor, geom, dtype,
                      want_bits: bool):

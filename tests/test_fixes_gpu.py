@@ -296,3 +296,60 @@ def test_stem_weight_gradient_with_fused_batchnorm_backward(hip_lib, dtype, hw):
     assert rel(dw2.cpu(), ref) < 2e-3  # the bracket's rounding (1 ulp flips between fmaf and two roundings)
     assert rel(dw.cpu(), dw2.cpu()) < 1e-5, rel(dw.cpu(), dw2.cpu())  # same bracket bit for bit: only the atomics' order differs
     assert rel(dw.cpu(), ref) < 2e-3
+
+
+def test_weight_copies_never_answer_for_another_parameter(hip_lib):
+    """The process-wide default engine outlives the models it serves.  Its derived weight copies are keyed on id(parameter)
+    + version counter + device address -- all three can repeat once a model has been dropped and another one built (CPython
+    reuses object addresses, the caching allocator reuses blocks; seen in a long test session: a later model multiplied with
+    an earlier model's weights).  Each entry therefore carries a weak reference to its source: forge exactly that collision
+    and check the store does not fall for it."""
+    from msf_wsi_amd.engine import WeightStore
+
+    ws = WeightStore()
+    g = torch.Generator().manual_seed(0)
+    p1 = torch.nn.Parameter(torch.randn(64, 32, 1, 1, generator=g).cuda())
+    p2 = torch.nn.Parameter(torch.randn(64, 32, 1, 1, generator=g).cuda())
+    c1 = ws.get(p1, torch.bfloat16)
+    f1 = ws.derived("f32", c1, lambda t: t.float())
+    assert ws.get(p1, torch.bfloat16) is c1 and ws.derived("f32", c1, lambda t: t.float()) is f1
+    # the collision: p1's entry filed under p2's id with p2's version key
+    ref1, _, copy1 = ws._cache.pop((id(p1), torch.bfloat16, 0))
+    ws._cache[(id(p2), torch.bfloat16, 0)] = (ref1, (p2._version, WeightStore.physical(p2).data_ptr()), copy1)
+    c2 = ws.get(p2, torch.bfloat16)
+    assert c2 is not copy1
+    assert torch.equal(c2.float().permute(0, 3, 1, 2), p2.detach().to(torch.bfloat16).float())
+    # a derived tensor filed under another object's id
+    ws._derived[("f32", id(c2))] = ws._derived.pop(("f32", id(c1)))
+    f2 = ws.derived("f32", c2, lambda t: t.float())
+    assert f2 is not f1 and torch.equal(f2, c2.float())
+    # a dead source: the entry is not served to whoever inherits the id
+    key = (id(p1), torch.bfloat16, 0)
+    ws.get(p1, torch.bfloat16)
+    dead = ws._cache[key][0]
+    del p1
+    import gc
+
+    gc.collect()
+    assert dead() is None
+
+
+def test_models_in_sequence_through_the_default_engine(hip_lib):
+    """eight differently seeded models, each built after the previous one was dropped, through the shared default engine
+    in 16-bit storage: every forward equals the same model's forward on a private, empty engine bit for bit (the ResNet-18
+    forward has no atomics on data)"""
+    from msf_wsi_amd.engine import Engine
+    from msf_wsi_amd.models import resnet as my_resnet
+
+    x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    for seed in range(8):
+        torch.manual_seed(100 + seed)
+        enc = my_resnet.resnet18(pretrained=False, return_features=True)
+        enc.fc = torch.nn.Identity()
+        enc = enc.cuda().train()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            shared = [f.float().clone() for f in enc(x)]
+            enc._engine = Engine()
+            private = [f.float().clone() for f in enc(x)]
+        assert all(torch.equal(a, b) for a, b in zip(shared, private)), seed
+        del enc
