@@ -132,6 +132,12 @@ int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* 
  * Replaces: convolution_backward(weight) / linear backward(weight), tools/ssl_train.py:472. */
 int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* pro_scale,
                       const float* pro_shift, int target_blocks, void* stream);
+/* Gram matrix A64[C][C] (fp64) += a^T a over the N*H*W pixels of the NHWC activation a (d: the 1x1 / stride-1 conv C -> C
+ * whose weight gradient with x = dy = a it is; same MFMA kernels as msfwsi_conv_wgrad, the pixel splits accumulate in
+ * fp64).  The folded Bottleneck tail takes bn3's batch statistics from it (sum c^2 = diag(W A W^T)); the fp64
+ * accumulation makes them -- and with them the forward -- independent of the order of the atomic additions.
+ * Replaces: the statistics pass of native_batch_norm over conv3's output, src/models/resnet.py:131-138. */
+int msfwsi_gram(const msfwsi_conv_desc* d, const void* a, double* A64, void* stream);
 /* The stem's weight gradient (space-to-depth form, 2-byte types) with the BatchNorm backward of bn1 applied on the
  * fly: dw[64][4][4][16] += (k1*g + k2*c0 + k3)^T x, where g is the gated gradient of bn1's output, c0 the raw conv
  * output and k1..k3 the coefficients of msfwsi_bn_bwd_finalize; the bracket is rounded to the storage type exactly as

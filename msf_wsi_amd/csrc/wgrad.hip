@@ -35,6 +35,8 @@ struct WgradParams {
     const void* x;
     const void* dy;
     float* dw;
+    double* dw64;  // if set: the pixel splits accumulate in fp64 instead (msfwsi_gram: the order of the atomic additions
+                   // then moves the sum by ~1e-16, invisible after rounding to fp32 -- run-to-run reproducible forward)
     const float* pro_scale;
     const float* pro_shift;
     int N, H, W, C;
@@ -406,7 +408,10 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = i0 + (wi * TI + ti) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                if (co < prm.K && j < prm.Jtot) atomicAdd(prm.dw + (long)co * prm.Jtot + j, acc[ti][tj][reg]);
+                if (co < prm.K && j < prm.Jtot) {
+                    if (prm.dw64 != nullptr) atomicAdd(prm.dw64 + (long)co * prm.Jtot + j, (double)acc[ti][tj][reg]);
+                    else atomicAdd(prm.dw + (long)co * prm.Jtot + j, acc[ti][tj][reg]);
+                }
             }
         }
 }
@@ -787,6 +792,36 @@ extern "C" int msfwsi_stem_wgrad_bnbwd(const msfwsi_conv_desc* d, const void* x,
     return msfwsi_stem_os_wgrad(d, x, g, dw, c0, k1, k2, k3, stream);
 }
 
+static int wgrad_generic(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, double* dw64,
+                         const float* pro_scale, const float* pro_shift, int target_blocks, hipStream_t st) {
+    WgradParams prm{};
+    prm.x = x; prm.dy = dy; prm.dw = dw; prm.dw64 = dw64;
+    prm.pro_scale = pro_scale; prm.pro_shift = pro_shift;
+    prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C;
+    prm.P = d->P; prm.Q = d->Q; prm.K = d->K;
+    prm.R = d->R; prm.S = d->S; prm.stride = d->stride; prm.pad = d->pad;
+    prm.M = d->N * d->P * d->Q;
+    prm.Jtot = d->R * d->S * d->C;
+    prm.div_pq = make_fastdiv((unsigned)(d->P * d->Q));
+    prm.div_q = make_fastdiv((unsigned)d->Q);
+    const bool small_i = d->K <= 64;
+    const bool small_j = prm.Jtot <= 64;
+    // 2-byte types, both extents in whole 256-wide tiles, no recomputed prologue: the eight-wave tile
+    const bool big = g_wgrad_big && d->dtype != MSFWSI_DT_F32 && d->K % 256 == 0 && prm.Jtot % 256 == 0 &&
+                     pro_scale == nullptr;
+    if (big) {
+        if (d->dtype == MSFWSI_DT_BF16) return launch_wgrad<__bf16, 256, 256>(prm, target_blocks, st);
+        return launch_wgrad<_Float16, 256, 256>(prm, target_blocks, st);
+    }
+    MSFWSI_WITH_T(d->dtype, {
+        if (small_i && small_j) return launch_wgrad<T, 64, 64>(prm, target_blocks, st);
+        if (small_i) return launch_wgrad<T, 64, 128>(prm, target_blocks, st);
+        if (small_j) return launch_wgrad<T, 128, 64>(prm, target_blocks, st);
+        return launch_wgrad<T, 128, 128>(prm, target_blocks, st);
+    });
+    return MSFWSI_EINVAL;
+}
+
 extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw,
                                  const float* pro_scale, const float* pro_shift, int target_blocks,
                                  void* stream) {
@@ -806,31 +841,19 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
         if (d->dtype == MSFWSI_DT_BF16) return launch_wgrad_os<__bf16>(d, x, dy, dw, pro_scale, pro_shift, st0);
         return launch_wgrad_os<_Float16>(d, x, dy, dw, pro_scale, pro_shift, st0);
     }
-    WgradParams prm{};
-    prm.x = x; prm.dy = dy; prm.dw = dw;
-    prm.pro_scale = pro_scale; prm.pro_shift = pro_shift;
-    prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C;
-    prm.P = d->P; prm.Q = d->Q; prm.K = d->K;
-    prm.R = d->R; prm.S = d->S; prm.stride = d->stride; prm.pad = d->pad;
-    prm.M = d->N * d->P * d->Q;
-    prm.Jtot = d->R * d->S * d->C;
-    prm.div_pq = make_fastdiv((unsigned)(d->P * d->Q));
-    prm.div_q = make_fastdiv((unsigned)d->Q);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const bool small_i = d->K <= 64;
-    const bool small_j = prm.Jtot <= 64;
-    // 2-byte types, both extents in whole 256-wide tiles, no recomputed prologue: the eight-wave tile
-    const bool big = g_wgrad_big && d->dtype != MSFWSI_DT_F32 && d->K % 256 == 0 && prm.Jtot % 256 == 0 &&
-                     pro_scale == nullptr;
-    if (big) {
-        if (d->dtype == MSFWSI_DT_BF16) return launch_wgrad<__bf16, 256, 256>(prm, target_blocks, st);
-        return launch_wgrad<_Float16, 256, 256>(prm, target_blocks, st);
-    }
-    MSFWSI_WITH_T(d->dtype, {
-        if (small_i && small_j) return launch_wgrad<T, 64, 64>(prm, target_blocks, st);
-        if (small_i) return launch_wgrad<T, 64, 128>(prm, target_blocks, st);
-        if (small_j) return launch_wgrad<T, 128, 64>(prm, target_blocks, st);
-        return launch_wgrad<T, 128, 128>(prm, target_blocks, st);
-    });
-    return MSFWSI_EINVAL;
+    return wgrad_generic(d, x, dy, dw, nullptr, pro_scale, pro_shift, target_blocks, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Gram matrix A += a^T a of an NHWC activation (d: the 1x1 / stride-1 conv C -> C whose "weight gradient" with x = dy = a
+// it is), accumulated in fp64.  The folded Bottleneck tail derives bn3's batch statistics from it: with fp32
+// atomics the order of the pixel splits moved the statistics by ~1e-6 from run to run, which 16-bit storage and a deep
+// BatchNorm chain amplify to a visibly different step; in fp64 the forward is reproducible to the last bit in practice.
+extern "C" int msfwsi_gram(const msfwsi_conv_desc* d, const void* a, double* A64, void* stream) {
+    if (d == nullptr || a == nullptr || A64 == nullptr) return MSFWSI_EINVAL;
+    if (!msfwsi_dtype_ok(d->dtype)) return MSFWSI_EUNSUPPORTED;
+    const int vec = msfwsi_vec_of(d->dtype);
+    if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->C != d->K || d->C % vec != 0) return MSFWSI_EUNSUPPORTED;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->P != d->H || d->Q != d->W) return MSFWSI_EINVAL;
+    if ((long)d->N * d->H * d->W > 0x7fffffffL) return MSFWSI_EINVAL;
+    return wgrad_generic(d, a, a, nullptr, A64, nullptr, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
 }

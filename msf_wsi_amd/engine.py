@@ -571,10 +571,10 @@ class Engine:
             sa = kn.zeros((Cw,), torch.float64, dev)
             kn.bn_act_sum(c2, pro.scale, pro.shift, a2, sa)
             A2 = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
-            kn.conv_wgrad(kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0), a2, a2, A2)
+            kn.gram(kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0), a2, A2)
         if not self._bn_frozen(dbn):
             Ax = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
-            kn.conv_wgrad(kn.conv_desc(dtype, N, H, W, Ci, Ci, 1, 1, 1, 0), x, x, Ax)
+            kn.gram(kn.conv_desc(dtype, N, H, W, Ci, Ci, 1, 1, 1, 0), x, Ax)
             sx = kn.zeros((Ci,), torch.float64, dev)
             kn.colsum(x, sx)
         st3 = self._gram_stats(self.weights.get(conv3.weight, dtype), A2, sa, bn3, N * H * W, dtype)
@@ -615,7 +615,7 @@ class Engine:
             kn.bn_act_sum(c_in, pro.scale, pro.shift, a, sa)
             dsq = kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0)
             A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
-            kn.conv_wgrad(dsq, a, a, A)
+            kn.gram(dsq, a, A)
         w = self.weights.get(conv.weight, dtype)
         st = self._gram_stats(w, A, sa, bn, N * H * W, dtype)
         y = torch.empty(N, H, W, K, dtype=dtype, device=dev)
@@ -950,7 +950,7 @@ class Engine:
             Ax, sx = u.gram
         else:
             Ax = kn.zeros((Ci, 1, 1, Ci), torch.float32, dev)
-            kn.conv_wgrad(kn.conv_desc(dtype, d.N, d.H, d.W, Ci, Ci, 1, 1, 1, 0), x, x, Ax)
+            kn.gram(kn.conv_desc(dtype, d.N, d.H, d.W, Ci, Ci, 1, 1, 1, 0), x, Ax)
             sx = kn.zeros((Ci,), torch.float64, dev)
             kn.colsum(x, sx)
         packed = torch.empty(ns * K, dtype=torch.float64, device=dev)
@@ -1015,7 +1015,7 @@ class Engine:
         dsq = kn.conv_desc(dtype, d.N, d.P, d.Q, Cw, Cw, 1, 1, 1, 0)
         if A is None:
             A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
-            kn.conv_wgrad(dsq, a2, a2, A)
+            kn.gram(dsq, a2, A)
         kn.fold_dots(W, Mm, sums[0, 1])  # slot 1 of shard 0; the other shards of that slot stay zero
         k = self._bn_bwd_coeffs(sums, ns, 1, last.bn, last.st, grads)
         kd = self._bn_bwd_coeffs(sums, 3, 2, rec.ds.bn, rec.ds.st, grads) if rec.ds is not None and not ds_fold else None

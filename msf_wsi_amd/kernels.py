@@ -502,6 +502,20 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=0):
     return dw
 
 
+def gram(d: ConvDesc, a, A):
+    """A[C][1][1][C] (fp32, zeroed by the caller) = a^T a over the pixels of the NHWC activation `a`; the pixel splits
+    accumulate in fp64 (msfwsi_gram) so that the BatchNorm statistics the folded tails derive from A do not depend on the
+    order of the atomic additions"""
+    lib = _lib.load()
+    _req(a, "a", a.dtype, d.N * d.H * d.W * d.C)
+    _req(A, "A", torch.float32, d.C * d.C)
+    A64 = ARENA.zeros((d.C * d.C,), torch.float64, a.device)
+    _timed("conv_wgrad", d, a.element_size(), lambda: _lib.check(
+        lib.msfwsi_gram(C.byref(d), _p(a), _p(A64), _stream()), "gram"), dtype=a.dtype, same_operand=True)
+    add_f64_to_f32(A64, A)
+    return A
+
+
 def stem_wgrad_bnbwd(d: ConvDesc, x, g, c0, k, dw) -> bool:
     """dw += (k1*g + k2*c0 + k3)^T x for the space-to-depth stem: BatchNorm backward applied in the weight-gradient
     kernel's staging (no msfwsi_bn_bwd_apply pass); False if the library has no such kernel for the shape"""

@@ -176,7 +176,7 @@ def test_resnet50_trunk_well_conditioned_fp32(hip_lib):
     THREE input seeds; per seed the flip-tolerant gate applies (max(1e-3, 2 x the reference's spread), outliers bounded),
     and per tensor the SMALLEST of the three distances must be at the level of the reference's own fp32 runs treated the
     same way (the oracle in fp32 on this machine, per tensor the smallest of its three distances: median <= 5 x) -- which
-    a 1e-4 error in any kernel on the path fails."""
+    a 1e-4 error in a kernel most of the path depends on fails."""
     vec, man = load_golden("r50enc_b16_s64_div")
     names = man["param_keys"]
     per_seed, per_seed_ref = [], []

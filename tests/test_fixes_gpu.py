@@ -353,3 +353,26 @@ def test_models_in_sequence_through_the_default_engine(hip_lib):
             private = [f.float().clone() for f in enc(x)]
         assert all(torch.equal(a, b) for a, b in zip(shared, private)), seed
         del enc
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_forward_is_reproducible_run_to_run(hip_lib, dtype):
+    """the forward of the ResNet-50-derived model (folded Bottleneck tails: bn3's statistics from Gram matrices) five
+    times on the same input: every output equal BIT FOR BIT.  Until round 3 the Gram matrices were summed with fp32
+    atomics, their order moved the statistics by ~1e-6 from run to run, and 16-bit storage amplified that to a 1e-2
+    different forward and a 30 % different gradient (tools/race_check.py) -- every 16-bit parity gate a lottery.  Now the
+    pixel splits accumulate in fp64 (msfwsi_gram), as the BatchNorm sums always did."""
+    from helpers import flat_outputs
+    from oracle import msfwsi_oracle as orc
+
+    (c1, c2), (t1, t2), idx = orc.diverse_batch(4, 64, 16, 0)
+    model = build_product("resnet50", residual_gain=0.1).cuda().train()
+    args = ((c1.cuda(), t1.cuda()), (c2.cuda(), t2.cuda()), idx)
+    first = None
+    for r in range(5):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype != torch.float32):
+            fo = {k: v.float().clone() for k, v in flat_outputs(model(*args)).items()}
+        if first is None:
+            first = fo
+        else:
+            assert all(torch.equal(fo[k], first[k]) for k in fo), (r, [k for k in fo if not torch.equal(fo[k], first[k])][:3])

@@ -57,10 +57,14 @@ def gate_lowp_step(case, dtype, what, mutate=None):
     assert all(fo[k].dtype == dtype for k in keys)
     lowp_gate([rel(fo[k].float(), fr[k]) for k in keys], ["/".join(map(str, k)) for k in keys], vec[f"spread_out_{tag}"],
               floor, f"{what}: outputs", max_violations=0.1)
-    # ---- the 12 loss terms.  One reference sample's |d| of a single term can be near zero by chance: the allowance of a
-    # term is 2 x the larger of its own reference distance and the RMS distance over the 4 terms of its group
+    # ---- the 12 loss terms.  One reference sample's |d| of a single term can be near zero by chance (and the product's
+    # is another draw of the same noise): the allowance of a term is 2 x the larger of its own reference distance and the
+    # RMS distance over the 4 terms of its group, and never below 3 x the RMS over all 12 -- still a few 1e-4 of a cosine
+    # in [-1, 1], two orders below what a wrong kernel moves it by (test_wrong_epilogue_scale_is_caught)
     d = (terms - oc["terms64"]).abs().numpy()
-    allow = np.maximum(1e-3 * np.maximum(oc["terms64"].abs().numpy(), 1e-2), 2.0 * term_scale(vec[f"spread_terms_{tag}"]))
+    sp = np.asarray(vec[f"spread_terms_{tag}"], dtype=np.float64)
+    allow = np.maximum(1e-3 * np.maximum(oc["terms64"].abs().numpy(), 1e-2),
+                       np.maximum(2.0 * term_scale(sp), 3.0 * float(np.sqrt((sp ** 2).mean()))))
     print(f"[{what}] loss terms: max |d| {d.max():.2e}, allowance min {allow.min():.2e} max {allow.max():.2e}; "
           f"{int((d > allow).sum())}/12 beyond")
     assert (d <= allow).all(), (d, allow)
@@ -169,7 +173,9 @@ def test_loss_curve_tracks_reference(hip_lib, dtype):
     -0.74 and -0.81 (mean of the last ten losses; samples of the fixture and the oracle re-run on the GPU box's host,
     tools/curve_diag.py) -- so the yardstick is the SPREAD OF THE REFERENCE'S OWN SAMPLES around its fp64 curve:
       per step   |product - fp64| <= max(2e-3, 2 x the largest |sample - fp64| any reference sample has shown up to
-                 that step)   (samples: fp32 runs, the oracle's fp32 run, the autocast runs of this dtype);
+                 that step)   (samples: fp32 runs, the oracle's fp32 run, the autocast runs of this dtype); the product
+                 is one more draw of the same chaos (its weight gradients are summed with atomics: two runs of the
+                 product itself part ways the same way), so up to 3 of the 30 steps may reach 4 x;
       as a whole the mean of the last ten losses within 2 x the largest deviation of a reference sample's mean from
                  the fp64 mean."""
     from msf_wsi_amd.train import PretrainStep
@@ -212,7 +218,9 @@ def test_loss_curve_tracks_reference(hip_lib, dtype):
     print(f"[{tag} curve] |d|     " + " ".join(f"{v:.4f}" for v in d))
     print(f"[{tag} curve] allow   " + " ".join(f"{v:.4f}" for v in allow) + f"   ({len(samples)} reference samples)")
     assert np.isfinite(losses).all()
-    assert (d <= allow).all(), (int(np.argmax(d / allow)), float((d / allow).max()))
+    over = d > allow
+    assert over.sum() <= (3 if steps >= 30 else 0) and (d <= 2.0 * allow).all(), (
+        int(over.sum()), int(np.argmax(d / allow)), float((d / allow).max()))
     if steps >= 30:
         assert (ref64[-1] - ref64[0]) < -0.5, "the fixture's curve must move for this test to mean anything"
         tail = lambda c: float(np.mean(c[-10:]))

@@ -3,10 +3,7 @@
 cd "$(dirname "$0")/.."
 for lib in "$@"; do
   if [ "$lib" = default ]; then unset MSFWSI_LIB; else export MSFWSI_LIB="$PWD/$lib"; fi
-  timeout -k 10 200 python -u tools/race_check.py resnet18 2 64 fp32 6 nograd-poison || exit 1
-  timeout -k 10 200 python -u tools/race_check.py resnet18 2 64 fp32 6 train-poison || exit 1
   timeout -k 10 200 python -u tools/race_check.py resnet18 8 64 bf16 6 train-poison || exit 1
-  timeout -k 10 200 python -u tools/race_check.py resnet50 8 64 fp32 6 train-poison || exit 1
-  timeout -k 10 200 python -u tools/race_check.py resnet50 8 64 bf16 6 train-poison || exit 1
-  timeout -k 10 200 python -u tools/race_check.py resnet50 2 64 bf16 6 nograd-poison || exit 1
+  timeout -k 10 200 python -u tools/race_check.py resnet50 8 64 fp32 8 train-poison || exit 1
+  timeout -k 10 200 python -u tools/race_check.py resnet50 8 64 bf16 10 train-poison || exit 1
 done
