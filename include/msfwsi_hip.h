@@ -385,6 +385,26 @@ int msfwsi_dice_loss(int dtype, const void* logits, const long* target, long M, 
 int msfwsi_tile_views(const unsigned char* img, int B, int H, int W, int grid, const long* perm, const int* boxes,
                       const unsigned char* flips, const float* mean, const float* std_, float max_pixel, int S,
                       float* out, void* stream);
+/* The crop + bilinear resize of msfwsi_tile_views alone: out[b][k] (uint8 [S][S][3]) -- no flip, no Normalize.  The context
+ * view's colour augmentations sit between its crop and its flip (tools/ssl_train.py:176-196). */
+int msfwsi_tile_crops_u8(const unsigned char* img, int B, int H, int W, int grid, const long* perm, const int* boxes, int S,
+                         unsigned char* out, void* stream);
+/* ---- colour augmentations (row f3; PARITY UNPINNED: albumentations / cv2 arithmetic restated, see csrc/augment.hip) ----
+ * Images: uint8 [N][H][W][3] RGB.  The random decisions are the caller's (msf_wsi_amd/augment.py draws them).
+ * Replaces: albu.ColorJitter / ToGray / OneOf(GaussianBlur, Sharpen) of context_aug and target_aug,
+ * tools/ssl_train.py:176-201, applied by BcssPretrainDataset.__getitem__, src/utils/data/bcss.py:166-170.
+ *   msfwsi_gray_sum:     sums[n] += sum over the image of gray(pixel) (cv2 RGB2GRAY, 8-bit); sums ZEROED by the caller
+ *   msfwsi_color_stage:  one adjustment per image: op[n] in {0 none, 1 brightness, 2 contrast, 3 saturation, 4 hue,
+ *                        5 to-gray} with factor[n]; contrast reads gray_sum[n] (of the image as it enters this stage).
+ *                        in == out is allowed (pointwise).  ColorJitter = four stages in the image's random order.
+ *   msfwsi_blur_sharpen: kind[n] in {0 copy, 1 Gaussian blur with ksize[n] <= 31 taps, 2 Sharpen with a 3x3 matrix};
+ *                        taps [N][32] fp32 (the 1-D Gaussian taps, or the 3x3 matrix row-major); tmp fp32 [N][H][W][3]
+ *                        scratch; in != out; H, W >= 16. */
+int msfwsi_gray_sum(const unsigned char* img, int N, int H, int W, double* sums, void* stream);
+int msfwsi_color_stage(const unsigned char* in, unsigned char* out, int N, int H, int W, const int* op, const double* factor,
+                       const double* gray_sum, void* stream);
+int msfwsi_blur_sharpen(const unsigned char* in, unsigned char* out, float* tmp, int N, int H, int W, const int* kind,
+                        const int* ksize, const float* taps, void* stream);
 /* inv[r][perm[r][k]] = k: jigsaw_reverse_idx = argsort(jigsaw_idx) (src/utils/data/bcss.py:172) */
 int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* stream);
 

@@ -91,6 +91,10 @@ SIGNATURES = {
     "msfwsi_seg_scores": [_vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp],
     "msfwsi_seg_scores_imagewise": [_vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp],
     "msfwsi_tile_views": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp],
+    "msfwsi_tile_crops_u8": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
+    "msfwsi_gray_sum": [_vp, _i, _i, _i, _vp, _vp],
+    "msfwsi_color_stage": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "msfwsi_blur_sharpen": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "msfwsi_inverse_perm": [_vp, _vp, _l, _i, _vp],
     "msfwsi_set_tuning": [_i, _l],
     "msfwsi_conv3x3_supported": [_desc],

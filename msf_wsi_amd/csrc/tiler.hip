@@ -23,6 +23,7 @@ namespace {
 struct TilerParams {
     const unsigned char* img;  // [B][H][W][3] uint8
     float* out;                // [B][K][3][S][S] fp32
+    unsigned char* out_u8;     // instead: [B][K][S][S][3] uint8, the resized crop before flip / Normalize (msfwsi_tile_crops_u8)
     const long* perm;          // [B][K] block order (jigsaw_idx), nullable (identity)
     const int* boxes;          // [B][K][4] = x0, y0, w, h inside the block
     const unsigned char* flips;  // [B][K], nullable
@@ -60,6 +61,7 @@ __global__ void tiler_kernel(const TilerParams p) {
         const unsigned char* r0 = p.img + (((long)b * p.H + by + y0 + iy) * p.W + bx + x0) * 3;
         const unsigned char* r1 = p.img + (((long)b * p.H + by + y0 + iy1) * p.W + bx + x0) * 3;
         float* o = p.out + bk * 3 * p.S * p.S + (long)y * p.S + x;
+        unsigned char* o8 = p.out_u8 + ((bk * p.S + y) * p.S + x) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             // the blend in exact integers (like cv2's 8-bit path, which is fixed-point too):
@@ -71,6 +73,10 @@ __global__ void tiler_kernel(const TilerParams p) {
             long q = num / den;
             const long rem2 = 2 * (num - q * den);
             if (rem2 > den || (rem2 == den && (q & 1))) ++q;
+            if (p.out_u8 != nullptr) {
+                o8[c] = (unsigned char)q;
+                continue;
+            }
             const float v = (float)q;  // 0 .. 255: the reference's uint8 intermediate image
             o[(long)c * p.S * p.S] = __fmul_rn(__fsub_rn(v, p.mean255[c]), p.denom[c]);
         }
@@ -100,6 +106,22 @@ extern "C" int msfwsi_tile_views(const unsigned char* img, int B, int H, int W, 
         p.mean255[c] = mean[c] * max_pixel;
         p.denom[c] = 1.0f / (std_[c] * max_pixel);  // host code: IEEE fp32 division, as np.reciprocal(float32)
     }
+    p.B = B; p.H = H; p.W = W; p.K = grid * grid; p.grid = grid; p.bh = H / grid; p.bw = W / grid; p.S = S;
+    const long total = (long)B * p.K * S * S;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(tiler_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p);
+    return msfwsi_launch_status();
+}
+
+// the crop + resize alone, uint8 HWC out: the context view's colour augmentations sit between the crop and the flip
+// (tools/ssl_train.py:176-196: RandomResizedCrop, ColorJitter, ToGray, blur | sharpen, HorizontalFlip, Normalize)
+extern "C" int msfwsi_tile_crops_u8(const unsigned char* img, int B, int H, int W, int grid, const long* perm,
+                                    const int* boxes, int S, unsigned char* out, void* stream) {
+    MSFWSI_CHECK_ARG(img && boxes && out && B > 0 && H > 0 && W > 0 && grid > 0 && S > 0);
+    MSFWSI_CHECK_ARG(H % grid == 0 && W % grid == 0);
+    TilerParams p{};
+    p.img = img; p.out_u8 = out; p.perm = perm; p.boxes = boxes;
     p.B = B; p.H = H; p.W = W; p.K = grid * grid; p.grid = grid; p.bh = H / grid; p.bw = W / grid; p.S = S;
     const long total = (long)B * p.K * S * S;
     long blocks = (total + 255) / 256;

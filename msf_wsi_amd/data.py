@@ -9,9 +9,10 @@ produces, per 1024x1024 tile and per view, on DataLoader CPU workers:
 up to 34 crops per sample.  `DeviceTiler.batch` does the same on the GPU from the uint8 tiles: the random decisions are
 drawn on the host exactly where the reference draws them (torch.randperm for the jigsaw; albumentations'
 RandomResizedCrop box law for the crops), the pixels never leave HBM.  The colour augmentations (ColorJitter, ToGray,
-GaussianBlur / Sharpen, tools/ssl_train.py:176-201) are NOT part of this front end: they are albumentations arithmetic
-(package absent from this image, unpinned) and stay wherever the caller runs them (they commute with nothing here: feed
-already colour-augmented tiles, or raw tiles for a geometry-only pipeline).
+GaussianBlur / Sharpen, tools/ssl_train.py:176-201) are optional: `batch(..., color=DeviceColorAug())` runs them on
+the device where the reference's lists place them -- on the whole tile BEFORE the split for the target views
+(bcss.py:166-170), between the crop and the flip for the context views (msf_wsi_amd/augment.py; albumentations
+arithmetic restated, unpinned); without it feed already colour-augmented tiles.
 
 Output = exactly the batch contract the step consumes (tools/ssl_train.py:425-438):
     (ctx_v1, ctx_v2) fp32 [B,3,224,224], (tgt_v1, tgt_v2) fp32 [B*16,3,224,224] (flattened), [idx_v1, idx_v2] int64 [B,16]
@@ -77,8 +78,9 @@ class DeviceTiler:
                              flips.to(dev) if flips is not None else None, self.mean, self.std, self.size)
 
     def batch(self, ctx_tiles_u8: Sequence[torch.Tensor], tgt_tiles_u8: Sequence[torch.Tensor],
-              gen: Optional[torch.Generator] = None) -> Tuple[tuple, tuple, list]:
-        """ctx_tiles_u8[v], tgt_tiles_u8[v]: uint8 [B,H,W,3] device tensors of view v (already colour-augmented).
+              gen: Optional[torch.Generator] = None, color=None) -> Tuple[tuple, tuple, list]:
+        """ctx_tiles_u8[v], tgt_tiles_u8[v]: uint8 [B,H,W,3] device tensors of view v -- raw tiles with
+        color=augment.DeviceColorAug(), already colour-augmented ones without.
         Returns ((ctx_v1, ctx_v2), (tgt_v1, tgt_v2), [idx_v1, idx_v2]) as the step consumes them."""
         gen = gen or torch.Generator()
         ctx, tgt, idx = [], [], []
@@ -87,7 +89,15 @@ class DeviceTiler:
             perm = torch.stack([torch.randperm(self.K, generator=gen) for _ in range(B)])  # bcss.py:171
             cb, cf = self._decisions(B, 1, H, W, gen)
             tb, tf = self._decisions(B, self.K, H // self.grid, W // self.grid, gen)
-            ctx.append(self.view(ctx_tiles_u8[v], 1, None, cb, cf).flatten(0, 1))
-            tgt.append(self.view(tgt_tiles_u8[v], self.grid, perm, tb, tf).flatten(0, 1))
+            ctx_in, tgt_in = ctx_tiles_u8[v], tgt_tiles_u8[v]
+            if color is not None:
+                # target_aug on the whole tile, before blockshaped (bcss.py:166-170)
+                tgt_in = color.apply(tgt_in, color.decisions(B, gen))
+                # context_aug: RandomResizedCrop, then the colour list, then flip + Normalize (ssl_train.py:176-196)
+                crops = kn.tile_crops_u8(ctx_in, 1, None, cb.to(ctx_in.device), self.size).flatten(0, 1)
+                ctx_in = color.apply(crops, color.decisions(B, gen))
+                cb = torch.tensor([0, 0, self.size, self.size], dtype=torch.int32).repeat(B, 1, 1)  # exact copy
+            ctx.append(self.view(ctx_in, 1, None, cb, cf).flatten(0, 1))
+            tgt.append(self.view(tgt_in, self.grid, perm, tb, tf).flatten(0, 1))
             idx.append(kn.inverse_perm(perm.to(tgt_tiles_u8[v].device)))  # jigsaw_reverse_idx, bcss.py:172
         return tuple(ctx), tuple(tgt), idx

@@ -1152,6 +1152,62 @@ def tile_views(img, grid: int, perm, boxes, flips, mean, std, size: int = 224, m
     return out
 
 
+def tile_crops_u8(img, grid: int, perm, boxes, size: int = 224):
+    """img uint8 [B,H,W,3] -> uint8 [B, grid*grid, size, size, 3]: crop + bilinear resize of tile_views alone"""
+    lib = _lib.load()
+    B, H, W, ch = img.shape
+    K = grid * grid
+    _req(img, "img", torch.uint8, B * H * W * 3)
+    if ch != 3 or H % grid or W % grid:
+        raise ValueError(f"expected [B,H,W,3] with H, W divisible by {grid}, got {tuple(img.shape)}")
+    _req(boxes, "boxes", torch.int32, B * K * 4)
+    _opt(perm, "perm", torch.int64, B * K)
+    out = torch.empty(B, K, size, size, 3, dtype=torch.uint8, device=img.device)
+    _lib.check(lib.msfwsi_tile_crops_u8(_p(img), B, H, W, int(grid), _p(perm), _p(boxes), int(size), _p(out), _stream()),
+               "tile_crops_u8")
+    return out
+
+
+def gray_sum(img):
+    """img uint8 [N,H,W,3] -> fp64 [N]: sum of the 8-bit gray value over each image"""
+    lib = _lib.load()
+    N, H, W, ch = img.shape
+    _req(img, "img", torch.uint8, N * H * W * 3)
+    sums = torch.zeros(N, dtype=torch.float64, device=img.device)
+    _lib.check(lib.msfwsi_gray_sum(_p(img), N, H, W, _p(sums), _stream()), "gray_sum")
+    return sums
+
+
+def color_stage(img, op, factor, gray_sums=None, out=None):
+    """one colour adjustment per image (op int32 [N], factor fp64 [N]); in place unless `out` is given"""
+    lib = _lib.load()
+    N, H, W, ch = img.shape
+    _req(img, "img", torch.uint8, N * H * W * 3)
+    _req(op, "op", torch.int32, N)
+    _opt(factor, "factor", torch.float64, N)
+    _opt(gray_sums, "gray_sums", torch.float64, N)
+    out = img if out is None else out
+    _req(out, "out", torch.uint8, N * H * W * 3)
+    _lib.check(lib.msfwsi_color_stage(_p(img), _p(out), N, H, W, _p(op), _p(factor), _p(gray_sums), _stream()),
+               "color_stage")
+    return out
+
+
+def blur_sharpen(img, kind, ksize, taps):
+    """kind int32 [N] (0 copy, 1 Gaussian blur, 2 sharpen), ksize int32 [N], taps fp32 [N,32] -> new uint8 image"""
+    lib = _lib.load()
+    N, H, W, ch = img.shape
+    _req(img, "img", torch.uint8, N * H * W * 3)
+    _req(kind, "kind", torch.int32, N)
+    _req(ksize, "ksize", torch.int32, N)
+    _req(taps, "taps", torch.float32, N * 32)
+    out = torch.empty_like(img)
+    tmp = torch.empty(N, H, W, 3, dtype=torch.float32, device=img.device)
+    _lib.check(lib.msfwsi_blur_sharpen(_p(img), _p(out), _p(tmp), N, H, W, _p(kind), _p(ksize), _p(taps), _stream()),
+               "blur_sharpen")
+    return out
+
+
 def inverse_perm(perm):
     """argsort of each row of a permutation matrix int64 [rows, K]"""
     lib = _lib.load()
