@@ -515,10 +515,14 @@ def main():
                     f.write(f"{kind}\t{1e3 * sec / nst:.3f}\t{n / nst:.1f}\t{fl / sec / 1e12:.1f}\t{by / sec / 1e9:.0f}\t"
                             f"{shape}\t{sym if kind != 'stream' else ''}\n")
         if timer is not None:
-            step_bytes = (ACT_BYTES_PER_PAIR_16BIT.get(args.arch, 0) * (2 if args.dtype == "fp32" else 1) * args.batch
+            area = (args.size / 224.0) ** 2  # SURVEY 8(d)'s per-pair figures are for 224 x 224 tiles
+            step_bytes = (ACT_BYTES_PER_PAIR_16BIT.get(args.arch, 0) * (2 if args.dtype == "fp32" else 1) * args.batch * area
                           + ADAM_BYTES_PER_STEP.get(args.arch, 0))
+            # the committed counter summary is of ONE workload (config 2 as the default command runs it): replayed
+            # only beside that workload, never beside another architecture / batch / tile size / dtype
+            profiled = (args.arch, args.batch, args.size, args.dtype) == ("resnet50", 256, 224, "bf16")
             out["roofline"] = build_roofline(timer, args, dt, timed_from, step_bytes,
-                                             FLOP_PER_PAIR.get(args.arch, 0) * args.batch)
+                                             FLOP_PER_PAIR.get(args.arch, 0) * args.batch * area, use_pmc=profiled)
         if world == 1 and not args.no_cpu_baseline:
             del ts, model, batch
             torch.cuda.empty_cache()
