@@ -29,6 +29,9 @@
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
+#ifndef MSFWSI_STAGGER
+#define MSFWSI_STAGGER 0  // 1: the second half of a workgroup's waves (the SIMD partners of the first half) issue the DMA requests AFTER their MFMAs
+#endif
 #ifndef MSFWSI_FETCH_FIRST
 #define MSFWSI_FETCH_FIRST 1  // DMA requests of slab kt+2 before the MFMAs of slab kt (0: after them; A/B: make EXTRA=-DMSFWSI_FETCH_FIRST=0)
 #endif
@@ -1046,7 +1049,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         // transposed reads draining the pipeline every slab (common.h, lds_dma16_buf): a request issued before the MFMAs
         // then only delayed them.  With the requests in inline asm two slabs really are in flight, and requests first is
         // the faster order again (whole step 547.5 -> 545.3 ms, A/B on one box, two rounds).
-#if MSFWSI_FETCH_FIRST
+#if MSFWSI_STAGGER
+        // waves w and w + NW/2 share a SIMD and would run in lockstep (same program, one barrier per slab): the first half
+        // requests before its MFMAs, the second half after -- one partner's request stalls beside the other's MFMAs
+        const bool late = wave >= (Cfg::NW / 2);
+        if (!late && kt + 2 < nk) fetch(st_f);
+        compute(st_c);
+        if (late && kt + 2 < nk) fetch(st_f);
+#elif MSFWSI_FETCH_FIRST
         if (kt + 2 < nk) fetch(st_f);
         compute(st_c);
 #else

@@ -17,6 +17,9 @@
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
+#ifndef MSFWSI_STAGGER
+#define MSFWSI_STAGGER 0
+#endif
 #ifndef MSFWSI_WGRAD_BIG_WAVES
 #define MSFWSI_WGRAD_BIG_WAVES 16  // waves of the 256 x 256 tile (8: 128 x 64 per wave, 16: 64 x 64)
 #endif
@@ -376,7 +379,12 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
             // DMA requests of slab kt+NST-1 (its stage was read in kt-1, every wave is past this iteration's barrier) and the
             // MFMAs of slab kt: requests first since the DMA is issued from inline asm (see igemm.hip's main loop and
             // common.h lds_dma16_buf; round 2's "MFMAs first" belonged to the drained pipeline)
-#if MSFWSI_FETCH_FIRST
+#if MSFWSI_STAGGER
+            const bool late = wave >= (Cfg::NW / 2);  // see igemm.hip: SIMD partners alternate request / MFMA phases
+            if (!late && kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
+            compute(st_c);
+            if (late && kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
+#elif MSFWSI_FETCH_FIRST
             if (kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
             compute(st_c);
 #else
