@@ -29,6 +29,9 @@
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
+#ifndef MSFWSI_SETPRIO
+#define MSFWSI_SETPRIO 0
+#endif
 #ifndef MSFWSI_STAGGER
 #define MSFWSI_STAGGER 0  // 1: the second half of a workgroup's waves (the SIMD partners of the first half) issue the DMA requests AFTER their MFMAs
 #endif
@@ -1018,10 +1021,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                     wf[tn] = t;
                 }
             }
+#if MSFWSI_SETPRIO
+            __builtin_amdgcn_s_setprio(1);  // T5 of the HIP guide: keeps hipcc from spreading the MFMA cluster (A/B: no gain here)
+#endif
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) mma_step<T>(acc[tn][tm], wf[tn], xf[tm]);
+#if MSFWSI_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     };
 
