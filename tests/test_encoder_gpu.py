@@ -221,3 +221,39 @@ def test_resnet50_trunk_well_conditioned_lowp(hip_lib, dtype):
     print(f"[trunk {tag}] features rel {fr}, reference under autocast {vec[f'spread_feat_{tag}']}")
     assert (fr <= np.maximum(LOWP_FLOOR[dtype], 2.0 * vec[f"spread_feat_{tag}"])).all(), fr
     lowp_gate(rels, names, vec[f"spread_grad_{tag}"], LOWP_FLOOR[dtype], f"resnet50 trunk {tag}: gradients")
+
+
+@pytest.mark.parametrize("arch,hw", [("resnet50", (75, 67)), ("resnet18", (75, 67)), ("resnet50", (33, 64))],
+                         ids=["r50-75x67", "r18-75x67", "r50-33x64"])
+def test_trunk_on_odd_and_non_square_inputs(hip_lib, arch, hw):
+    """ragged geometry through the whole trunk: odd, non-square images (the space-to-depth stem does not apply, every
+    strided layer sees odd extents, the deepest maps are 3x3 / 2x2 pixels) -- features and every gradient against the fp64
+    oracle with the fp32 tolerance of the parity tests (max(1e-3, 2 x the oracle's own fp32<->fp64 spread), outliers
+    bounded), fp32"""
+    from helpers import spread_gate
+    from msf_wsi_amd.models import resnet
+    from oracle import msfwsi_oracle as orc
+
+    H, W = hw
+    torch.manual_seed(MODEL_SEED)
+    enc = resnet.__dict__[arch](zero_init_residual=False, return_features=True)
+    enc.fc = torch.nn.Identity()
+    last = ".bn3.weight" if arch == "resnet50" else ".bn2.weight"
+    with torch.no_grad():
+        for k, v in enc.state_dict().items():
+            if k.startswith("layer") and k.endswith(last):
+                v.mul_(0.1)  # trained-like residual gains (tests/golden/make_golden.py RESIDUAL_GAIN)
+    sd0 = {k: v.detach().clone() for k, v in enc.state_dict().items() if not k.startswith("fc.")}
+    x = orc.diverse_images(8, 96, 3)[:, :, :H, :W].contiguous()
+    dims = (256, 512, 1024, 2048) if arch == "resnet50" else (64, 128, 256, 512)
+    g = torch.Generator().manual_seed(3)
+    Rs = [torch.randn(8, d, generator=g) for d in dims]
+    f64, g64 = _trunk_oracle(sd0, x, Rs)
+    _, g32 = _trunk_oracle(sd0, x, Rs, torch.float32)
+    feats, grads = _trunk_product(enc, x, Rs, torch.float32)
+    fr = np.array([rel(f.float(), r) for f, r in zip(feats, f64)])
+    assert fr.max() < 1e-3, fr
+    names = [k for k in g64 if g64[k] is not None]
+    rels = np.array([rel(grads[k], g64[k]) for k in names])
+    box = np.array([rel(g32[k], g64[k]) for k in names])
+    spread_gate(rels, names, [box], f"{arch} trunk on {H}x{W} images, fp32 gradients")
