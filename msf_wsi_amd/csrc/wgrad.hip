@@ -691,6 +691,10 @@ int launch_wgrad_os(const msfwsi_conv_desc* d, const void* x, const void* dy, fl
 }
 
 long g_wgrad_lin = 1;  // msfwsi_set_tuning(2, .): 0 = always the generic staging
+// msfwsi_set_tuning(15, .): cap on the pixel splits of the gather weight-gradient kernel (0 = none).  With 1 every
+// gradient tile is summed by ONE workgroup in pixel order: the step is then reproducible bit for bit (the splits add
+// their partial sums with fp32 atomics in arrival order, 4e-7 jitter per tensor) -- what a chaotic 30-step test needs
+long g_wgrad_max_splits = 0;
 long g_wgrad_big = 1;  // msfwsi_set_tuning(6, .): 0 = never the 256 x 256 tile
 
 // workgroups of `kern` that fit the device at once (all splits carry equal work, so a grid that overshoots this by
@@ -748,6 +752,7 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
     }
     const long max_splits = (prm.M + Cfg::BKM - 1) / Cfg::BKM;
     if (splits > max_splits) splits = max_splits;
+    if (g_wgrad_max_splits > 0 && splits > g_wgrad_max_splits) splits = g_wgrad_max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     long rows = (prm.M + splits - 1) / splits;
@@ -773,6 +778,7 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v) { g_wgrad_lin = v; }
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_max_splits(long v) { g_wgrad_max_splits = v; }
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long v) { g_wgrad_big = v; }
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os(long v) { g_wgrad_os = v; }
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(long v) { g_wgrad_os_min_pos = v; }
