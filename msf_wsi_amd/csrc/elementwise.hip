@@ -977,16 +977,27 @@ __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __
     const int kb = blockIdx.y * kFoldRows;
     const int ke = kb + kFoldRows < K ? kb + kFoldRows : K;
     const float s = (float)sa[c];
-    float bacc = 0.f;
     for (int k = kb; k < ke; ++k) {
         const long o = (long)k * C + c;
         const float w = W[o], a = k1[k], b = k2[k], d = k3[k];
         atomicAdd(dW + o, fmaf(a, Mm[o], fmaf(b, WA[o], d * s)));  // shared with the other view's stream
         Wk1[o] = a * w;
         Wk2[o] = b * w;
-        bacc = fmaf(d, w, bacc);
     }
-    atomicAdd(bvec + c, bacc);
+    // bvec[c] += sum_k k3[k] W[k][c]: the first row block walks the whole column in row order (one addition per
+    // element and launch: the same value on every run; per-block partial sums added atomically came in arrival order)
+    if (blockIdx.y == 0) {
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {
+            b0 = fmaf(k3[k], W[(long)k * C + c], b0);
+            b1 = fmaf(k3[k + 1], W[(long)(k + 1) * C + c], b1);
+            b2 = fmaf(k3[k + 2], W[(long)(k + 2) * C + c], b2);
+            b3 = fmaf(k3[k + 3], W[(long)(k + 3) * C + c], b3);
+        }
+        for (; k < K; ++k) b0 = fmaf(k3[k], W[(long)k * C + c], b0);
+        bvec[c] += (b0 + b1) + (b2 + b3);
+    }
 }
 
 __global__ void add_f64_kernel(const double* __restrict__ in, double* out, int n) {

@@ -6,7 +6,7 @@ import torch
 
 from helpers import MODEL_SEED, load_golden, rel, spread_gate
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reproducible_sums")]
 
 
 def test_resnet50_trunk_matches_reference(hip_lib):

@@ -16,7 +16,7 @@ import torch
 from helpers import (LOWP_FLOOR, LOWP_TAG, LR, build_case, case_batch, flat_outputs, load_golden, lowp_gate,
                      oracle_case, reference_loop_loss, rel)
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reproducible_sums")]
 FP16_LOSS_SCALE = 1024.0  # the fixed power of two the fixture's fp16 reference run used
 
 
@@ -208,17 +208,11 @@ def test_loss_curve_tracks_reference(hip_lib, dtype):
     ts = PretrainStep(model, lr=LR, global_batch=B, dtype=dtype,
                       init_scale=65536.0 if dtype == torch.bfloat16 else man["fp16_loss_scale"])
     losses = []
-    # The weight gradients' pixel splits add their partial sums with fp32 atomics in arrival order (4e-7 per tensor between
-    # two runs); 30 chaotic steps turn that into a visibly different curve, i.e. a test whose outcome varies from run to
-    # run.  msfwsi_set_tuning(15, 1): one workgroup per gradient tile, fixed summation order -- measured with
-    # tools/race_check.py: every gradient of this model then repeats bit for bit, so this test has ONE outcome per build.
-    hip_lib.msfwsi_set_tuning(15, 1)
-    try:
-        for t in range(steps):
-            (c1, c2), (t1, t2), idx = orc.diverse_batch(B, size, 16, man["curve_seed0"] + t)
-            losses.append(ts.step(((c1.cuda(), c2.cuda()), (t1.cuda(), t2.cuda()), idx)))
-    finally:
-        hip_lib.msfwsi_set_tuning(15, 0)
+    # (reproducible_sums: one workgroup per weight-gradient tile -- 30 chaotic steps would turn the default's 4e-7 atomics
+    #  jitter into a visibly different curve from run to run; with it this test has ONE outcome per build)
+    for t in range(steps):
+        (c1, c2), (t1, t2), idx = orc.diverse_batch(B, size, 16, man["curve_seed0"] + t)
+        losses.append(ts.step(((c1.cuda(), c2.cuda()), (t1.cuda(), t2.cuda()), idx)))
     losses = torch.stack(losses).cpu().numpy().ravel()
     d = np.abs(losses - ref64)
     print(f"[{tag} curve] product " + " ".join(f"{v:.4f}" for v in losses))

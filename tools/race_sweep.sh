@@ -8,4 +8,5 @@ for lib in "$@"; do
   timeout -k 10 200 python -u tools/race_check.py resnet50 8 64 bf16 10 train-poison || exit 1
   MSFWSI_WGRAD_MAX_SPLITS=1 timeout -k 10 200 python -u tools/race_check.py resnet18 16 64 bf16 8 train || exit 1
   MSFWSI_WGRAD_MAX_SPLITS=1 timeout -k 10 200 python -u tools/race_check.py resnet50 8 64 bf16 8 train || exit 1
+  MSFWSI_WGRAD_MAX_SPLITS=1 timeout -k 10 200 python -u tools/race_check.py resnet50 8 64 fp32 8 train || exit 1
 done
