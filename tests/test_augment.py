@@ -61,6 +61,32 @@ def test_oracle_known_answers():
     assert tv(ao.gaussian_blur(img, 19, 2.0)) < 0.5 * tv(img) < tv(ao.sharpen(img, 0.5, 1.0))
 
 
+def test_decision_law_matches_the_reference_lists():
+    """DeviceColorAug.decisions (host, no GPU): the rates and ranges of tools/ssl_train.py:176-201 -- ColorJitter(0.4, 0.4,
+    0.4, 0.1, p=0.8) with a random order of its four adjustments, ToGray(p=0.2), OneOf([GaussianBlur([19,23], [0.1,2.0]),
+    Sharpen()], p=0.5) -- and albumentations' kernel-size rule (randrange(19, 24); an even draw k becomes (k+1) % 24)"""
+    from msf_wsi_amd.augment import DeviceColorAug, gaussian_taps, sharpen_matrix
+    from oracle import augment_oracle as ao
+
+    big = DeviceColorAug().decisions(40000, torch.Generator().manual_seed(1))
+    near = lambda x, p: abs(float(x.float().mean()) - p) < 0.01
+    assert near(big.jitter, 0.8) and near(big.gray, 0.2) and near(big.filt == 1, 0.25) and near(big.filt == 2, 0.25)
+    assert near(big.ksize == 19, 0.2) and near(big.ksize == 21, 0.4) and near(big.ksize == 23, 0.4)
+    for op, (lo, hi) in ((1, (0.6, 1.4)), (2, (0.6, 1.4)), (3, (0.6, 1.4)), (4, (-0.1, 0.1))):
+        f = big.factors[:, op]
+        assert float(f.min()) >= lo and float(f.max()) <= hi and abs(float(f.mean()) - (lo + hi) / 2) < 0.01
+    assert float(big.sigma.min()) >= 0.1 and float(big.sigma.max()) <= 2.0
+    assert float(big.alpha.min()) >= 0.2 and float(big.alpha.max()) <= 0.5
+    assert float(big.lightness.min()) >= 0.5 and float(big.lightness.max()) <= 1.0
+    assert all(sorted(o) == [1, 2, 3, 4] for o in big.order[:200].tolist())
+    firsts = torch.bincount(big.order[:, 0].long(), minlength=5)[1:].float() / big.order.shape[0]
+    assert float((firsts - 0.25).abs().max()) < 0.01  # every adjustment leads a quarter of the orders
+    # the host-side tap tables are the oracle's, bit for bit
+    for ks, sg in ((19, 0.1), (21, 1.0), (23, 2.0)):
+        assert np.array_equal(gaussian_taps(ks, sg).numpy(), ao.gaussian_taps(ks, sg))
+    assert np.array_equal(sharpen_matrix(0.37, 0.81).numpy(), ao.sharpen_matrix(0.37, 0.81))
+
+
 def _decisions_for_oracle(dec, n):
     from oracle import augment_oracle as ao
 
