@@ -469,7 +469,7 @@ def main():
 
     for _ in range(args.warmup):
         ts.step(batch)
-    timer = None if args.no_kernel_timer else kn.KernelTimer(streams=args.layer_report is not None)
+    timer = None if args.no_kernel_timer else kn.KernelTimer(streams=True)
     sync()
     # the per-launch HIP events cost ~1 % of the step: bracket the launches of the LAST two timed steps only
     timed_from = max(0, args.steps - 2)

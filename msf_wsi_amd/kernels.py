@@ -155,6 +155,12 @@ class KernelTimer:
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += fl
             a[3] += by
+        if not by_symbol and self.stream_records:  # the HBM-bound elementwise kernels as one family (streams=True)
+            a = agg.setdefault("stream", [0, 0.0, 0.0, 0.0, "stream"])
+            for _name, by, e0, e1 in self.stream_records:
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1) * 1e-3
+                a[3] += by
         return {k: {"launches": v[0], "seconds": v[1], "flops": v[2], "bytes": v[3], "family": v[4]}
                 for k, v in agg.items()}
 
@@ -239,7 +245,7 @@ def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = 
 
 
 def _stream_timed(name: str, nbytes: float, fn):
-    """the HBM-bound elementwise kernels, timed only for the layer report (KernelTimer(streams=True))"""
+    """the HBM-bound elementwise kernels (KernelTimer(streams=True): the layer report and the `stream` family of the bench line)"""
     if TIMER is None or TIMER.stream_records is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
