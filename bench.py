@@ -471,8 +471,10 @@ def main():
         ts.step(batch)
     timer = None if args.no_kernel_timer else kn.KernelTimer(streams=True)
     sync()
-    # the per-launch HIP events cost ~1 % of the step: bracket the launches of the LAST two timed steps only
-    timed_from = max(0, args.steps - 2)
+    # the per-launch HIP events (two per launch, dense and streaming kernels: ~7 500 per step) cost ~3 % of a step they
+    # bracket (measured: 545.2 -> 550.8 ms/step averaged over six steps with two of them bracketed): they are recorded
+    # on the LAST timed step only
+    timed_from = max(0, args.steps - 1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         kn.TIMER = timer if i >= timed_from else None

@@ -237,7 +237,7 @@ int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW, int C, vo
 /* BatchNorm backward folded into the weights of the 1x1 conv W[K][C] that produced the BatchNorm input
  * (Bottleneck conv3 -> bn3, src/models/resnet.py:115-117, backward by autograd in the reference): with c = W a,
  *   fold_dots:    out[k] = sum_c W[k][c]*M[k][c]  (= sum over pixels of g*c, M = g^T a from msfwsi_conv_wgrad)
- *   fold_weights: dW += k1 o M + k2 o WA + k3 (x) sa;  Wk1 = k1 o W;  Wk2 = k2 o W;  bvec[c] += sum_k k3[k] W[k][c]
+ *   fold_weights: dW += k1 o M + k2 o WA + k3 (x) sa;  Wk1 = k1 o W;  Wk2 = k2 o W;  bvec[c] (fp64) += sum_k k3[k] W[k][c]
  * (WA = W (a^T a), sa = column sums of a, k1..k3 from msfwsi_bn_bwd_finalize).  All fp32 / fp64. */
 int msfwsi_fold_dots(const float* W, const float* M, double* out, int K, int C, void* stream);
 /* out[k] = [s1[k]*W1[k][0:C1] | s2[k]*W2[k][0:C2]] (fp32 [K][C1+C2]), shift[k] = b1[k] + b2[k]: two BatchNorm
@@ -249,7 +249,7 @@ int msfwsi_row_scale_cat(const float* W1, const float* s1, int C1, const float* 
  * conv once with the BatchNorm apply + residual + ReLU in its epilogue (msfwsi_conv_fwd_post). */
 int msfwsi_fold_matvec(const float* W, const double* v, double* out, int K, int C, void* stream);
 int msfwsi_fold_weights(const float* W, const float* M, const float* WA, const float* k1, const float* k2,
-                        const float* k3, const double* sa, float* dW, float* Wk1, float* Wk2, float* bvec, int K, int C,
+                        const float* k3, const double* sa, float* dW, float* Wk1, float* Wk2, double* bvec, int K, int C,
                         void* stream);
 
 /* column sums of x[M][C] added into sums[shard][C] (fp64, nshard replicas against same-address atomic contention)

@@ -971,7 +971,7 @@ __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __
                                     const float* __restrict__ WA, const float* __restrict__ k1,
                                     const float* __restrict__ k2, const float* __restrict__ k3,
                                     const double* __restrict__ sa, float* __restrict__ dW, float* __restrict__ Wk1,
-                                    float* __restrict__ Wk2, float* bvec, int K, int C) {
+                                    float* __restrict__ Wk2, double* bvec64, int K, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int kb = blockIdx.y * kFoldRows;
@@ -984,20 +984,13 @@ __global__ void fold_weights_kernel(const float* __restrict__ W, const float* __
         Wk1[o] = a * w;
         Wk2[o] = b * w;
     }
-    // bvec[c] += sum_k k3[k] W[k][c]: the first row block walks the whole column in row order (one addition per
-    // element and launch: the same value on every run; per-block partial sums added atomically came in arrival order)
-    if (blockIdx.y == 0) {
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= K; k += 4) {
-            b0 = fmaf(k3[k], W[(long)k * C + c], b0);
-            b1 = fmaf(k3[k + 1], W[(long)(k + 1) * C + c], b1);
-            b2 = fmaf(k3[k + 2], W[(long)(k + 2) * C + c], b2);
-            b3 = fmaf(k3[k + 3], W[(long)(k + 3) * C + c], b3);
-        }
-        for (; k < K; ++k) b0 = fmaf(k3[k], W[(long)k * C + c], b0);
-        bvec[c] += (b0 + b1) + (b2 + b3);
-    }
+    // bvec64[c] += sum_k k3[k] W[k][c]: this block's 16 rows in row order (fp32, fixed), the blocks' partial sums added in
+    // fp64 -- their arrival order then moves the sum by ~1e-16, invisible once the caller rounds it to fp32
+    // (msfwsi_add_f64_to_f32), where fp32 atomics moved the folded backward's bias by 1e-7 from run to run.  (One block
+    // walking the whole column in a fixed order was measured 2.7 ms/step slower: 2048 dependent loads in one wave.)
+    float bacc = 0.f;
+    for (int k = kb; k < ke; ++k) bacc = fmaf(k3[k], W[(long)k * C + c], bacc);
+    atomicAdd(bvec64 + c, (double)bacc);
 }
 
 __global__ void add_f64_kernel(const double* __restrict__ in, double* out, int n) {
@@ -1346,7 +1339,7 @@ extern "C" int msfwsi_row_scale_cat(const float* W1, const float* s1, int C1, co
 }
 
 extern "C" int msfwsi_fold_weights(const float* W, const float* M, const float* WA, const float* k1, const float* k2,
-                                   const float* k3, const double* sa, float* dW, float* Wk1, float* Wk2, float* bvec,
+                                   const float* k3, const double* sa, float* dW, float* Wk1, float* Wk2, double* bvec,
                                    int K, int C, void* stream) {
     MSFWSI_CHECK_ARG(W && M && WA && k1 && k2 && k3 && sa && dW && Wk1 && Wk2 && bvec && K > 0 && C > 0);
     hipLaunchKernelGGL(fold_weights_kernel, dim3((C + 63) / 64, (K + kFoldRows - 1) / kFoldRows), dim3(64), 0,

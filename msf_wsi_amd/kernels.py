@@ -802,7 +802,8 @@ def fold_dots(W, Mm, out):
 
 
 def fold_weights(W, Mm, WA, k1, k2, k3, sa, dW, Wk1, Wk2, bvec):
-    """dW += k1 o Mm + k2 o WA + k3 (x) sa;  Wk1 = k1 o W;  Wk2 = k2 o W;  bvec += W^T k3"""
+    """dW += k1 o Mm + k2 o WA + k3 (x) sa;  Wk1 = k1 o W;  Wk2 = k2 o W;  bvec (fp32, zeroed by the caller) += W^T k3,
+    accumulated in fp64 (the order of the row blocks' atomic additions then does not show in the fp32 result)"""
     lib = _lib.load()
     K = k1.numel()
     Cn = W.numel() // K
@@ -812,8 +813,10 @@ def fold_weights(W, Mm, WA, k1, k2, k3, sa, dW, Wk1, Wk2, bvec):
         _req(t, nm, torch.float32, K)
     _req(sa, "sa", torch.float64, Cn)
     _req(bvec, "bvec", torch.float32, Cn)
+    b64 = ARENA.zeros((Cn,), torch.float64, bvec.device)
     _lib.check(lib.msfwsi_fold_weights(_p(W), _p(Mm), _p(WA), _p(k1), _p(k2), _p(k3), _p(sa), _p(dW), _p(Wk1), _p(Wk2),
-                                       _p(bvec), K, Cn, _stream()), "fold_weights")
+                                       _p(b64), K, Cn, _stream()), "fold_weights")
+    add_f64_to_f32(b64, bvec)
 
 
 def colsum(x, sums):
