@@ -125,7 +125,9 @@ def _oracle_steps(arch, B, size, n_timed, budget_s):
 def cpu_baseline(arch, size, budget_s, threads):
     """SURVEY.md 8(d) / BASELINE.md 3: the oracle (a port of the reference step, verified against the real reference)
     on BASELINE config 1 EXACTLY -- ResNet-18 dual-stream, 8 tile pairs of 224x224, fp32 -- 1 warm-up + 3 timed steps
-    on the host's physical cores.  `extra` carries one step of the bench's own architecture at 2 tile pairs, labelled."""
+    on the CPUs the process may use (`cores` = the torch threads actually used = min(affinity, cgroup CPU quota): a GPU
+    box of this pool shows 256 logical CPUs but grants 16; the round-3 figure ran 128 throttled threads and was 3-5x
+    too slow).  `extra` carries one step of the bench's own architecture at 2 tile pairs, labelled."""
     torch.set_num_threads(threads)
     val, n = _oracle_steps("resnet18", 8, 224, 3, max(budget_s, 60.0))
     out = {"value": round(val, 4), "unit": "tile-pairs/s", "cores": threads, "kind": "port",
@@ -199,18 +201,20 @@ def build_roofline(timer, args, dt, timed_from, step_bytes, step_flop, use_pmc=T
     return roof
 
 
-def stock_gpu_baseline(arch, size, B, steps=2):
+def stock_gpu_baseline(arch, size, B, steps=5, warmups=3):
     """A same-box yardstick beside cpu_baseline: the ORACLE (plain functional PyTorch: F.conv2d / F.batch_norm / F.linear,
     torch autograd, its own Adam) run on cuda:0 by stock PyTorch-ROCm eager -- MIOpen / hipBLASLt kernels under
     torch.autocast("cuda", bfloat16) -- at the largest batch that fits eager autograd's activation memory (stated).
-    Not the target and not the product: the product path never touches it."""
+    Protocol: MIOpen in its DEFAULT find mode with workspace (round 3 forced MIOPEN_FIND_MODE=FAST
+    and timed 2 steps after 1 warm-up: that measured MIOpen's zero-workspace fallback kernels, 5 TFLOP/s), 3 warm-up
+    steps (kernel search, allocator), 5 timed steps.  OPT-IN (--stock-batch N): the kernel search of the warm-up takes
+    minutes.  Not the target and not the product: the product path never touches it."""
     import gc
 
     from oracle import msfwsi_oracle as orc
     from msf_wsi_amd.models import resnet as R
     from msf_wsi_amd.models.backbone import MSFWSI
 
-    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # no exhaustive kernel search on a fresh box
     dev = torch.device("cuda", torch.cuda.current_device())
     hub_stub()
     torch.manual_seed(3407)
@@ -223,7 +227,8 @@ def stock_gpu_baseline(arch, size, B, steps=2):
     lr = orc.init_lr(1e-3, B)
     opt = orc.Adam(sd, [lr, lr, lr])
     torch.cuda.reset_peak_memory_stats()
-    orc.train_step(sd, batch, opt, autocast_dtype=torch.bfloat16)  # warm-up: MIOpen kernel selection, allocator
+    for _ in range(warmups):  # MIOpen kernel search (default find mode), hipBLASLt heuristics, allocator
+        orc.train_step(sd, batch, opt, autocast_dtype=torch.bfloat16)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -232,7 +237,8 @@ def stock_gpu_baseline(arch, size, B, steps=2):
     dt = time.perf_counter() - t0
     return {"value": round(B * steps / dt, 3), "unit": "tile-pairs/s", "ms_per_step": round(1e3 * dt / steps, 1),
             "batch": B, "kind": "oracle on cuda (PyTorch-ROCm eager: MIOpen / hipBLASLt, bf16 autocast)",
-            "sample": f"{steps} timed step(s) after 1 warm-up, {arch}, {B} tile pairs of {size}x{size} (eager autograd "
+            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE", "default"),
+            "sample": f"{steps} timed step(s) after {warmups} warm-ups, {arch}, {B} tile pairs of {size}x{size} (eager autograd "
                       f"keeps every activation: the bench batch of the product does not fit)",
             "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "torch": torch.__version__}
 
@@ -338,11 +344,9 @@ def run_finetune(args, world, rank, dev, dtype):
     if world == 1 and not args.no_cpu_baseline:
         del ts, model
         torch.cuda.empty_cache()
-        threads = max(1, (os.cpu_count() or 2) // 2)
-        try:
-            threads = min(threads, len(os.sched_getaffinity(0)))
-        except AttributeError:
-            pass
+        from oracle.hostcpu import usable_cpus
+
+        threads = usable_cpus()
         out["cpu_baseline"] = finetune_cpu_baseline(args.arch, args.classes, S, threads, args.cpu_budget)
     print(json.dumps(out), flush=True)
 
@@ -385,8 +389,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="storage / MFMA input type (bf16: BASELINE config 2; fp16: the reference's default --amp dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stock-batch", type=int, default=32,
-                    help="tile pairs of the stock-PyTorch GPU yardstick (0 = skip it); it runs with the CPU baseline")
+    ap.add_argument("--stock-batch", type=int, default=0,
+                    help="tile pairs of the stock-PyTorch GPU yardstick (0 = skip it, the default: its MIOpen kernel search "
+                         "takes minutes; 32 fits eager autograd's memory); it runs with the CPU baseline")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--layer-report", default=None,
@@ -528,11 +533,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del ts, model, batch
             torch.cuda.empty_cache()
-            threads = max(1, (os.cpu_count() or 2) // 2)
-            try:
-                threads = min(threads, len(os.sched_getaffinity(0)))
-            except AttributeError:
-                pass
+            # the CPUs this process may really use (cgroup quota: 16 on a GPU box that shows 256, oracle/hostcpu.py)
+            from oracle.hostcpu import usable_cpus
+
+            threads = usable_cpus()
             out["cpu_baseline"] = cpu_baseline(args.arch, args.size, args.cpu_budget, threads)
             if args.stock_batch > 0:
                 try:

@@ -270,6 +270,10 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned hw_id, unsigned nwg) {
 // completion is tracked by the kernels' own counted waits (they already were).  M0 (the LDS base of the DMA) is written
 // in the same statement that uses it; `s_nop 4` covers an operand fresh from v_readfirstlane (VALU-written SGPR ->
 // VMEM: 5 wait states), `s_nop 0` the M0 write -> LDS-DMA wait state.
+// RULE: a kernel stages EITHER through this asm path OR through the compiler-tracked builtin
+// (__builtin_amdgcn_global_load_lds: wdma16 / dma16 of the register-address kernels), never both in one instance: the
+// asm loads are invisible to SIInsertWaitcnts, so a mixed kernel's compiler-inserted waits would under-count.  The
+// -DMSFWSI_ASM_DMA=0 build (make asmdma0) is the A/B correctness reference of the hand-counted waits.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef MSFWSI_ASM_DMA
 #define MSFWSI_ASM_DMA 1
@@ -280,7 +284,7 @@ __device__ __forceinline__ void lds_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void*
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :
                  : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
+                 : "memory", "m0");  // M0 is clobbered: hipcc must not keep a live value in it across the statement
 #else
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff,
                                              0, 0);

@@ -124,47 +124,56 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__
 }
 
 // ---- Dice ------------------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void softmax_px(const T* lp, int C1, float* p) {
+// NC = compile-time bound of the class count (8 / 16 / 32): every per-class array is indexed by fully unrolled loops
+// and stays in registers.  (Round 3: arrays of kMaxCls indexed by runtime loops put dice_reduce_kernel's accumulators
+// into 528 bytes of scratch per lane.)
+template <typename T, int NC>
+__device__ __forceinline__ void softmax_px(const T* lp, int C1, float (&p)[NC]) {
     float mx = -INFINITY;
-    for (int c = 0; c < C1; ++c) {
-        p[c] = load_elem<T>(lp, c);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        p[c] = c < C1 ? load_elem<T>(lp, c) : -INFINITY;
         mx = fmaxf(mx, p[c]);
     }
     float s = 0.f;
-    for (int c = 0; c < C1; ++c) {
-        p[c] = expf(p[c] - mx);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        p[c] = c < C1 ? expf(p[c] - mx) : 0.f;
         s += p[c];
     }
     const float inv = 1.f / s;
-    for (int c = 0; c < C1; ++c) p[c] *= inv;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) p[c] *= inv;
 }
 
 // sums[3][C1] (fp64) += { sum p_c t_c, sum p_c, sum t_c } over all pixels
-template <typename T>
+template <typename T, int NC>
 __global__ void dice_reduce_kernel(const T* __restrict__ logits, const long* __restrict__ target, long M, int C1, int CP,
                                    double* __restrict__ sums) {
     __shared__ float sh[3 * kMaxCls];
     for (int i = threadIdx.x; i < 3 * C1; i += blockDim.x) sh[i] = 0.f;
     __syncthreads();
-    float acc[3][kMaxCls];
-    for (int c = 0; c < C1; ++c) acc[0][c] = acc[1][c] = acc[2][c] = 0.f;
+    float acc[3][NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[0][c] = acc[1][c] = acc[2][c] = 0.f;
     for (long m = blockIdx.x * (long)blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
-        float p[kMaxCls];
-        softmax_px<T>(logits + m * CP, C1, p);
-        const long t = target[m];
-        for (int c = 0; c < C1; ++c) {
+        float p[NC];
+        softmax_px<T, NC>(logits + m * CP, C1, p);
+        const int t = (int)target[m];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
             acc[1][c] += p[c];
-            if (t == c) {
-                acc[0][c] += p[c];
-                acc[2][c] += 1.f;
-            }
+            const bool hit = t == c;
+            acc[0][c] += hit ? p[c] : 0.f;
+            acc[2][c] += hit ? 1.f : 0.f;
         }
     }
-    for (int c = 0; c < C1; ++c)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float v = wave_sum(acc[k][c]);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&sh[k * C1 + c], v);
+            if ((threadIdx.x & 63) == 0 && c < C1) atomicAdd(&sh[k * C1 + c], v);
         }
     __syncthreads();
     for (int i = threadIdx.x; i < 3 * C1; i += blockDim.x) atomicAdd(sums + i, (double)sh[i]);
@@ -193,22 +202,32 @@ __global__ void dice_finalize_kernel(const double* __restrict__ sums, int C1, un
 }
 
 // dlogits[m][j] = gs * p_j (dp_j - sum_c p_c dp_c),  dp_c = a_c [t == c] + b_c;  channels C1..CP-1 get 0
-template <typename T>
+template <typename T, int NC>
 __global__ void dice_bwd_kernel(const T* __restrict__ logits, const long* __restrict__ target, long M, int C1, int CP,
                                 const float* __restrict__ coef, const float* __restrict__ grad_scale,
                                 T* __restrict__ dlogits) {
     const float gs = grad_scale != nullptr ? *grad_scale : 1.f;
+    float ca[NC], cb[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        ca[c] = c < C1 ? coef[c] : 0.f;
+        cb[c] = c < C1 ? coef[C1 + c] : 0.f;
+    }
     for (long m = blockIdx.x * (long)blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
-        float p[kMaxCls], dp[kMaxCls];
-        softmax_px<T>(logits + m * CP, C1, p);
-        const long t = target[m];
+        float p[NC], dp[NC];
+        softmax_px<T, NC>(logits + m * CP, C1, p);
+        const int t = (int)target[m];
         float dot = 0.f;
-        for (int c = 0; c < C1; ++c) {
-            dp[c] = (t == c ? coef[c] : 0.f) + coef[C1 + c];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            dp[c] = (t == c ? ca[c] : 0.f) + cb[c];
             dot = fmaf(p[c], dp[c], dot);
         }
         T* o = dlogits + m * CP;
-        for (int c = 0; c < CP; ++c) store_elem<T>(o, c, c < C1 ? gs * p[c] * (dp[c] - dot) : 0.f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < CP) store_elem<T>(o, c, c < C1 ? gs * p[c] * (dp[c] - dot) : 0.f);
+        for (int c = NC; c < CP; ++c) store_elem<T>(o, c, 0.f);
     }
 }
 
@@ -267,15 +286,19 @@ extern "C" int msfwsi_dice_loss(int dtype, const void* logits, const long* targe
                                 double* loss, float* coef, const float* grad_scale, void* dlogits, void* stream) {
     MSFWSI_CHECK_ARG(msfwsi_dtype_ok(dtype) && logits && target && sums && loss && coef && M > 0);
     MSFWSI_CHECK_ARG(C1 > 0 && C1 <= kMaxCls && CP >= C1 && CP % msfwsi_vec_of(dtype) == 0);
-    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(dice_reduce_kernel<T>, dim3(ugrid(M) > 1024 ? 1024 : ugrid(M)), dim3(kT), 0,
-                           ST(stream), (const T*)logits, target, M, C1, CP, sums));
+#define MSFWSI_DICE_NC(KERNEL, GRID, ...)                                                                              \
+    do {                                                                                                               \
+        if (C1 <= 8) { MSFWSI_WITH_T(dtype, hipLaunchKernelGGL((KERNEL<T, 8>), GRID, dim3(kT), 0, ST(stream), __VA_ARGS__)); }   \
+        else if (C1 <= 16) { MSFWSI_WITH_T(dtype, hipLaunchKernelGGL((KERNEL<T, 16>), GRID, dim3(kT), 0, ST(stream), __VA_ARGS__)); } \
+        else { MSFWSI_WITH_T(dtype, hipLaunchKernelGGL((KERNEL<T, 32>), GRID, dim3(kT), 0, ST(stream), __VA_ARGS__)); }  \
+    } while (0)
+    MSFWSI_DICE_NC(dice_reduce_kernel, dim3(ugrid(M) > 1024 ? 1024 : ugrid(M)), (const T*)logits, target, M, C1, CP, sums);
     int rc = msfwsi_launch_status();
     if (rc != MSFWSI_OK) return rc;
     hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), sums, C1, class_mask, eps, smooth, weight,
                        loss, coef);
     rc = msfwsi_launch_status();
     if (rc != MSFWSI_OK || dlogits == nullptr) return rc;
-    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(dice_bwd_kernel<T>, dim3(ugrid(M)), dim3(kT), 0, ST(stream), (const T*)logits,
-                           target, M, C1, CP, coef, grad_scale, (T*)dlogits));
+    MSFWSI_DICE_NC(dice_bwd_kernel, dim3(ugrid(M)), (const T*)logits, target, M, C1, CP, coef, grad_scale, (T*)dlogits);
     return msfwsi_launch_status();
 }

@@ -78,6 +78,7 @@ class FinetuneStep(FlatAdamScaler):
         """one optimisation step; returns (device-resident fp64 loss, (tp, fp, fn, tn) of the target prediction
         [B, n_classes] int64 -- what the loop appends to tp_all ... tn_all, ssl_finetune.py:440-453)"""
         bs = images[0].shape[0]
+        self.model.train()  # the reference's train() does so every epoch (ssl_finetune.py:419); validate() leaves eval mode
         self.engine.reset_counters()
         self.flats.zero_grads()
         kn.ARENA.begin_step(self.device)
@@ -125,5 +126,5 @@ class FinetuneStep(FlatAdamScaler):
 
     def checkpoint(self, epoch: int) -> dict:
         sd = {"module." + k: v.detach().clone() for k, v in self.model.state_dict().items()}
-        return {"epoch": epoch + 1, "state_dict": sd, "optimizer": self.optimizer_state_dict(),
-                "scaler": self.scaler_state_dict()}
+        return {"epoch": epoch + 1, "arch": getattr(self.model, "encoder_name", "resnet18"), "state_dict": sd,
+                "optimizer": self.optimizer_state_dict(), "scaler": self.scaler_state_dict()}

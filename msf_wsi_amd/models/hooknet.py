@@ -171,6 +171,7 @@ class HookNet(nn.Module):
         super().__init__()
         args = (encoder_name, encoder_depth, encoder_weights, decoder_use_batchnorm, decoder_channels,
                 decoder_attention_type, in_channels, classes, activation, aux_params)
+        self.encoder_name = encoder_name  # the fine-tune checkpoint's "arch" entry (ssl_finetune.py:355)
         self.context_branch = ContextUnet(*args)
         self.target_branch = TargetUnet(*args)
 

@@ -99,7 +99,7 @@ def reference_loop_loss(outputs, weights=WEIGHTS):
 FLOOR = 1e-3  # north_star tolerance
 
 
-def spread_gate(rels, names, spreads, what, envelope=(), strict_count=False, tight_median=None):
+def spread_gate(rels, names, spreads, what, envelope=(), strict_count=False, tight_median=None, count_rule=True):
     """Per-tensor gate of SURVEY.md 8(d): rel-L2 against the fp64 oracle <= max(1e-3, 2 x the reference's OWN
     fp32<->fp64 spread of that tensor).
 
@@ -155,7 +155,12 @@ def spread_gate(rels, names, spreads, what, envelope=(), strict_count=False, tig
           f"({names[int(rels.argmax())]}); reference noise: median {np.median(env):.2e} max {env.max():.2e}")
     assert np.median(rels) <= max(FLOOR, 2.0 * float(np.median(env))), (what, "median", float(np.median(rels)))
     # (the same factor 2 as rule 1: the count of flip-hit tensors is itself a random number of the same process)
-    assert int(over.sum()) <= count_bound, (what, "tensors beyond their allowance", int(over.sum()), "bound", count_bound)
+    # count_rule=False: a pure chain (an encoder trunk without heads), where ONE flip near the top moves EVERY tensor below
+    # it -- the count of tensors then says where the flip sat, not how many there were (measured on the reference's own
+    # fp32 runs of one trunk case: 13 tensors above 1e-3 with 16 torch threads, 153 of 159 with 128); the median and size
+    # rules above / below still apply, and the caller adds a rule a flip cannot satisfy by luck (three-seed minimum)
+    if count_rule:
+        assert int(over.sum()) <= count_bound, (what, "tensors beyond their allowance", int(over.sum()), "bound", count_bound)
     if over.any():
         assert float(rels[over].max()) <= max(FLOOR, 2.0 * worst_ref), (what, names[int(rels.argmax())],
                                                                         float(rels[over].max()), worst_ref)
@@ -177,34 +182,19 @@ _ORACLE_CACHE = {}
 def oracle_case(case):
     """One fp64 and one fp32 oracle step (forward, loss, backward, Adam) of a golden case on THIS machine, shared by
     the tests of a session: {B, size, batch, sd0, lr, loss64, terms64, outs64, grads64, sd64 (updated weights),
-    loss32, grads32, sd32, names, box_grad, box_step (the oracle's own fp32<->fp64 spread per tensor here)}"""
+    loss32, sd32, names, box_grad, box_step (the oracle's own fp32<->fp64 spread per tensor here), vec, man}.
+    The arithmetic runs in a background CPU worker when the session started some (tests/oracle_jobs.py, conftest.py:
+    the GPU suite overlaps it with the GPU tests), otherwise inline."""
     if case in _ORACLE_CACHE:
         return _ORACLE_CACHE[case]
-    from oracle import msfwsi_oracle as orc
+    import oracle_jobs
 
     vec, man = load_golden(case)
-    B, size = man["B"], man["size"]
-    model = build_case(man)
-    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    names = [n for n, _ in model.named_parameters()]
-    del model
-    batch = case_batch(man)
-    lr = orc.init_lr(LR, B)
-    out = {"B": B, "size": size, "batch": batch, "sd0": sd0, "lr": lr, "names": names, "vec": vec, "man": man}
-    for tag, dt in (("64", torch.float64), ("32", torch.float32)):
-        sd = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
-        (c1, c2), (t1, t2), idx = batch
-        b = ((c1.to(dt), c2.to(dt)), (t1.to(dt), t2.to(dt)), idx)
-        loss, terms, outs, grads = orc.train_step(sd, b, orc.Adam(sd, [lr, lr, lr]), 4, 0.5, WEIGHTS)
-        out["loss" + tag] = float(loss)
-        out["terms" + tag] = torch.stack([t for row in terms for t in row])
-        out["outs" + tag] = tuple(tuple(tuple(t.detach() for t in tup) for tup in grp) for grp in outs)
-        out["grads" + tag] = grads
-        out["sd" + tag] = sd
+    out = dict(oracle_jobs.get("oracle_case", case))
+    out["vec"], out["man"] = vec, man
+    out["batch"] = case_batch(man)
     # pinned: this machine's fp64 oracle reproduces the real reference's golden loss terms
     assert torch.allclose(out["terms64"], torch.as_tensor(vec["terms"]), rtol=0, atol=1e-7)
-    out["box_grad"] = np.array([rel(out["grads32"][n], out["grads64"][n]) for n in names])
-    out["box_step"] = np.array([rel(out["sd32"][n], out["sd64"][n]) for n in names])
     _ORACLE_CACHE[case] = out
     return out
 

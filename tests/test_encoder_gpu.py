@@ -190,9 +190,12 @@ def test_resnet50_trunk_well_conditioned_fp32(hip_lib):
         rels = np.array([rel(grads[k], g64[k]) for k in names])
         box = np.array([rel(g32[k], g64[k]) for k in names])
         spreads = [box] + ([vec["spread_grad"]] if seed == man["data_seed"] else [])
-        # (the reference's own fp32 run of a seed can carry a flip at the top as well -- measured: 153 of 159 tensors above
-        #  1e-3 for seed 2 on the EPYC host -- so no fixture-quality assertion here: strict_count=False)
-        spread_gate(rels, names, spreads, f"resnet50 trunk (well-conditioned, seed {seed}), fp32 gradients")
+        # (the reference's own fp32 run of a seed can carry a flip at the top as well -- measured for seed 2 on the EPYC
+        #  host: 153 of 159 tensors above 1e-3 with 128 torch threads, 13 with 16 threads, while the product's flip of the
+        #  same seed moved 28 -- so the per-seed gate holds the median and the size of the deviations, not the COUNT of
+        #  tensors below a flip (count_rule=False); the three-seed minimum below is the rule a systematic error fails)
+        spread_gate(rels, names, spreads, f"resnet50 trunk (well-conditioned, seed {seed}), fp32 gradients",
+                    count_rule=False)
         per_seed.append(rels)
         per_seed_ref.append(np.min(np.stack(spreads), axis=0))
     best, best_ref = np.min(np.stack(per_seed), axis=0), np.min(np.stack(per_seed_ref), axis=0)

@@ -194,13 +194,10 @@ def test_loss_curve_tracks_reference(hip_lib, dtype):
         # ... and the ORACLE under torch.autocast("cpu", bfloat16) on THIS machine: bf16 kernels differ by CPU (the build
         # container's samples end at -0.81 .. -0.84, an EPYC 9575F with native AVX512-BF16 at -0.74), and the oracle's
         # autocast mode is pinned to the reference's (make_golden.py: same forward bit for bit in one process)
-        osd = {k: v.detach().clone() for k, v in build_case(man).state_dict().items()}
-        oopt = orc.Adam(osd, [orc.init_lr(LR, B)] * 3)
-        here = []
-        for t in range(steps):
-            l_, _, _, _ = orc.train_step(osd, orc.diverse_batch(B, size, 16, man["curve_seed0"] + t), oopt,
-                                         autocast_dtype=torch.bfloat16)
-            here.append(float(l_))
+        # (a background CPU worker computes it while the GPU runs the other tests: tests/oracle_jobs.py)
+        import oracle_jobs
+
+        here = oracle_jobs.get("curve_oracle", "r18_b16_s64_curve", "bf16")["losses"]
         samples["oracle_bf16_this_machine"] = np.array(here)
     env = np.max(np.stack([np.maximum.accumulate(np.abs(v - ref64)) for v in samples.values()]), axis=0)
     allow = np.maximum(2e-3, 2.0 * env)

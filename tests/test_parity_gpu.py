@@ -47,7 +47,6 @@ def run_reference_loop_case(case, check_golden_outputs=True):
 
     oc = oracle_case(case)
     loss64, terms64, outs64, grads64, sd64 = oc["loss64"], oc["terms64"], oc["outs64"], oc["grads64"], oc["sd64"]
-    grads32, sd32 = oc["grads32"], oc["sd32"]
     assert abs(float(loss64) - float(vec["loss"][0])) < 1e-7
 
     model = model.cuda().train()
@@ -86,7 +85,7 @@ def run_reference_loop_case(case, check_golden_outputs=True):
     assert names == man["param_keys"]
     pg = [(n, p.grad) for n, p in named]
     assert all(g is not None for _, g in pg)
-    box_spread = np.array([rel(grads32[n], grads64[n]) for n in names])
+    box_spread = oc["box_grad"]  # the oracle's own fp32<->fp64 distance per tensor on this machine
     fixture = [vec["spread_grad"]] if "spread_grad" in vec else []
     spread_gate(grad_rels(pg, grads64), names, fixture + [box_spread], f"{case} gradients vs fp64 oracle",
                 envelope=() if diverse else other_spreads("spread_grad", case), strict_count=diverse)
@@ -111,7 +110,7 @@ def run_reference_loop_case(case, check_golden_outputs=True):
     # ---- optimizer step on the product's gradients (torch Adam, as the reference loop does): updated weights
     opt.step()
     torch.cuda.synchronize()
-    box_step = np.array([rel(sd32[n], sd64[n]) for n in names])
+    box_step = oc["box_step"]
     fixture = [vec["spread_step"]] if "spread_step" in vec else []
     gfix = [vec["spread_grad"]] if "spread_grad" in vec else []
     updated_weights_gate(named, sd0, sd64, grads64, lr, fixture + [box_step], gfix + [box_spread],

@@ -11,19 +11,13 @@ from helpers import LR, WEIGHTS, build_product, load_golden, rel, spread_gate
 pytestmark = pytest.mark.gpu
 
 
-def _oracle(sd0, batch, B, steps=1, dt=torch.float64):
-    from oracle import msfwsi_oracle as orc
+def _oracle(steps=1, dt="fp64"):
+    """`steps` oracle steps of the r18_b8_s64 case (seeded model, N(0,1) batch): (losses, weights after the last step)
+    -- from a background CPU worker when the session runs some (tests/oracle_jobs.py), else inline"""
+    import oracle_jobs
 
-    osd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
-    (c1, c2), (t1, t2), idx = batch
-    b64 = ((c1.to(dt), c2.to(dt)), (t1.to(dt), t2.to(dt)), idx)
-    lr = orc.init_lr(LR, B)
-    opt = orc.Adam(osd, [lr, lr, lr])
-    losses = []
-    for _ in range(steps):
-        loss, terms, outs, grads = orc.train_step(osd, b64, opt, 4, 0.5, WEIGHTS)
-        losses.append(float(loss))
-    return losses, osd
+    res = oracle_jobs.get("steps", "r18_b8_s64", steps, dt)
+    return res["losses"], res["sd"]
 
 
 def _gpu_batch(batch):
@@ -40,7 +34,7 @@ def test_fused_step_fp32_matches_oracle(hip_lib):
     model = build_product("resnet18")
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
-    olosses, osd = _oracle(sd0, batch, B, steps=2)
+    olosses, osd = _oracle(steps=2)
     model = model.cuda().train()
     ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=True, init_scale=1024.0)
     gb = _gpu_batch(batch)
@@ -52,7 +46,7 @@ def test_fused_step_fp32_matches_oracle(hip_lib):
     # second step sees the updated weights.  Adam's first step is lr*sign(g), so elements whose gradient lies inside
     # the fp32 noise move the other way; the reference's own fp32 second-step loss shows how far that carries:
     # allow 2x its distance from the fp64 run (floor: the 1e-3 of the first step)
-    o32, _ = _oracle(sd0, batch, B, steps=2, dt=torch.float32)
+    o32, _ = _oracle(steps=2, dt="fp32")
     ref_spread = abs(o32[1] - olosses[1])
     print(f"second-step loss: product {float(l2):.6f} fp64 oracle {olosses[1]:.6f} fp32 oracle {o32[1]:.6f}")
     assert abs(float(l2) - olosses[1]) <= max(1e-3 * max(abs(olosses[1]), 1e-2), 2 * ref_spread)
@@ -72,8 +66,9 @@ def test_fused_single_step_weights_fp32(hip_lib):
     model = build_product("resnet18")
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
-    _, osd = _oracle(sd0, batch, B, steps=1)
-    _, osd32 = _oracle(sd0, batch, B, steps=1, dt=torch.float32)
+    from helpers import oracle_case
+
+    osd = oracle_case("r18_b8_s64")["sd64"]  # one fp64 oracle step of the same seeded model and batch
     model = model.cuda().train()
     ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False)
     ts.step(_gpu_batch(batch))
@@ -163,17 +158,14 @@ def test_infonce_variant_matches_torch_restatement(hip_lib):
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     batch = orc.synthetic_batch(B, size, 16, man["data_seed"])
 
-    def oracle(dt):
-        sd = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
-        (c1, c2), (t1, t2), idx = batch
-        b = ((c1.to(dt), c2.to(dt)), (t1.to(dt), t2.to(dt)), idx)
-        nop = type("NoOpt", (), {"step": lambda self, *a, **k: None})()
-        loss, _, _, grads = orc.train_step(sd, b, nop, 4, 0.5, WEIGHTS,
-                                           loss_fn=lambda o, w: orc.infonce_terms(o, w, temperature=0.2))
-        return float(loss), grads
+    import oracle_jobs
 
-    l64, g64 = oracle(torch.float64)
-    l32, g32 = oracle(torch.float32)
+    def oracle(dt):  # orc.train_step with loss_fn = orc.infonce_terms(temperature 0.2), no optimizer step
+        res = oracle_jobs.get("steps", "r18_b8_s64", 1, dt, "infonce", 0.2, True)
+        return res["losses"][0], res["grads"]
+
+    l64, g64 = oracle("fp64")
+    l32, g32 = oracle("fp32")
     model = model.cuda().train()
     ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False, loss="infonce",
                       temperature=0.2)

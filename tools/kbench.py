@@ -1,0 +1,183 @@
+"""GPU box: micro-benchmarks of single launches at the shapes of BASELINE config 2 (ResNet-50, 256 tile pairs: N = 4096
+target tiles), through the same C-ABI entry points the engine uses.  One line per case: ms per launch, algorithmic GB/s
+and TFLOP/s.     python tools/kbench.py [case ...]        (MSFWSI_LIB=other.so for an A/B of two builds)
+
+cases: epi3 (strided-residual 1x1 input gradients), s2 (stride-2 3x3 input gradients), wide (short-k 1x1 launches with
+wide outputs), pool (stem max-pool forward / backward), fuser (18432-wide Linear layers at 512 rows), dma (plain 1x1)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from msf_wsi_amd import _lib, kernels as kn  # noqa: E402
+
+DT = torch.bfloat16
+NIMG = int(os.environ.get("KBENCH_N", 4096))
+ITERS = int(os.environ.get("KBENCH_ITERS", 6))
+
+
+def rnd(*shape, scale=1.0, dtype=DT):
+    return (torch.randn(*shape, device="cuda") * scale).to(dtype)
+
+
+def timeit(fn, iters=ITERS, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def report(name, ms, nbytes, flop=0.0):
+    print(f"{name:78s} {ms:8.3f} ms  {nbytes / ms / 1e6:7.0f} GB/s  {flop / ms / 1e9:7.0f} TF", flush=True)
+
+
+def case_epi3():
+    """conv1 (1x1) input gradient of the three strided Bottlenecks: gate bits + sums + the low-resolution residual"""
+    for H, C, K in ((56, 256, 128), (28, 512, 256), (14, 1024, 512)):
+        N = NIMG
+        d = kn.conv_desc(DT, N, H, H, C, K, 1, 1, 1, 0)
+        M = N * H * H
+        dy = rnd(M, K, scale=0.05)
+        w = rnd(K, C, scale=0.05)
+        dx = torch.empty(M, C, dtype=DT, device="cuda")
+        lo = rnd(N * (H // 2) * (H // 2), C, scale=0.05)
+        full = rnd(M, C, scale=0.05)
+        bits = torch.randint(0, 256, (M * C // 8,), dtype=torch.uint8, device="cuda")
+        gapg = rnd(N, C, scale=0.05)
+        base = (M * K + M * C) * 2 + M * C // 8
+        flop = 2.0 * M * K * C
+        for label, kw, extra in (
+            ("bits+sums, no residual", dict(), 0),
+            ("bits+sums+lowres residual (engine)", dict(resid=lo, resid_stride=2), lo.numel() * 2),
+            ("bits+sums+full residual", dict(resid=full), full.numel() * 2),
+            ("bits+sums+gap+lowres residual", dict(resid=lo, resid_stride=2, gapg=gapg, gap_scale=1.0 / (H * H)), lo.numel() * 2),
+        ):
+            def run():
+                sums = kn.new_stats(C, 2, "cuda")
+                kn.conv_dgrad(d, dy, w, dx, mask_bits=bits, sums=sums, **kw)
+            report(f"epi3 {H}x{H} dY{K}->dX{C}: {label}", timeit(run), base + extra, flop)
+        del dy, dx, lo, full, bits
+
+
+def case_s2():
+    """conv2 (3x3 / stride 2) input gradients of the strided Bottlenecks, gated by the producer's BatchNorm+ReLU"""
+    for H, C in ((56, 128), (28, 256), (14, 512)):
+        N = NIMG
+        d = kn.conv_desc(DT, N, H, H, C, C, 3, 3, 2, 1)
+        M, Mo = N * H * H, N * d.P * d.Q
+        dy = rnd(Mo, C, scale=0.05)
+        w = rnd(C * 9, C, scale=0.05)
+        dx = torch.empty(M, C, dtype=DT, device="cuda")
+        c = rnd(M, C)
+        sc, sh = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        nbytes = (Mo * C + 2 * M * C) * 2
+        flop = 2.0 * Mo * 9 * C * C
+
+        def run():
+            sums = kn.new_stats(C, 2, "cuda")
+            kn.conv_dgrad(d, dy, w, dx, mask=(c, sc, sh), sums=sums)
+        report(f"s2   {H}x{H} C{C} 3x3/s2 dgrad (+gate, sums)", timeit(run), nbytes, flop)
+        del dy, dx, c
+
+
+def case_wide():
+    """short-k 1x1 launches with a wide output: conv3 forward with its fused tail, conv1 input gradient"""
+    for H, Cn, Kw in ((14, 256, 1024), (28, 128, 512), (7, 512, 2048), (56, 64, 256)):
+        N = NIMG
+        M = N * H * H
+        # forward conv3: a2 [M][Cn] -> y [M][Kw], BatchNorm apply + identity + ReLU + gate bits
+        d = kn.conv_desc(DT, N, H, H, Cn, Kw, 1, 1, 1, 0)
+        a = rnd(M, Cn)
+        w = rnd(Kw, Cn, scale=0.05)
+        y = torch.empty(M, Kw, dtype=DT, device="cuda")
+        ident = rnd(M, Kw)
+        ps, pb = torch.ones(Kw, device="cuda"), torch.zeros(Kw, device="cuda")
+        bits = kn.gate_bytes(M, Kw, DT, "cuda")
+        nb = (M * Cn + 2 * M * Kw) * 2 + M * Kw // 8
+        report(f"wide {H}x{H} fwd C{Cn}->K{Kw} post (bn+ident+relu+bits)",
+               timeit(lambda: kn.conv_fwd_post(d, a, w, y, ps, pb, ident=ident, relu=True, gate_out=bits)), nb,
+               2.0 * M * Cn * Kw)
+        # input gradient of conv1 (Kw -> Cn): dY [M][Cn] -> dX [M][Kw], residual + gate bits + sums
+        d1 = kn.conv_desc(DT, N, H, H, Kw, Cn, 1, 1, 1, 0)
+        w1 = rnd(Cn, Kw, scale=0.05)
+
+        def run():
+            sums = kn.new_stats(Kw, 2, "cuda")
+            kn.conv_dgrad(d1, a, w1, y, resid=ident, mask_bits=bits, sums=sums)
+        report(f"wide {H}x{H} dgrad dY{Cn}->dX{Kw} (+resid, bits, sums)", timeit(run), nb, 2.0 * M * Cn * Kw)
+        del a, y, ident, bits
+
+
+def case_pool():
+    N, H, C = NIMG, 112, 64
+    P = H // 2
+    c0 = rnd(N * H * H, C)
+    sc, sh = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    out = torch.empty(N * P * P, C, dtype=DT, device="cuda")
+    am = torch.empty(N * P * P, C, dtype=torch.uint8, device="cuda")
+    nb_f = c0.numel() * 2 + out.numel() * 3
+    report("pool fwd 112x112x64", timeit(lambda: kn.stem_pool_fwd(c0, sc, sh, out, am, N, H, H, C)), nb_f)
+    dp = rnd(N * P * P, C, scale=0.05)
+    g0 = torch.empty_like(c0)
+
+    def run():
+        sums = kn.new_stats(C, 2, "cuda")
+        kn.stem_pool_bwd(dp, am, c0, sc, sh, g0, sums, N, H, H, C)
+    nb_b = dp.numel() * 3 + 2 * c0.numel() * 2
+    report("pool bwd 112x112x64", timeit(run), nb_b)
+
+
+def case_fuser():
+    """the fuser heads' Linear layers (backbone.py:195-212) at 2 x 256 rows"""
+    rows = 512
+    for Cin, K in ((18432, 18432), (9216, 9216), (18432, 4608), (4608, 18432), (4608, 4608)):
+        d = kn.conv_desc(DT, rows, 1, 1, Cin, K, 1, 1, 1, 0)
+        x = rnd(rows, Cin)
+        w = rnd(K, Cin, scale=0.02)
+        y = torch.empty(rows, K, dtype=DT, device="cuda")
+        wb = K * Cin * 2
+        flop = 2.0 * rows * Cin * K
+        report(f"fuser fwd   {rows}x{Cin} -> {K}", timeit(lambda: kn.conv_fwd(d, x, w, y)), wb + (x.numel() + y.numel()) * 2, flop)
+        dy = rnd(rows, K, scale=0.05)
+        dx = torch.empty(rows, Cin, dtype=DT, device="cuda")
+        report(f"fuser dgrad {rows}x{K} -> {Cin}", timeit(lambda: kn.conv_dgrad(d, dy, w, dx)), wb + (dy.numel() + dx.numel()) * 2, flop)
+        dw = torch.zeros(K, Cin, device="cuda")
+        report(f"fuser wgrad {rows}: {K}x{Cin}", timeit(lambda: kn.conv_wgrad(d, x, dy, dw)), K * Cin * 8 + (x.numel() + dy.numel()) * 2, flop)
+        del x, w, y, dy, dx, dw
+
+
+def case_dma():
+    """plain 1x1 forward / input gradient without epilogue operands (reference points for the classes above)"""
+    for H, Cn, K in ((56, 256, 64), (56, 64, 256), (28, 512, 128), (14, 1024, 256), (14, 256, 1024)):
+        N = NIMG
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cn, K, 1, 1, 1, 0)
+        x = rnd(M, Cn)
+        w = rnd(K, Cn, scale=0.05)
+        y = torch.empty(M, K, dtype=DT, device="cuda")
+        nb = (M * Cn + M * K) * 2
+        report(f"dma  {H}x{H} fwd C{Cn}->K{K} (+stats)",
+               timeit(lambda: kn.conv_fwd(d, x, w, y, stats=kn.new_stats(K, 2, "cuda"))), nb, 2.0 * M * Cn * K)
+        report(f"dma  {H}x{H} dgrad dY{K}->dX{Cn}", timeit(lambda: kn.conv_dgrad(d, y, w, x)), nb, 2.0 * M * Cn * K)
+        del x, y
+
+
+CASES = {"epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+
+
+def main():
+    _lib.load()
+    for name in (sys.argv[1:] or list(CASES)):
+        CASES[name]()
+
+
+if __name__ == "__main__":
+    main()
