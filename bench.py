@@ -143,7 +143,9 @@ def cpu_baseline(arch, size, budget_s, threads):
     return out
 
 
-def build_roofline(timer, args, dt, timed_from, step_bytes, step_flop, use_pmc=True):
+def build_roofline(timer, args, dt, timed_from, step_bytes, step_flop, use_pmc=True, nst=None, ev_seconds=None):
+    # nst / ev_seconds: number and wall time of the event-bracketed steps when they are not the last (steps - timed_from)
+    # steps of the timed region (multi-stream runs: one extra single-stream step after it, see main)
     """the `roofline` object of the bench line from the HIP-event timings of the last (steps - timed_from) steps:
     the dominant kernel symbol by time, its algorithmic FLOP/s and GB/s against the gfx950 peaks, the replayed counter
     figures of the committed rocprofv3 --pmc summary (config 2 only), whole-step fractions (where SURVEY 8(d) gives the
@@ -157,7 +159,7 @@ def build_roofline(timer, args, dt, timed_from, step_bytes, step_flop, use_pmc=T
     frac_m, frac_h = tf / PEAK_TFLOPS[args.dtype], gbs / PEAK_HBM_GBS
     bound = "mfma" if frac_m >= frac_h else "hbm"
     pmc = pmc_entry(dom) if use_pmc else {}
-    nst = args.steps - timed_from
+    nst = (args.steps - timed_from) if nst is None else nst
     # the counters are per rocprofv3 launch; one timer entry can issue several launches (the stride-2 3x3 input
     # gradient is four): compare per STEP, and quote `traffic` per timer entry like `achieved`
     pmc_per_step = (pmc["hbm_bytes_per_launch"] * pmc["launches_in_pass"] / 2.0
@@ -194,9 +196,9 @@ def build_roofline(timer, args, dt, timed_from, step_bytes, step_flop, use_pmc=T
         "families": {k: {"launches": v["launches"], "ms": round(1e3 * v["seconds"], 2),
                          "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 2),
                          "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1)} for k, v in fam.items()},
-        "event_timed_steps": args.steps - timed_from,
+        "event_timed_steps": nst,
         "timed_fraction_of_step": round(sum(v["seconds"] for v in fam.values())
-                                        / (dt * (args.steps - timed_from) / args.steps), 3),
+                                        / (ev_seconds if ev_seconds else dt * nst / args.steps), 3),
     }
     return roof
 
@@ -476,10 +478,16 @@ def main():
         ts.step(batch)
     timer = None if args.no_kernel_timer else kn.KernelTimer(streams=True)
     sync()
-    # the per-launch HIP events (two per launch, dense and streaming kernels: ~7 500 per step) cost ~3 % of a step they
-    # bracket (measured: 545.2 -> 550.8 ms/step averaged over six steps with two of them bracketed): they are recorded
-    # on the LAST timed step only
-    timed_from = max(0, args.steps - 1)
+    # One rank runs the step on three HIP streams (target views on two, context passes on a third: engine.Engine).  An
+    # event pair around a launch on a stream that SHARES the chip measures that launch plus its queueing behind the other
+    # streams' kernels (measured: the summed "durations" exceed the step time several times over) -- useless for a
+    # roofline.  In that case the timed region carries NO events, and the roofline comes from ONE EXTRA step right after
+    # it, on one stream, whose launches are bracketed as before: the same kernels on the same tensors, each alone on the
+    # chip.  `value` / `ms_per_step` are of the timed region only.
+    multi = ",dual-stream" in ts.engine.last_plan  # decided by the engine during the warm-up steps
+    # otherwise (one stream; more than one rank): the per-launch HIP events (two per launch, ~7 500 per step) cost ~3 % of
+    # a step they bracket and are recorded on the LAST timed step only
+    timed_from = args.steps if multi else max(0, args.steps - 1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         kn.TIMER = timer if i >= timed_from else None
@@ -487,12 +495,43 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     kn.TIMER = None
+    run_plan = ts.engine.last_plan
+    if timer is not None and ",dual-stream" in run_plan and not multi:
+        # fewer than two warm-up steps: the engine switched to several streams INSIDE the timed region, so the last step's
+        # event pairs are of shared streams -- discard them and measure the extra step instead
+        timer, multi = kn.KernelTimer(streams=True), True
+    run_collectives = ts.engine.collectives_last_step + ts.reducer.launches_last_step
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    peak_reserved = torch.cuda.max_memory_reserved() / 2 ** 30
+    ev_nst, ev_seconds = None, None
+    if timer is not None and multi:
+        torch.cuda.empty_cache()  # the side streams' cached blocks go back before one stream needs room for every pass
+        keep = ts.engine.dual_stream
+        ts.engine.dual_stream = False
+        ts.step(batch)  # un-bracketed: the main stream's pool grows back to hold every pass (seconds of hipMalloc)
+        kn.TIMER = timer
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ts.step(batch)
+        torch.cuda.synchronize()
+        ev_nst, ev_seconds = 1, time.perf_counter() - t1
+        kn.TIMER = None
+        ts.engine.dual_stream = keep
+    # A number measured on a recompute plan (a pass run features-only and re-run before its backward: +16 % / +32 %
+    # time) is not the configuration the metric names unless the caller asked for it: fail loudly instead of printing it
+    if "recompute:" in run_plan and "MSFWSI_RECOMPUTE" not in os.environ:
+        raise SystemExit(f"bench.py: the memory plan of this run fell back to '{run_plan}' (not enough HBM to "
+                         f"keep every activation at {args.batch} tile pairs per GPU); set MSFWSI_RECOMPUTE=auto to accept "
+                         f"a number measured with recomputation, or lower --batch")
+    plan8 = None
+    if world == 1 and ts.engine.last_shape is not None:
+        torch.cuda.empty_cache()
+        Bs, Ks, sk = ts.engine.last_shape
+        plan8 = ts.engine.plan_preview(Bs, Ks, sk, dev, 8)  # with the 4 GiB RCCL reserve of a multi-rank run
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
-    peak_reserved = torch.cuda.max_memory_reserved() / 2 ** 30
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -509,8 +548,11 @@ def main():
                        "images_per_s": round(34 * pairs / dt, 1), "loss": float(loss),
                        "peak_mem_GiB": round(peak_mem, 1), "peak_reserved_GiB": round(peak_reserved, 1),
                        "step_TFLOP_per_s_algorithmic": round(FLOP_PER_PAIR.get(args.arch, 0) * pairs / dt / 1e12, 1),
-                       "recompute_plan": ts.engine.last_plan, "collectives_per_step": ts.engine.collectives_last_step
-                       + (3 if world > 1 else 0)},
+                       "recompute_plan": run_plan, "plan_at_8_ranks": plan8,
+                       # SyncBatchNorm exchanges (+ the plan) of the last step and the gradient exchange's messages
+                       "collectives_per_step": run_collectives,
+                       "gradient_messages_per_step": ts.reducer.launches_last_step,
+                       "gradient_bytes_per_step": ts.reducer.bytes_last_step},
         }
         if timer is not None and args.layer_report:
             rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1][1])
@@ -529,7 +571,14 @@ def main():
             # only beside that workload, never beside another architecture / batch / tile size / dtype
             profiled = (args.arch, args.batch, args.size, args.dtype) == ("resnet50", 256, 224, "bf16")
             out["roofline"] = build_roofline(timer, args, dt, timed_from, step_bytes,
-                                             FLOP_PER_PAIR.get(args.arch, 0) * args.batch * area, use_pmc=profiled)
+                                             FLOP_PER_PAIR.get(args.arch, 0) * args.batch * area, use_pmc=profiled,
+                                             nst=ev_nst, ev_seconds=ev_seconds)
+            out["roofline"]["concurrent_streams_in_timed_region"] = 3 if "+context-stream" in run_plan else (2 if multi else 1)
+            out["roofline"]["measured_on"] = (
+                "one extra step right after the timed region (and one un-bracketed step that regrows the allocator pool), on ONE "
+                "stream (the timed region runs three streams, where "
+                "an event pair brackets queueing, not a kernel); ms of that step: %.1f" % (1e3 * ev_seconds)
+                if multi else "the last step of the timed region")
         if world == 1 and not args.no_cpu_baseline:
             del ts, model, batch
             torch.cuda.empty_cache()

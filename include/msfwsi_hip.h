@@ -416,7 +416,8 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * kernel of the 64 -> 64 layers, key 10 = 0 their output-stationary weight-gradient kernel, key 11 = smallest
  * padded raster (positions) that kernel takes, key 12 = 0 the stationary stem kernels (forward and weight gradient), key 13 =
  * smallest padded raster the stem's weight-gradient kernel takes, key 14 = 1 the max-pool backward by 2x2 input
- * patches (default 0: per pixel, measured faster) (A/B measurements, tests).
+ * patches (default 0, measured slower), key 16 = 0 the column-walk max-pool forward / backward (default 1; 0 = one thread per
+ * window / pixel) (A/B measurements, tests).
  * One knob trades speed for run-to-run reproducibility: key 15 = cap on the pixel splits of the gather weight-gradient
  * kernel (0 = none; 1 = each gradient tile summed by one workgroup in pixel order instead of fp32 atomics in arrival
  * order -- the results then differ from the default's by rounding, 4e-7, and are the same on every run). */

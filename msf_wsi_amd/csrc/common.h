@@ -257,6 +257,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned hw_id, unsigned nwg) {
     return base + idx;
 }
 
+// Lane index of the calling wave, RE-DERIVED at the point of the call (v_mbcnt) instead of kept in a register since
+// kernel entry.  The persistent kernels need tid / lane only before and after a main loop that uses every VGPR the
+// launch bounds allow; hipcc parked those two values in scratch across the loop (12-20 bytes per lane, -Rpass-analysis=
+// kernel-resource-usage) although one instruction pair re-creates them -- `asm volatile` keeps it from merging this
+// computation with the one at kernel entry.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 16 bytes per lane global -> LDS through a buffer descriptor without touching VGPRs (`buffer_load_dwordx4 ... lds`):
 // per-lane byte offset `voff` + wave-uniform byte offset `soff`, out-of-range -> zeros; lds_wave_base is wave-uniform,

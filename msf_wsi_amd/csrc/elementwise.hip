@@ -332,6 +332,83 @@ __global__ void stem_pool_fwd_kernel(const T* __restrict__ c0, const float* __re
     }
 }
 
+// The same by COLUMN WALK (round 4, the default): a thread owns one output column q and one channel chunk and walks down
+// the output rows of one image.  Window row 2p+1 of output row p is window row 2(p+1)-1 of output row p+1: its
+// transformed values' horizontal maximum (value + column index, the first one on ties) is carried in registers, so each
+// input row is loaded and transformed ONCE per column -- 6 loads per output instead of 9 -- and the result (value and
+// first-maximum position in (r, s) order) is the per-window kernel's bit for bit.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_fwd_walk_kernel(const T* __restrict__ c0, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, T* __restrict__ out,
+                                                                 unsigned char* __restrict__ amax, int N, int H, int W, int C,
+                                                                 int P, int Q, int cpp, int qgroups, long ntask) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cols = 64 / cpp;
+    const int kc = lane % cpp, jc = lane / cpp;
+    const int ch = kc * VEC;
+    const long task = (long)blockIdx.x * 4 + wave;
+    if (task >= ntask) return;
+    const int n = (int)(task / qgroups);
+    const int q = (int)(task - (long)n * qgroups) * cols + jc;
+    if (q >= Q) return;
+    float sc[VEC], sh[VEC], cv[VEC];
+    int ci[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        sc[e] = scale[ch + e];
+        sh[e] = shift[ch + e];
+        cv[e] = -INFINITY;  // carried odd row (none above the first window row)
+        ci[e] = 0;
+    }
+    for (int p = 0; p < P; ++p) {
+        float best[VEC];
+        int bidx[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            best[e] = cv[e];
+            bidx[e] = ci[e];       // r = 0: position code = s of the carried row
+            cv[e] = -INFINITY;
+            ci[e] = 0;
+        }
+#pragma unroll
+        for (int r = 1; r < 3; ++r) {
+            const int h = 2 * p - 1 + r;
+            if (h >= H) continue;
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                const int w = 2 * q - 1 + s2;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float f[VEC];
+                unpack16<T>(*reinterpret_cast<const uint4*>(c0 + (((long)n * H + h) * W + w) * C + ch), f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float v = round_to<T>(fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f));
+                    if (v > best[e]) {
+                        best[e] = v;
+                        bidx[e] = r * 3 + s2;
+                    }
+                    if (r == 2 && v > cv[e]) {  // the odd row's own first maximum: row r = 0 of the next window
+                        cv[e] = v;
+                        ci[e] = s2;
+                    }
+                }
+            }
+        }
+        const long o = (((long)n * P + p) * Q + q) * C + ch;
+        *reinterpret_cast<uint4*>(out + o) = pack16<T>(best);
+        unsigned char* ap = amax + o;
+        if (VEC == 8) {
+            uint2 pk;
+            pk.x = bidx[0] | (bidx[1] << 8) | (bidx[2] << 16) | (bidx[3] << 24);
+            pk.y = bidx[4 % VEC] | (bidx[5 % VEC] << 8) | (bidx[6 % VEC] << 16) | (bidx[7 % VEC] << 24);
+            *reinterpret_cast<uint2*>(ap) = pk;
+        } else {
+            *reinterpret_cast<unsigned*>(ap) = bidx[0] | (bidx[1] << 8) | (bidx[2] << 16) | (bidx[3] << 24);
+        }
+    }
+}
+
 // backward of the above: g0 = relu'(.) * sum over the (<= 4) windows that selected this pixel of dp,
 // plus the BatchNorm-backward sums  S1 = sum g0,  S2 = sum g0*c0
 template <typename T>
@@ -531,6 +608,173 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_patch_kernel(const T* __res
         }
     }
     if (sums != nullptr) col_commit<2, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same by COLUMN WALK (round 4, the default for the training path: g0 + sums, no second gradient, no k1 mode).
+// The per-pixel kernel above loads the gradient + argmax chunks of every window that covers a pixel: 2.25 window loads
+// (24 bytes each) per pixel, 344 bytes through the vector memory path per 64 bytes of output, and each window row is
+// fetched by three input rows at three different times (measured 2.8 TB/s algorithmic, 1.55x over-fetch).  Here a thread
+// owns one window column q and one channel chunk and walks down the window rows p of ONE image:
+//   * it loads window (p, q) ONCE (16 bytes of gradient + VEC argmax bytes, kept packed), keeps the previous row's in
+//     registers and takes the right-hand neighbour's (p, q+1) from the lane CPP further on (ds_bpermute; the last
+//     column of a wave loads it itself) -- 24 bytes of window data per FOUR output pixels instead of 216;
+//   * per step it emits the 2 x 2 pixels (2p-1, 2p) x (2q, 2q+1): a pixel in an odd row / column sits under two window
+//     rows / columns, one in an even row / column under one, so every contribution is in registers by then;
+//   * c0 is read and g0 written exactly once, in whole 128-byte lines, and the walk keeps each wave on one DRAM page run.
+// position codes r*3+s of the window (p', q') that selected pixel (h, w): r = h - (2p'-1), s = w - (2q'-1).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void pool_take(float (&g)[ElemTraits<T>::VEC], const uint4& dpk, unsigned long long ab,
+                                          unsigned code) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    float d[VEC];
+    unpack16<T>(dpk, d);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+        if (((unsigned)(ab >> (8 * e)) & 0xffu) == code) g[e] += d[e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bwd_walk_kernel(
+    const T* __restrict__ dp, const unsigned char* __restrict__ amax, const T* __restrict__ c0,
+    const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ g0, double* sums, int nshard,
+    int N, int H, int W, int C, int P, int Q, int cpp /* chunks per pixel = C / VEC */, int qgroups, long ntask) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    __shared__ float red[4][2][64 * 8];  // [wave][slot][chunk * VEC + e], C <= 64 * 8 / ... (C == cpp * VEC <= 512)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cols = 64 / cpp;            // window columns per wave
+    const int kc = lane % cpp, jc = lane / cpp;
+    const int ch = kc * VEC;
+    const long task = (long)blockIdx.x * 4 + wave;  // (image, column group)
+    float acc[2][VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = 0.f;
+    if (task < ntask) {
+        const int n = (int)(task / qgroups);
+        const int q = (int)(task - (long)n * qgroups) * cols + jc;
+        const bool qok = q < Q;
+        const bool rok = q + 1 < Q;            // the right-hand neighbour column exists
+        const bool last_col = jc == cols - 1;  // its window data is not in this wave: loaded directly
+        float sc[VEC], sh[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sc[e] = scale[ch + e];
+            sh[e] = shift[ch + e];
+        }
+        const int w0 = 2 * q, w1 = 2 * q + 1;
+        const bool w0ok = qok && w0 < W, w1ok = qok && w1 < W;
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4 pv = z4, pvR = z4;                                   // window row p-1 (own column, right neighbour)
+        unsigned long long pa = ~0ull, paR = ~0ull;                // no position code matches 0xff
+        auto load_win = [&](int p, int qq, uint4& d, unsigned long long& a) {
+            const long o = (((long)n * P + p) * Q + qq) * C + ch;
+            d = *reinterpret_cast<const uint4*>(dp + o);
+            if constexpr (VEC == 8) a = *reinterpret_cast<const unsigned long long*>(amax + o);
+            else a = 0xffffffff00000000ull | *reinterpret_cast<const unsigned*>(amax + o);
+        };
+        auto emit = [&](int h, int w, float (&g)[VEC]) {
+            const long m = ((long)n * H + h) * W + w;
+            float x[VEC];
+            unpack16<T>(*reinterpret_cast<const uint4*>(c0 + m * C + ch), x);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (!(fmaf(x[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
+                g[e] = round_to<T>(g[e]);
+                acc[0][e] += g[e];
+                acc[1][e] = fmaf(g[e], x[e], acc[1][e]);
+            }
+            if (g0 != nullptr) *reinterpret_cast<uint4*>(g0 + m * C + ch) = pack16<T>(g);
+        };
+        for (int p = 0; p <= P; ++p) {
+            // window row p (none at p == P: only the last odd input row 2P-1 is left to emit)
+            uint4 cv = z4, cvR = z4;
+            unsigned long long ca = ~0ull, caR = ~0ull;
+            if (p < P) {
+                if (qok) load_win(p, q, cv, ca);
+                // the neighbour's chunk from the lane cpp further on (every lane takes part in the shuffle)
+                cvR.x = __shfl_down(cv.x, cpp, 64);
+                cvR.y = __shfl_down(cv.y, cpp, 64);
+                cvR.z = __shfl_down(cv.z, cpp, 64);
+                cvR.w = __shfl_down(cv.w, cpp, 64);
+                const unsigned alo = __shfl_down((unsigned)ca, cpp, 64), ahi = __shfl_down((unsigned)(ca >> 32), cpp, 64);
+                caR = ((unsigned long long)ahi << 32) | alo;
+                if (last_col) {
+                    cvR = z4;
+                    caR = ~0ull;
+                    if (rok) load_win(p, q + 1, cvR, caR);
+                }
+                if (!rok) {
+                    cvR = z4;
+                    caR = ~0ull;
+                }
+            }
+            const int ho = 2 * p - 1, he = 2 * p;
+            if (ho >= 0 && ho < H) {  // odd row 2p-1: windows p-1 (r = 2) and p (r = 0)
+                if (w0ok) {
+                    float g[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+                    pool_take<T>(g, pv, pa, 7u);
+                    pool_take<T>(g, cv, ca, 1u);
+                    emit(ho, w0, g);
+                }
+                if (w1ok) {
+                    float g[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+                    pool_take<T>(g, pv, pa, 8u);
+                    pool_take<T>(g, pvR, paR, 6u);
+                    pool_take<T>(g, cv, ca, 2u);
+                    pool_take<T>(g, cvR, caR, 0u);
+                    emit(ho, w1, g);
+                }
+            }
+            if (p < P && he < H) {    // even row 2p: window p only (r = 1)
+                if (w0ok) {
+                    float g[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+                    pool_take<T>(g, cv, ca, 4u);
+                    emit(he, w0, g);
+                }
+                if (w1ok) {
+                    float g[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+                    pool_take<T>(g, cv, ca, 5u);
+                    pool_take<T>(g, cvR, caR, 3u);
+                    emit(he, w1, g);
+                }
+            }
+            pv = cv;
+            pa = ca;
+            pvR = cvR;
+            paR = caR;
+        }
+    }
+    if (sums == nullptr) return;
+    // per channel: sum over the wave's columns (lanes kc, kc + cpp, ...), then over the four waves, then fp64 atomics
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float v = acc[s][e];
+            for (int off = cpp; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            acc[s][e] = v;
+        }
+    if (lane < cpp) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) red[wave][s][lane * VEC + e] = acc[s][e];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) {
+        const int s = i / C, c = i - s * C;
+        const float t = red[0][s][c] + red[1][s][c] + red[2][s][c] + red[3][s][c];
+        atomicAdd(sums + ((long)(blockIdx.x % nshard) * 2 + s) * C + c, (double)t);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1192,11 +1436,30 @@ extern "C" int msfwsi_bn_act_sum(int dtype, const void* c, const float* scale, c
     return msfwsi_launch_status();
 }
 
+static long g_pool_bwd_patch = 0;
+static long g_pool_bwd_walk = 1;  // msfwsi_set_tuning(16, .): 0 = the per-window / per-pixel max-pool kernels (A/B); 1 = column walk
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_patch(long v) { g_pool_bwd_patch = v; }
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_walk(long v) { g_pool_bwd_walk = v; }
+
 extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scale, const float* shift, void* out,
                                     unsigned char* argmax, int N, int H, int W, int C, void* stream) {
     MSFWSI_CHECK_ARG(dtype_ok(dtype) && c0 && scale && shift && out && argmax && N > 0 && H > 1 && W > 1);
     MSFWSI_CHECK_ARG(C % vec_of(dtype) == 0);
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    {   // column walk: each input row loaded once per output column (see stem_pool_fwd_walk_kernel)
+        const int cpp = C / vec_of(dtype);
+        if (g_pool_bwd_walk && cpp >= 1 && cpp <= 64 && (cpp & (cpp - 1)) == 0) {
+            const int cols = 64 / cpp;
+            const int qgroups = (Q + cols - 1) / cols;
+            const long ntask = (long)N * qgroups;
+            const long nblk = (ntask + 3) / 4;
+            if (nblk > 0x7fffffffL) return MSFWSI_EINVAL;
+            MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_fwd_walk_kernel<T>, dim3((unsigned)nblk), dim3(256), 0,
+                                   ST(stream), (const T*)c0, scale, shift, (T*)out, argmax, N, H, W, C, P, Q, cpp, qgroups,
+                                   ntask));
+            return msfwsi_launch_status();
+        }
+    }
     const long total = (long)N * P * Q * (C / vec_of(dtype));
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_fwd_kernel<T>, dim3(stream_grid(total)), dim3(kThreads), 0, ST(stream),
                            (const T*)c0, scale, shift, (T*)out, argmax, N, H, W, C, P, Q));
@@ -1207,8 +1470,6 @@ extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scal
 // 568-571 ms/step with it against 563.6 without -- fewer bytes through the vector memory path, but four pixels per
 // thread need ~180 VGPRs (hipcc schedules them together: two waves per SIMD, or 150-300 bytes of scratch when capped at
 // 128 / 96 registers), too few waves in flight for a streaming kernel; the per-pixel kernel (109 VGPRs) stays the default
-static long g_pool_bwd_patch = 0;
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_patch(long v) { g_pool_bwd_patch = v; }
 
 extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax, const void* c0,
                                     const float* scale, const float* shift, void* g0, double* sums, int nshard,
@@ -1221,6 +1482,21 @@ extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned ch
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     const int vec = vec_of(dtype);
     const size_t lds = (size_t)kThreads * 2 * vec * sizeof(float);
+    // column walk (see stem_pool_bwd_walk_kernel): the training path's form -- gated gradient + sums, chunks per pixel a
+    // power of two <= 64 (the stem: 64 channels = 8 chunks of 16-bit / 16 of fp32)
+    const int cpp = C / vec;
+    if (g_pool_bwd_walk && k1 == nullptr && dact == nullptr && cpp >= 1 && cpp <= 64 && (cpp & (cpp - 1)) == 0 &&
+        C <= 512) {
+        const int cols = 64 / cpp;
+        const int qgroups = (Q + cols - 1) / cols;
+        const long ntask = (long)N * qgroups;
+        const long nblk = (ntask + 3) / 4;
+        if (nblk > 0x7fffffffL) return MSFWSI_EINVAL;
+        MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_walk_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, ST(stream),
+                               (const T*)dp, argmax, (const T*)c0, scale, shift, (T*)g0, sums, nshard, N, H, W, C, P, Q,
+                               cpp, qgroups, ntask));
+        return msfwsi_launch_status();
+    }
     if (g_pool_bwd_patch) {  // by 2x2 input patches: 4 window loads per 4 pixels instead of 9
         ColGrid gp = make_col_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2), C, vec, 4096);
         MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_patch_kernel<T>, gp.grid, dim3(kThreads), lds, ST(stream),

@@ -1170,6 +1170,7 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v)
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_os_min(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_patch(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_max_splits(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_walk(long v);
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
@@ -1206,6 +1207,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 15) {
         msfwsi_wgrad_set_max_splits(value);
+        return MSFWSI_OK;
+    }
+    if (key == 16) {
+        msfwsi_pool_bwd_set_walk(value);
         return MSFWSI_OK;
     }
     if (key == 4) {

@@ -221,15 +221,16 @@ __global__ __launch_bounds__(512, 4) void stem_ws_kernel(const StemParams prm) {
                 ssq[e] += __shfl_xor(ssq[e], off, 64);
             }
         }
-        if (lane < CPR) {
+        const int lane_e = fresh_lane(), tid_e = wave * 64 + lane_e;  // re-derived: not carried through the main loop
+        if (lane_e < CPR) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                red[(wave * BN + lane * VEC + e) * 2 + 0] = ssum[e];
-                red[(wave * BN + lane * VEC + e) * 2 + 1] = ssq[e];
+                red[(wave * BN + lane_e * VEC + e) * 2 + 0] = ssum[e];
+                red[(wave * BN + lane_e * VEC + e) * 2 + 1] = ssq[e];
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * BN; i += NT) {
+        for (int i = tid_e; i < 2 * BN; i += NT) {
             const int col = i % BN, which = i / BN;
             float t = 0.f;
 #pragma unroll

@@ -634,11 +634,13 @@ __global__ __launch_bounds__(512) void wgrad_os_kernel(const WgWParams prm) {
     }
 
     // dW[co][t][ci] += partial: lane -> ci (contiguous), registers -> co
+    const int lane_e = fresh_lane();  // re-derived (common.h): kept since kernel entry it cost 16-20 bytes of scratch per lane
+    const int l31_e = lane_e & 31, lh_e = lane_e >> 5;
     auto flush = [&](const f32x16& a, int t, int cb, int ib) {
-        const int j = t * 64 + ib * 32 + l31;
+        const int j = t * 64 + ib * 32 + l31_e;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const int co = cb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh_e;
             atomicAdd(prm.dw + (long)co * 576 + j, a[reg]);
         }
     };

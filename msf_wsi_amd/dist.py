@@ -161,31 +161,71 @@ class FlatGroups:
         for g in self.g:
             g.zero_()
 
+    def range_of(self, gi: int, name_prefix: str) -> Tuple[int, int]:
+        """[lo, hi) element range of group gi's flat buffers that holds the parameters whose names start with
+        `name_prefix` (e.g. "inter_projector.3."): they are adjacent in named_parameters() order, hence contiguous"""
+        idx = [i for i, n in enumerate(self.names[gi]) if n.startswith(name_prefix)]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError(f"no contiguous parameter range for prefix {name_prefix!r} in group {self.prefixes[gi]!r}")
+        lo = self.offsets[gi][idx[0]]
+        hi = self.offsets[gi][idx[-1] + 1] if idx[-1] + 1 < len(self.offsets[gi]) else self.sizes[gi]
+        return lo, hi
+
 
 class GradReducer:
-    """Per-group asynchronous gradient averaging (the DDP reduction of tools/ssl_train.py:170)."""
+    """Per-group asynchronous gradient averaging (the DDP reduction of tools/ssl_train.py:170).
+
+    `launch(group)` averages a whole optimizer group in one collective; `launch(group, part=prefix)` only the slice of
+    it that holds the parameters named `prefix*` -- the backward schedule calls it per scale of the `inter_` heads (80-95 %
+    of all gradient bytes: 4 x (projector + predictor) = 8 buckets, the largest 4 GB), each as soon as that scale's weight
+    gradients are complete, so RCCL starts on the first bucket while the next head is still in backward and the exchange
+    is several medium messages instead of one 6.3 GB one (DDP buckets at 25 MB, ssl_train.py:170; xGMI rings are per-link
+    bound, and nothing is gained below ~100 MB per message).  `launch(group)` after parts sends what is left of it."""
 
     def __init__(self, flats: FlatGroups, group=None):
         self.flats = flats
         self.group = group
-        self.pending: List[Tuple[int, object]] = []
+        self.pending: List[Tuple[Optional[torch.Tensor], object]] = []
         self.world = world_size(group)
         # MSFWSI_FORCE_SYNC: rehearse the collective path with a single rank (RCCL calls execute, results unchanged)
         self.active = self.world > 1 or (os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0" and dist.is_available()
                                          and dist.is_initialized())
         self.op = probe_collectives(group, flats.g[0].device) if self.active else None
+        self.sent: Dict[int, List[Tuple[int, int]]] = {}  # group index -> element ranges already launched this step
+        self.launches = 0                                   # collectives launched since the last wait()
+        self.bytes = 0
+        self.launches_last_step = 0                         # ... and of the step that the last wait() closed
+        self.bytes_last_step = 0
 
-    def launch(self, group_name: str):
+    def _send(self, buf: torch.Tensor):
+        work = dist.all_reduce(buf, op=self.op, group=self.group, async_op=True)
+        self.pending.append((None if self.op == dist.ReduceOp.AVG else buf, work))
+        self.launches += 1
+        self.bytes += buf.numel() * buf.element_size()
+
+    def launch(self, group_name, part: Optional[str] = None):
         if not self.active:
             return
         gi = group_name if isinstance(group_name, int) else {"context": 0, "target": 1, "inter": 2}[group_name]
         buf = self.flats.g[gi]
-        work = dist.all_reduce(buf, op=self.op, group=self.group, async_op=True)
-        self.pending.append((-1 if self.op == dist.ReduceOp.AVG else gi, work))
+        if part is not None:
+            lo, hi = self.flats.range_of(gi, part)
+            self.sent.setdefault(gi, []).append((lo, hi))
+            self._send(buf[lo:hi])
+            return
+        done = sorted(self.sent.pop(gi, []))
+        pos = 0
+        for lo, hi in done + [(buf.numel(), buf.numel())]:  # whatever no part covered
+            if lo > pos:
+                self._send(buf[pos:lo])
+            pos = max(pos, hi)
 
     def wait(self):
-        for gi, work in self.pending:
+        for buf, work in self.pending:
             work.wait()
-            if gi >= 0:
-                self.flats.g[gi].mul_(1.0 / self.world)
+            if buf is not None:  # backends without AVG (gloo): SUM, then scale
+                buf.mul_(1.0 / self.world)
         self.pending = []
+        self.sent = {}
+        self.launches_last_step, self.bytes_last_step = self.launches, self.bytes
+        self.launches = self.bytes = 0

@@ -18,6 +18,7 @@ There is no CPU / eager-torch fallback: CPU tensors raise.
 from __future__ import annotations
 
 import os
+import threading
 import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -103,6 +104,8 @@ class StepRec:
     tgt_sorted: Dict[Tuple[int, int], torch.Tensor] = field(default_factory=dict)
     nosave: set = field(default_factory=set)
     dual: bool = False  # view-1 passes ran on the side stream (their activations live in that stream's pool)
+    tri: bool = False   # ... and both context passes on the third stream
+    pair_bwd: bool = True  # the memory plan allows the two views' backward passes side by side (lockstep)
 
 
 def chan_pad(dtype: torch.dtype) -> int:
@@ -194,14 +197,18 @@ class GradStore:
     def __init__(self):
         self.bufs: Dict[int, torch.Tensor] = {}
         self.params: Dict[int, torch.Tensor] = {}
+        self._lock = threading.Lock()  # two view passes may run their backward on two host threads (_ViewPair)
 
     def get(self, param: torch.Tensor) -> torch.Tensor:
         b = self.bufs.get(id(param))
         if b is None:
-            phys = WeightStore.physical(param)
-            b = torch.zeros(phys.shape, dtype=torch.float32, device=phys.device)
-            self.bufs[id(param)] = b
-            self.params[id(param)] = param
+            with self._lock:
+                b = self.bufs.get(id(param))
+                if b is None:
+                    phys = WeightStore.physical(param)
+                    b = torch.zeros(phys.shape, dtype=torch.float32, device=phys.device)
+                    self.bufs[id(param)] = b
+                    self.params[id(param)] = param
         return b
 
     def logical(self, param: torch.Tensor) -> Optional[torch.Tensor]:
@@ -209,6 +216,77 @@ class GradStore:
         if b is None:
             return None
         return b.permute(0, 3, 1, 2) if param.dim() == 4 else b
+
+
+class _ViewPair:
+    """Rendezvous of the two view passes of ONE encoder running in lockstep on two host threads (Engine._run_views).
+
+    Why: with SyncBatchNorm every BatchNorm call exchanges one small packed fp64 message per direction, and the two
+    views of an encoder are separate BatchNorm batches (backbone.py:140-145) that issue the SAME sequence of exchanges.
+    Run one after the other that is 4 x 154 = 616 latency-bound all-reduces per ResNet-50 step; run in lockstep, both
+    views' vectors travel in ONE message per BatchNorm and direction (308).  The passes still enqueue on one HIP stream:
+    a thread here is a coroutine with a stack, not a second stream -- kernels of the two views interleave in launch
+    order, data dependencies inside a view follow that view's program order, and the collective of an exchange is
+    enqueued by whichever view arrives second, i.e. after both producers and before either consumer.
+
+    exchange(v, fn): both views call it at the same point of their sequence; the last arriver runs fn() (the one
+    collective); everybody leaves after it has been enqueued.  turn(v): view 1 waits until view 0 has passed the same
+    point (the running-statistics update of a module happens for view 0 first, as in the reference)."""
+
+    def __init__(self):
+        self.cv = threading.Condition()
+        self.count = [0, 0]      # exchanges entered per view
+        self.done = 0            # exchanges whose collective has been enqueued
+        self.turns = 0           # turn points view 0 has passed
+        self.tcount = [0, 0]
+        self.failed: Optional[BaseException] = None
+
+    def fail(self, e: BaseException):
+        with self.cv:
+            if self.failed is None:
+                self.failed = e
+            self.cv.notify_all()
+
+    def _check(self):
+        if self.failed is not None:
+            raise RuntimeError("the other view pass of this encoder failed") from self.failed
+
+    def exchange(self, v: int, fn):
+        with self.cv:
+            self._check()
+            self.count[v] += 1
+            seq = self.count[v]
+            if self.count[1 - v] >= seq:  # the other view is already here: this thread issues the collective
+                try:
+                    fn()
+                except BaseException as e:  # noqa: BLE001 -- wake the partner, then re-raise here
+                    self.failed = e
+                    self.cv.notify_all()
+                    raise
+                self.done = seq
+                self.cv.notify_all()
+                return
+            while self.done < seq:
+                if not self.cv.wait(timeout=600.0):
+                    self.failed = TimeoutError("view passes out of step: the partner never reached exchange %d" % seq)
+                self._check()
+
+    def turn_wait(self, v: int):
+        """view 1: block until view 0 has passed its matching turn point; view 0: nothing to wait for"""
+        with self.cv:
+            self.tcount[v] += 1
+            if v == 0:
+                return
+            while self.turns < self.tcount[1]:
+                if not self.cv.wait(timeout=600.0):
+                    self.failed = TimeoutError("view passes out of step at a turn point")
+                self._check()
+
+    def turn_done(self, v: int):
+        if v == 0:
+            with self.cv:
+                self.turns += 1
+                self.cv.notify_all()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -219,6 +297,7 @@ class Engine:
         self._sync_bn = sync_bn
         self.update_running = True
         self._drop_c3 = False
+        self._pair_bwd = True
         self.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")  # off | t1 | targets | auto
         self.materialize_3x3 = os.environ.get("MSFWSI_MATERIALIZE_3X3", "1") != "0"
         self.materialize_wgrad = os.environ.get("MSFWSI_MATERIALIZE_WGRAD", "1") != "0"
@@ -243,6 +322,8 @@ class Engine:
         self.stem_fuse_bnbwd = os.environ.get("MSFWSI_STEM_FUSE_BNBWD", "1") != "0"  # bn1 backward inside the stem's dW
         self.pair_head_wgrad = os.environ.get("MSFWSI_PAIR_HEAD_WGRAD", "1") != "0"  # one dW launch for both views
         self.pair_head_fwd = os.environ.get("MSFWSI_PAIR_HEAD_FWD", "1") != "0"  # ... and one forward GEMM per layer
+        # gradient exchange of the fuser heads in per-scale buckets, each launched when its weight gradients are complete
+        self.bucket_inter = os.environ.get("MSFWSI_BUCKET_INTER", "1") != "0"
         # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
         # stem_pool_bwd + bn_bwd_apply (the pool-backward window logic is VALU-bound, not byte-bound): off
         self.stem_two_pass = os.environ.get("MSFWSI_STEM_TWO_PASS", "0") != "0"
@@ -257,6 +338,7 @@ class Engine:
         self._plan_cache: Dict[tuple, Tuple[frozenset, bool]] = {}
         self._mode_override: Optional[str] = None  # "targets" while a model built with use_checkpoint=True runs
         self._msgs: Dict[tuple, torch.Tensor] = {}
+        self._msg_lock = threading.Lock()
         # rehearsal switch: run the cross-replica code path (collectives included) even with one rank, so that the
         # RCCL calls of the SyncBatchNorm exchange execute on a one-GPU box
         self.force_sync = os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0"
@@ -265,19 +347,40 @@ class Engine:
         # chip usually holds an MFMA-bound kernel of one beside an HBM-bound kernel of the other, and tails / launch
         # gaps of one are filled by the other.  Per BatchNorm module the running-statistics update of view 1 waits for
         # the one of view 0 (an event), which keeps the reference's update order.
-        # Off by default (MSFWSI_DUAL_STREAM=1 turns it on): it measured -2 % step time on one GPU (and with more ranks
-        # also hides each view's SyncBatchNorm exchanges behind the other view's compute), but the second allocator
-        # pool raises the reserved memory of BASELINE config 2 from 233 to 260 GiB of the card's 268 GiB -- too little
-        # headroom beside RCCL's buffers to be the default -- and per-kernel timings stop being those of isolated kernels
+        # Round 4: ON BY DEFAULT ON ONE RANK from the second step of a shape on, when the memory plan of the previous step
+        # found room for a second set of transients (`_dual_ok`; the first step of a shape calibrates the plan on one
+        # stream): 540.6 -> 523.3 ms/step on BASELINE config 2 (A/B on one box, two rounds, gpurun_out/r4_ab_dual.log), at
+        # 257 GiB reserved instead of 233.5 (the side stream's allocator pool).  With more than one rank it stays off --
+        # RCCL's buffers need that memory -- and the views run in LOCKSTEP instead (coalesced SyncBatchNorm messages,
+        # _ViewPair).  MSFWSI_DUAL_STREAM=0 / 1 forces it off / on.  Per-kernel timings are those of two overlapping
+        # streams when it is on.
         env = os.environ.get("MSFWSI_DUAL_STREAM")
-        self.dual_stream: Optional[bool] = False if env is None else env != "0"
+        self.dual_stream: Optional[bool] = None if env is None else env != "0"
+        self._dual_ok: Dict[tuple, bool] = {}
+        self._dual_started: set = set()
+        # the automatic multi-stream schedule needs an owner whose gradient accumulators exist before the backward starts
+        # (the fused trainers: train.PretrainStep sets this); the process-wide default engine behind the plain model API
+        # accumulates into lazily created buffers from autograd's thread and stays on one stream
+        self.allow_multistream = False
+        # ... and with two streams active, the two CONTEXT passes (1/17 of the images, launches too small to fill the chip:
+        # 45 ms of a 545 ms step for 6 % of the work) run on a THIRD stream beside the target passes, forward and backward
+        # (different encoder, different parameters: no ordering between them and the target passes).  Needs the
+        # memory calibration of an earlier step of the same shape (`_calib`).  MSFWSI_CTX_STREAM=0 turns it off.
+        self.ctx_stream = os.environ.get("MSFWSI_CTX_STREAM", "1") != "0"
+        self._calib: Dict[tuple, Tuple[float, float]] = {}
         self._side: Dict[str, torch.cuda.Stream] = {}
         self._bn_order: Optional[Tuple[str, dict]] = None
+        # Cross-replica runs: the two views of an encoder in LOCKSTEP on two host threads, one SyncBatchNorm message per
+        # BatchNorm and direction for both views (_ViewPair).  On whenever statistics are exchanged (more than one rank,
+        # or MSFWSI_FORCE_SYNC) and the dual-stream schedule is off; MSFWSI_COALESCE_VIEWS=0 restores one pass after the other
+        self.coalesce_views = os.environ.get("MSFWSI_COALESCE_VIEWS", "1") != "0"
+        self._tls = threading.local()   # .pair = (_ViewPair, view index) inside a lockstep pass
         # bookkeeping a trainer / bench.py reports: the collectives this engine issued since `reset_counters`, and
         # the recompute plan of the last forward ("keep-all", "recompute:t1", "recompute:t0,t1" [+ ",drop-c3"])
         self.collectives = 0
         self.collectives_last_step = 0
         self.last_plan = "keep-all"
+        self.last_shape: Optional[tuple] = None
 
     def reset_counters(self):
         self.collectives = 0
@@ -311,8 +414,8 @@ class Engine:
             return dist.get_world_size(self.group)
         return 1
 
-    def _side_stream(self, dev) -> "torch.cuda.Stream":
-        key = str(dev)
+    def _side_stream(self, dev, which: str = "side") -> "torch.cuda.Stream":
+        key = f"{dev}/{which}"
         if key not in self._side:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
@@ -347,12 +450,72 @@ class Engine:
             buf = self._msgs[key] = torch.empty(n, dtype=torch.float64, device=dev)
         return buf
 
+    def _pair_buf(self, kind: str, n: int, dev) -> torch.Tensor:
+        """[2][n] fp64 message buffer of a lockstep exchange: row v is view v's packed vector, the collective sends both.
+        Re-use across exchanges is safe for the reason given in _msg_buf; the two views only ever touch their own row."""
+        key = (kind + "2", n, str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        buf = self._msgs.get(key)
+        if buf is None:
+            with self._msg_lock:
+                buf = self._msgs.get(key)
+                if buf is None:
+                    buf = self._msgs[key] = torch.empty(2, n, dtype=torch.float64, device=dev)
+        return buf
+
     def _sync(self, bn: nn.Module) -> bool:
         if self._world() == 1:
             return self.force_sync and dist.is_available() and dist.is_initialized()
         if self._sync_bn is not None:
             return self._sync_bn
         return isinstance(bn, nn.SyncBatchNorm)
+
+    def _pair_collective(self, both: torch.Tensor):
+        sync_sums(both.view(-1), self.group, force=self.force_sync)
+        self.collectives += 1
+
+    def _lockstep(self) -> bool:
+        """the two views of an encoder run as a lockstep pair (see _ViewPair)"""
+        if not self.coalesce_views:
+            return False
+        if self._world() > 1:
+            return True
+        return self.force_sync and dist.is_available() and dist.is_initialized()
+
+    def _run_views(self, fn0, fn1):
+        """run fn0() (view 0, on this thread) and fn1() (view 1, on a helper thread) as a lockstep pair on the CURRENT
+        stream; returns (result0, result1).  The helper thread inherits nothing implicitly: device, stream and the no-grad
+        mode are set explicitly (they are thread-local in torch)."""
+        pair = _ViewPair()
+        dev = torch.cuda.current_device()
+        stream = torch.cuda.current_stream(dev)
+        res: List[object] = [None, None]
+        err: List[Optional[BaseException]] = [None, None]
+
+        def body(v, fn):
+            self._tls.pair = (pair, v)
+            try:
+                res[v] = fn()
+            except BaseException as e:  # noqa: BLE001 -- handed to the calling thread
+                err[v] = e
+                pair.fail(e)
+            finally:
+                self._tls.pair = None
+
+        def helper():
+            with torch.cuda.device(dev), torch.cuda.stream(stream), torch.no_grad():
+                body(1, fn1)
+
+        t = threading.Thread(target=helper, name="msfwsi-view1", daemon=True)
+        t.start()
+        body(0, fn0)
+        t.join()
+        for e in err:
+            if e is not None and not (isinstance(e, RuntimeError) and "other view pass" in str(e)):
+                raise e
+        for e in err:
+            if e is not None:
+                raise e
+        return res[0], res[1]
 
     # ---- BatchNorm helpers ---------------------------------------------------------------------
     @staticmethod
@@ -375,11 +538,19 @@ class Engine:
         dev = stats.device
         vecs = torch.empty(4, Cn, dtype=torch.float32, device=dev)
         total = float(count)
+        pv = getattr(self._tls, "pair", None)
         if self._sync(bn):
-            packed = self._msg_buf("fwd", 2 * Cn, dev)
-            kn.shard_sum(stats, packed)
-            sync_sums(packed, self.group, force=self.force_sync)  # RCCL sum of [sum, sumsq]; equal shards per rank
-            self.collectives += 1
+            if pv is not None:  # lockstep: both views' [sum, sumsq] in ONE message
+                pair, v = pv
+                both = self._pair_buf("fwd", 2 * Cn, dev)
+                kn.shard_sum(stats, both[v])
+                pair.exchange(v, lambda: self._pair_collective(both))
+                packed = both[v]
+            else:
+                packed = self._msg_buf("fwd", 2 * Cn, dev)
+                kn.shard_sum(stats, packed)
+                sync_sums(packed, self.group, force=self.force_sync)  # RCCL sum of [sum, sumsq]; equal shards per rank
+                self.collectives += 1
             stats = packed.view(1, 2, Cn)
             total *= self._world()
         if bn.momentum is None:
@@ -390,9 +561,13 @@ class Engine:
             ev = order[1].get(id(bn))
             if ev is not None:  # view 0's update of this module's running statistics comes first (reference order)
                 torch.cuda.current_stream(dev).wait_event(ev)
+        if pv is not None and track:
+            pv[0].turn_wait(pv[1])  # view 0's update of this module's running statistics is enqueued first
         kn.bn_finalize(stats, total, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps,
                        bn.momentum, bn.running_mean if track else None, bn.running_var if track else None,
                        bn.num_batches_tracked if track else None, vecs[0], vecs[1], vecs[2], vecs[3])
+        if pv is not None and track:
+            pv[0].turn_done(pv[1])
         if order is not None and order[0] == "lead":
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
@@ -408,7 +583,12 @@ class Engine:
         Cn = sums.shape[-1]
         dev = sums.device
         if self._sync(bn):
-            packed = self._msg_buf("bwd", nslots * Cn, dev)
+            pv = getattr(self._tls, "pair", None)
+            if pv is not None:
+                both = self._pair_buf("bwd", nslots * Cn, dev)
+                packed = both[pv[1]]
+            else:
+                packed = self._msg_buf("bwd", nslots * Cn, dev)
             kn.shard_sum(sums, packed)
             k = torch.empty(3, Cn, dtype=torch.float32, device=dev)
             if bn.affine:
@@ -416,8 +596,11 @@ class Engine:
                 # taken from the message buffer before the exchange overwrites it (k is scratch here)
                 kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count, bn.weight, st.mean, st.invstd,
                                    grads.get(bn.weight), grads.get(bn.bias), k[0], k[1], k[2])
-            sync_sums(packed, self.group, force=self.force_sync)
-            self.collectives += 1
+            if pv is not None:  # lockstep: one message for both views (enqueued after both local finalizes)
+                pv[0].exchange(pv[1], lambda: self._pair_collective(both))
+            else:
+                sync_sums(packed, self.group, force=self.force_sync)
+                self.collectives += 1
             kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count,
                                bn.weight if bn.affine else None, st.mean, st.invstd, None, None, k[0], k[1], k[2])
             return k
@@ -426,6 +609,55 @@ class Engine:
                            grads.get(bn.weight) if bn.affine else None, grads.get(bn.bias) if bn.affine else None,
                            k[0], k[1], k[2])
         return k
+
+    def _bn_finalize_views(self, stats2: Sequence[torch.Tensor], counts: Sequence[int], bn: nn.Module) -> List[BNState]:
+        """_bn_finalize for the two views of a head at once (both statistics tensors are at hand on one thread): with
+        cross-replica statistics ONE message carries both views' [sum, sumsq]; view 0's running-statistics update is
+        enqueued first (backbone.py:161-186 calls the head on view 1 first and view 2 second)"""
+        if not (self._sync(bn) and self._lockstep()) or self._bn_frozen(bn):
+            return [self._bn_finalize(st, c, bn) for st, c in zip(stats2, counts)]
+        Cn = stats2[0].shape[-1]
+        dev = stats2[0].device
+        both = self._pair_buf("fwd", 2 * Cn, dev)
+        for v in range(2):
+            kn.shard_sum(stats2[v], both[v])
+        self._pair_collective(both)
+        if bn.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not used by MSF-WSI")
+        track = self.update_running and bn.track_running_stats and bn.training
+        out = []
+        for v in range(2):
+            vecs = torch.empty(4, Cn, dtype=torch.float32, device=dev)
+            total = float(counts[v]) * self._world()
+            kn.bn_finalize(both[v].view(1, 2, Cn), total, bn.weight if bn.affine else None,
+                           bn.bias if bn.affine else None, bn.eps, bn.momentum, bn.running_mean if track else None,
+                           bn.running_var if track else None, bn.num_batches_tracked if track else None,
+                           vecs[0], vecs[1], vecs[2], vecs[3])
+            out.append(BNState(vecs[0], vecs[1], vecs[2], vecs[3], total))
+        return out
+
+    def _bn_bwd_coeffs_views(self, sums2: Sequence[torch.Tensor], nslots: int, which: int, bn: nn.Module,
+                             sts: Sequence[BNState], grads: GradStore) -> List[torch.Tensor]:
+        """_bn_bwd_coeffs for the two views of a head at once: one message for both views' [sum g, sum g*c]"""
+        if not (self._sync(bn) and self._lockstep()) or any(st.frozen for st in sts):
+            return [self._bn_bwd_coeffs(sm, nslots, which, bn, st, grads) for sm, st in zip(sums2, sts)]
+        Cn = sums2[0].shape[-1]
+        dev = sums2[0].device
+        both = self._pair_buf("bwd", nslots * Cn, dev)
+        ks = []
+        for v in range(2):
+            kn.shard_sum(sums2[v], both[v])
+            k = torch.empty(3, Cn, dtype=torch.float32, device=dev)
+            if bn.affine:  # dgamma / dbeta from the LOCAL sums, before the exchange overwrites them
+                kn.bn_bwd_finalize(both[v].view(1, nslots, Cn), nslots, which, sts[v].count, bn.weight, sts[v].mean,
+                                   sts[v].invstd, grads.get(bn.weight), grads.get(bn.bias), k[0], k[1], k[2])
+            ks.append(k)
+        self._pair_collective(both)
+        for v in range(2):
+            kn.bn_bwd_finalize(both[v].view(1, nslots, Cn), nslots, which, sts[v].count,
+                               bn.weight if bn.affine else None, sts[v].mean, sts[v].invstd, None, None,
+                               ks[v][0], ks[v][1], ks[v][2])
+        return ks
 
     # ---- single conv / linear unit ---------------------------------------------------------------
     def _unit_fwd(self, op: nn.Module, bn: Optional[nn.Module], relu: bool, x: torch.Tensor,
@@ -797,7 +1029,7 @@ class Engine:
         return full
 
     def _plan_recompute(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float = 0.0,
-                        shape_key: tuple = ()) -> set:
+                        shape_key: tuple = (), ctx_passes: int = 1) -> set:
         """which encoder passes run features-only in forward, and whether bottleneck conv3 outputs are dropped
         (engine.recompute = off | c3 | t1 | targets | auto).  Sets self._drop_c3 for the remaining passes.
 
@@ -809,36 +1041,59 @@ class Engine:
         collective runs must never depend on a locally measured quantity, or one rank would issue it while its peers
         issue BatchNorm all-reduces (`per_image_bytes` comes from this rank's allocator and only feeds the LOCAL
         proposal that goes into the MAX)."""
-        nosave, drop = self._plan_local(per_image_bytes, B, K, device, c3_fraction)
+        nosave, drop, pair = self._plan_local(per_image_bytes, B, K, device, c3_fraction, ctx_passes)
         if self._world() > 1:
             key = (B, K, tuple(shape_key), self._mode_override or self.recompute, self.fold_bn3)
             hit = self._plan_cache.get(key)
             if hit is None:
-                code = torch.tensor([2 * len(nosave) + int(drop)], dtype=torch.int32, device=device)
+                # most conservative plan of all ranks: more features-only passes > drop conv3 > no side-by-side backward
+                code = torch.tensor([4 * len(nosave) + 2 * int(drop) + int(not pair)], dtype=torch.int32, device=device)
                 dist.all_reduce(code, op=dist.ReduceOp.MAX, group=self.group)
                 self.collectives += 1
                 c = int(code.item())
-                hit = (frozenset([(), ("t1",), ("t0", "t1")][c // 2]), bool(c & 1))
+                hit = (frozenset([(), ("t1",), ("t0", "t1")][c // 4]), bool(c & 2), not (c & 1))
                 self._plan_cache[key] = hit
-            nosave, drop = set(hit[0]), hit[1]
+            nosave, drop, pair = set(hit[0]), hit[1], hit[2]
         self._drop_c3 = drop
+        self._pair_bwd = pair
         self.last_plan = ("recompute:" + ",".join(sorted(nosave)) if nosave else "keep-all") + (",drop-c3" if drop else "")
         return nosave
 
-    def _plan_local(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float):
-        """this rank's own (features-only passes, drop conv3 outputs) choice"""
+    def _plan_known(self, B: int, K: int, shape_key: tuple) -> bool:
+        """the collective plan of this shape has been agreed (only ever true with more than one rank)"""
+        key = (B, K, tuple(shape_key), self._mode_override or self.recompute, self.fold_bn3)
+        return self._world() > 1 and key in self._plan_cache
+
+    def plan_preview(self, B: int, K: int, shape_key: tuple, device, world: int) -> Optional[str]:
+        """the LOCAL memory plan this rank would propose in a `world`-rank run of the shape it has just run (from the
+        calibration of that shape and the memory free right now): what bench.py prints as `plan_at_8_ranks` on a
+        one-GPU box.  None when the shape has not been calibrated."""
+        cal = self._calib.get((B, K) + tuple(shape_key))
+        if cal is None:
+            return None
+        self._world = lambda: world  # instance attribute shadows the method for the duration of the call
+        try:
+            nosave, drop, pair = self._plan_local(cal[0], B, K, device, cal[1], 2)
+        finally:
+            del self._world
+        plan = ("recompute:" + ",".join(sorted(nosave)) if nosave else "keep-all") + (",drop-c3" if drop else "")
+        return plan + (",views-lockstep" + ("" if pair else "(forward only)") if world > 1 else "")
+
+    def _plan_local(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float, ctx_passes: int = 1):
+        """this rank's own (features-only passes, drop conv3 outputs, two views' backward side by side) choice;
+        ctx_passes: context passes whose activations are not allocated yet when this is called"""
         mode = self._mode_override or getattr(self, "recompute", "off")
         if self.fold_bn3 and c3_fraction > 0:  # conv3 outputs are never kept on the folded path
             per_image_bytes *= 1.0 - c3_fraction
             c3_fraction = 0.0
         if mode == "off":
-            return set(), False
+            return set(), False, True
         if mode == "c3":
-            return set(), c3_fraction > 0
+            return set(), c3_fraction > 0, True
         if mode == "t1":
-            return {"t1"}, False
+            return {"t1"}, False, True
         if mode == "targets":
-            return {"t0", "t1"}, False
+            return {"t0", "t1"}, False, True
         free, _ = torch.cuda.mem_get_info(device)
         avail = free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         # head room: 6 GiB for the allocator's fragmentation; with more than one rank another 4 GiB for RCCL's channel
@@ -849,18 +1104,19 @@ class Engine:
         # recomputed conv3) are about a quarter of one full target pass
         one_target = per_image_bytes * B * K
         transients = 0.26 * one_target
-        ctx = per_image_bytes * B  # the second context pass
+        ctx = per_image_bytes * B * ctx_passes  # the second context pass (both, when the plan precedes the first)
         if ctx + 2 * one_target + transients < budget:
-            return set(), False
+            # lockstep backward of the two target passes holds two sets of transients at once
+            return set(), False, ctx + 2 * one_target + 2 * transients < budget
         slim, drop = 1.0, False
         if c3_fraction > 0:
             slim = 1.0 - c3_fraction
             drop = True
             if ctx * slim + 2 * one_target * slim + transients < budget:
-                return set(), drop
+                return set(), drop, False
         if ctx * slim + one_target * slim + transients < budget:
-            return {"t1"}, drop
-        return {"t0", "t1"}, drop
+            return {"t1"}, drop, False
+        return {"t0", "t1"}, drop, False
 
     def encoder_backward(self, ps: EncPass, dfeats: Sequence[Optional[torch.Tensor]], grads: GradStore,
                          dtype: torch.dtype, dmaps: Optional[Sequence[Optional[torch.Tensor]]] = None,
@@ -892,7 +1148,12 @@ class Engine:
             dy, pre = self._block_bwd(rec, dy, gapg, grads, dtype, pre=pre, gate=gate)
             rec.units = []  # release activations
             rec.ds = None
-        # stem: maxpool + relu + bn backward, then the 7x7 weight gradient
+        self._stem_bwd(ps, dy, grads, dtype, dstem)
+
+    def _stem_bwd(self, ps: EncPass, dy: torch.Tensor, grads: GradStore, dtype: torch.dtype,
+                  dstem: Optional[torch.Tensor] = None):
+        """stem: maxpool + relu + bn1 backward, then conv1's weight gradient (resnet.py:234-237 backwards); dy = gradient
+        of the max-pool output [N,P,Q,64]"""
         st, u = ps.stem.st, ps.stem
         H0, W0 = u.desc.P, u.desc.Q
         # two passes over (dy, argmax, c): sums first, then dc0 = k1*g + k2*c0 + k3 with g re-derived on the fly (the
@@ -1204,15 +1465,21 @@ class Engine:
             bias = getattr(lin, "bias", None)
             kn.conv_fwd(d, cur.view(tot, 1, 1, Cin), w, c, bias=bias.data if bias is not None else None)
             nxt_pro: List[Optional[BNState]] = [None, None]
+            sts2: List[Optional[BNState]] = [None, None]
+            if bn is not None:
+                stats2 = []
+                for v in range(2):
+                    stats = kn.new_stats(K, 2, dev)
+                    kn.colstats(c[offs[v]:offs[v] + rows[v]], stats)  # fp64 column statistics (see _unit_fwd: the heads' cancellation problem)
+                    stats2.append(stats)
+                sts2 = self._bn_finalize_views(stats2, rows, bn)
             for v in range(2):
                 cv = c[offs[v]:offs[v] + rows[v]]
                 xv = raw[offs[v]:offs[v] + rows[v]].view(rows[v], 1, 1, Cin)
                 dv = kn.conv_desc(dtype, rows[v], 1, 1, Cin, K, 1, 1, 1, 0)
                 u = Unit(lin, bn, relu, dv, xv, pros[v], cv)
                 if bn is not None:
-                    stats = kn.new_stats(K, 2, dev)
-                    kn.colstats(cv, stats)  # fp64 column statistics (see _unit_fwd: the heads' cancellation problem)
-                    u.st = self._bn_finalize(stats, rows[v], bn)
+                    u.st = sts2[v]
                 units[v].append(u)
                 if bn is not None and not relu:
                     out = torch.empty(rows[v], K, dtype=dtype, device=dev)
@@ -1273,10 +1540,10 @@ class Engine:
             Cin, Kout = u0.desc.C, u0.desc.K
             xcat = torch.empty(sum(rows), 1, 1, Cin, dtype=dtype, device=dev)
             dcat = torch.empty(sum(rows), 1, 1, Kout, dtype=dtype, device=dev)
-            off = 0
-            for v, u in enumerate(us):
-                dslot = dcat[off:off + rows[v]].view(rows[v], Kout)
-                if u.bn is not None:
+            ks2 = None
+            if u0.bn is not None:  # both views' backward sums first: their exchange is ONE message (_bn_bwd_coeffs_views)
+                sums2 = []
+                for v, u in enumerate(us):
                     Cn = u.c.shape[-1]
                     s2 = kn.new_stats(Cn, 2, dev)
                     c2 = u.c.view(-1, Cn)
@@ -1285,8 +1552,15 @@ class Engine:
                         kn.act_bwd_reduce(cur2, c2, u.st.scale, u.st.shift, cur2, s2)
                     else:
                         kn.act_bwd_reduce(cur2, c2, None, None, None, s2)
-                    k = self._bn_bwd_coeffs(s2, 2, 1, u.bn, u.st, grads)
-                    kn.bn_bwd_apply(cur2, c2, k[0], k[1], k[2], dslot)  # lands in its rows of the stacked gradient
+                    sums2.append(s2)
+                ks2 = self._bn_bwd_coeffs_views(sums2, 2, 1, u0.bn, [u.st for u in us], grads)
+            off = 0
+            for v, u in enumerate(us):
+                dslot = dcat[off:off + rows[v]].view(rows[v], Kout)
+                if u.bn is not None:
+                    Cn = u.c.shape[-1]
+                    k = ks2[v]
+                    kn.bn_bwd_apply(curs[v].view(-1, Cn), u.c.view(-1, Cn), k[0], k[1], k[2], dslot)  # lands in its rows of the stacked gradient
                 else:
                     kn.copy2d(curs[v], 0, Kout, dcat, off * Kout, Kout, rows[v], Kout)
                 curs[v] = dslot
@@ -1330,7 +1604,12 @@ class Engine:
             rec.idx.append(idx.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous())
         # reference call order (backbone.py:140-145): separate BatchNorm batches per call
         self._drop_c3 = False  # the first (small) context pass keeps everything and calibrates the planner
-        dual = self.dual_stream if self.dual_stream is not None else self._world() > 1
+        shape_key = (tuple(x1[0].shape[1:]), tuple(x1[1].shape[1:]), sum(1 for _ in model.parameters()), str(dtype))
+        if self.dual_stream is not None:
+            dual = self.dual_stream
+        else:  # automatic: one rank, backward wanted, and the previous step of this shape found the memory for it
+            dual = (need_backward and self.allow_multistream and self._world() == 1 and not self.force_sync
+                    and self._dual_ok.get((B, K) + shape_key, False))
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev) if dual else None
         ev_c, ev_t = {}, {}
@@ -1339,21 +1618,69 @@ class Engine:
             side.wait_stream(main)  # inputs, weights, the zero arena: everything enqueued so far
         m0 = torch.cuda.memory_allocated(dev)
         self._bn_order = ("lead", ev_c) if dual else None
-        rec.enc["c0"] = self.encoder_forward(model.context_encoder, x1[0], dtype)
-        per_image = (torch.cuda.memory_allocated(dev) - m0) / max(1, B)
-        c3_bytes = sum(b.units[-1].c.numel() * b.units[-1].c.element_size() for b in rec.enc["c0"].blocks
-                       if len(b.units) == 3 and b.units[-1].c is not None)
-        c3_frac = (c3_bytes / max(1, B)) / per_image if per_image > 0 else 0.0
         # MSFWSI(..., use_checkpoint=True) (the reference's --use-ac, backbone.py:103-127): trade compute for activation
         # memory -- here: both target passes (16/17 of the images) run features-only and are re-run before their backward
         self._mode_override = "targets" if getattr(model, "use_checkpoint", False) else None
-        shape_key = (tuple(x1[0].shape[1:]), tuple(x1[1].shape[1:]), sum(1 for _ in model.parameters()), str(dtype))
-        nosave = (self._plan_recompute(per_image, B, K, dev, c3_frac, shape_key) if need_backward
-                  else {"c1", "t0", "t1"})
+        lock = (not dual) and self._lockstep()
+        c1_done = False
+        ckey = (B, K) + shape_key
+        tri = dual and need_backward and self.ctx_stream and ckey in self._calib
+        third = self._side_stream(dev, "ctx") if tri else None
+        if dual and self.dual_stream is None and ckey not in self._dual_started:
+            # the automatic switch from one stream (first step of a shape) to several: the main stream's pool still caches
+            # the blocks of ALL passes of that step, the side streams' pools would grow beside it (measured: 287 GiB
+            # reserved and free-and-retry stalls instead of 257 GiB) -- hand the cached blocks back once
+            self._dual_started.add(ckey)
+            torch.cuda.empty_cache()
+        if tri:
+            # both context passes on the third stream, enqueued first; the plan comes from the calibration of an earlier
+            # step (this step's first context pass is not measured alone), with both context passes still to come
+            per_image, c3_frac = self._calib[ckey]
+            nosave = self._plan_recompute(per_image, B, K, dev, c3_frac, shape_key, ctx_passes=2)
+            third.wait_stream(main)
+            for t in (x1[0], x2[0]):
+                t.record_stream(third)
+            self._bn_order = None  # one stream: view 0's running-statistics updates precede view 1's by stream order
+            with torch.cuda.stream(third):
+                rec.enc["c0"] = self.encoder_forward(model.context_encoder, x1[0], dtype)
+                rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
+            c1_done = True
+        elif lock and need_backward and self._plan_known(B, K, shape_key):
+            # the collective plan of this shape is known (second step on): the context views run as a lockstep pair too
+            nosave = self._plan_recompute(0.0, B, K, dev, 0.0, shape_key)
+            rec.enc["c0"], rec.enc["c1"] = self._run_views(
+                lambda: self.encoder_forward(model.context_encoder, x1[0], dtype),
+                lambda: self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave))
+            c1_done = True
+        else:
+            rec.enc["c0"] = self.encoder_forward(model.context_encoder, x1[0], dtype)
+            per_image = (torch.cuda.memory_allocated(dev) - m0) / max(1, B)
+            c3_bytes = sum(b.units[-1].c.numel() * b.units[-1].c.element_size() for b in rec.enc["c0"].blocks
+                           if len(b.units) == 3 and b.units[-1].c is not None)
+            c3_frac = (c3_bytes / max(1, B)) / per_image if per_image > 0 else 0.0
+            if need_backward:
+                self._calib[ckey] = (per_image, c3_frac)  # this pass ran first and alone: nothing else allocated meanwhile
+            nosave = (self._plan_recompute(per_image, B, K, dev, c3_frac, shape_key) if need_backward
+                      else {"c1", "t0", "t1"})
+        if need_backward:
+            # two streams hold two sets of transients at once, like the lockstep backward: same memory condition
+            self._dual_ok[(B, K) + shape_key] = self._pair_bwd and not nosave
+            if dual:
+                self.last_plan += ",dual-stream" + ("+context-stream" if tri else "")
+            if lock:
+                self.last_plan += ",views-lockstep" + ("" if self._pair_bwd else "(forward only)")
         if not need_backward:
             rec.enc["c0"] = EncPass(model.context_encoder, B, 0, 0, None, None, None, None, [], rec.enc["c0"].feats,
                                     saved=False)
-        if not dual:
+        if lock:
+            # cross-replica statistics: the two views of an encoder in lockstep, one message per BatchNorm for both (on
+            # the first step of a shape the first context pass above ran alone: it calibrates the memory plan)
+            if not c1_done:
+                rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
+            rec.enc["t0"], rec.enc["t1"] = self._run_views(
+                lambda: self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave),
+                lambda: self.encoder_forward(model.target_encoder, x2[1], dtype, save="t1" not in nosave))
+        elif not dual:
             rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
             rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
             rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype, save="t1" not in nosave)
@@ -1361,9 +1688,10 @@ class Engine:
             try:
                 for t in (x2[0], x2[1]):
                     t.record_stream(side)
-                with torch.cuda.stream(side):
-                    self._bn_order = ("follow", ev_c)
-                    rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
+                if not c1_done:
+                    with torch.cuda.stream(side):
+                        self._bn_order = ("follow", ev_c)
+                        rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
                 self._bn_order = ("lead", ev_t)
                 rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
                 with torch.cuda.stream(side):
@@ -1372,11 +1700,16 @@ class Engine:
             finally:
                 self._bn_order = None
             main.wait_stream(side)
-            for name in ("c1", "t1"):  # allocated in the side stream's pool, read by the heads on this one
+            if tri:
+                main.wait_stream(third)
+            for name in ("c0", "c1", "t1") if tri else ("c1", "t1"):  # allocated in another stream's pool, read by the heads on this one
                 for f in rec.enc[name].feats:
                     f.record_stream(main)
         rec.dual = dual
+        rec.tri = tri
+        self.last_shape = (B, K, shape_key)
         rec.nosave = nosave
+        rec.pair_bwd = self._pair_bwd
         outs = {}
         for grp in ("context", "target", "inter"):
             proj = getattr(model, f"{grp}_projector")
@@ -1421,7 +1754,9 @@ class Engine:
         dcf = [[None] * 4 for _ in range(2)]
         dtf = [[None] * 4 for _ in range(2)]
         for grp in ("context", "target", "inter"):
-            for s in range(4):
+            # the fuser heads from the widest scale down: its 18432-wide layers are 2/3 of all gradient bytes, and their
+            # bucket of the gradient exchange (on_group_done("inter", part=...)) leaves first
+            for s in (range(3, -1, -1) if grp == "inter" else range(4)):
                 pair = None
                 if self.pair_head_wgrad:
                     hz, hp = zip(*(rec.heads.pop((grp, s, v)) for v in range(2)))
@@ -1446,8 +1781,12 @@ class Engine:
                         D = (n_keep + 1) * Cs
                         kn.copy2d(df, 0, D, dcf[v][s], 0, Cs, B, Cs, accumulate=True)
                         kn.copy2d(df, Cs, D, dtf[v][s], 0, K * Cs, B, n_keep * Cs, accumulate=True)
+                if grp == "inter" and on_group_done is not None and self.bucket_inter:
+                    # this scale's projector / predictor weight gradients are complete: their buckets may travel
+                    on_group_done("inter", part=f"inter_predictor.{s}.")
+                    on_group_done("inter", part=f"inter_projector.{s}.")
             if grp == "inter" and on_group_done is not None:
-                on_group_done("inter")
+                on_group_done("inter")  # whatever no bucket covered (nothing, unless bucketing is off)
         # saved passes first (frees their activations), then the features-only ones are re-materialised
         order = sorted((("t0", dtf[0]), ("t1", dtf[1])), key=lambda nd: not rec.enc[nd[0]].saved)
         # view 1 on the side stream again (its activations live in that stream's pool); both views add into the same
@@ -1457,26 +1796,53 @@ class Engine:
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev) if dual else None
 
+        tri = dual and rec.tri
+        third = self._side_stream(dev, "ctx") if tri else None
+
         def run(name, df):
-            if dual and name.endswith("1"):
+            st = third if (tri and name.startswith("c")) else (side if dual and name.endswith("1") else None)
+            if st is not None:
                 for d in df:
                     if d is not None:
-                        d.record_stream(side)
-                with torch.cuda.stream(side):
+                        d.record_stream(st)
+                with torch.cuda.stream(st):
                     self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
             else:
                 self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
 
         if dual:
             side.wait_stream(main)  # the heads' backward produced the feature gradients
-        for name, df in order:
-            run(name, df)
+        if tri:  # the context passes' backward on the third stream, enqueued first, beside the target passes'
+            third.wait_stream(main)
+            for name, df in (("c1", dcf[1]), ("c0", dcf[0])):
+                run(name, df)
+        # lockstep backward of a pair of passes (one SyncBatchNorm message per BatchNorm for both views): only when both
+        # passes kept their activations -- a features-only pass re-runs its forward first and would issue forward
+        # exchanges where its partner issues backward ones -- and only when the memory plan left room for two sets of
+        # backward transients (rec.pair_bwd: part of the COLLECTIVE plan, every rank takes the same branch)
+        pair_ok = (not dual) and self._lockstep() and rec.pair_bwd
+
+        def run_pair(n0, d0, n1, d1):
+            p0, p1 = rec.enc.pop(n0), rec.enc.pop(n1)
+            self._run_views(lambda: self.encoder_backward(p0, d0, grads, dtype),
+                            lambda: self.encoder_backward(p1, d1, grads, dtype))
+
+        if pair_ok and rec.enc["t0"].saved and rec.enc["t1"].saved:
+            run_pair("t0", dtf[0], "t1", dtf[1])
+        else:
+            for name, df in order:
+                run(name, df)
         if dual:
             main.wait_stream(side)
         if on_group_done is not None:
             on_group_done("target")
-        for name, df in (("c1", dcf[1]), ("c0", dcf[0])):
-            run(name, df)
+        if tri:
+            main.wait_stream(third)
+        elif pair_ok and rec.enc["c0"].saved and rec.enc["c1"].saved:
+            run_pair("c0", dcf[0], "c1", dcf[1])
+        else:
+            for name, df in (("c1", dcf[1]), ("c0", dcf[0])):
+                run(name, df)
         if dual:
             main.wait_stream(side)
         if on_group_done is not None:

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -80,6 +81,7 @@ class ZeroArena:
         self.off = 0
         self.demand = 0
         self.active = False
+        self._lock = threading.Lock()  # the two view passes of an encoder may run on two host threads (engine._ViewPair)
 
     def begin_step(self, device):
         want = int(self.demand * 1.1) + (1 << 20)
@@ -99,12 +101,16 @@ class ZeroArena:
         nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
         if not self.active:
             return torch.zeros(shape, dtype=dtype, device=device)
-        self.demand += nbytes
-        if self.buf is None or self.off + nbytes > self.buf.numel() or self.buf.device != torch.device(device):
+        with self._lock:
+            self.demand += nbytes
+            if self.buf is None or self.off + nbytes > self.buf.numel() or self.buf.device != torch.device(device):
+                off = -1
+            else:
+                off = self.off
+                self.off += nbytes
+        if off < 0:
             return torch.zeros(shape, dtype=dtype, device=device)
-        out = self.buf[self.off:self.off + nbytes].view(dtype)[:n].view(shape)
-        self.off += nbytes
-        return out
+        return self.buf[off:off + nbytes].view(dtype)[:n].view(shape)
 
 
 ARENA = ZeroArena()

@@ -183,6 +183,7 @@ class PretrainStep(FlatAdamScaler):
         self.eps = [1e-8, 1e-8, 1e-8]
         self.flats = FlatGroups(model, lowp_dtype=None if dtype == torch.float32 else dtype)
         self.engine = Engine(process_group=process_group, sync_bn=sync_bn)
+        self.engine.allow_multistream = True  # flat, pre-allocated gradient accumulators: several streams may add into them
         model._engine = self.engine
         self._register_lowp_weights()
         self.grads = _FlatGradStore(self.flats)

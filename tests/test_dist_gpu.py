@@ -28,7 +28,10 @@ def _worker(rank, world, port, ret):
     from msf_wsi_amd.dist import shard_range
     from msf_wsi_amd.train import PretrainStep
 
-    os.environ["MSFWSI_DUAL_STREAM"] = "1"  # the optional two-stream schedule under a real multi-rank exchange
+    if world == 2:
+        os.environ["MSFWSI_DUAL_STREAM"] = "1"  # the optional two-stream schedule under a real multi-rank exchange
+    # (world 4: the default multi-rank schedule -- the two views of an encoder in LOCKSTEP, one SyncBatchNorm message per
+    #  BatchNorm and direction for both views)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
@@ -43,9 +46,15 @@ def _worker(rank, world, port, ret):
         mean_loss = ts.epoch_loss()
         ret[f"collectives{rank}"] = ts.engine.collectives_last_step
         ret[f"plan{rank}"] = ts.engine.last_plan
+        ret[f"grad_msgs{rank}"] = ts.reducer.launches_last_step
         if rank == 0:
             ret["loss"] = mean_loss
             ret["sd"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        # a second step: the collective plan of the shape is known now, so the context views pair up too -- its count is
+        # the steady state of a run (the first step's context passes ran one after the other to calibrate the plan)
+        ts.step(local)
+        torch.cuda.synchronize()
+        ret[f"collectives_steady{rank}"] = ts.engine.collectives_last_step
     finally:
         dist.destroy_process_group()
 
@@ -65,8 +74,18 @@ def test_ranks_match_single_process(hip_lib, world):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    # every rank issued the same number of collectives and adopted the same plan
-    assert len({ret[f"collectives{r}"] for r in range(world)}) == 1 and ret["collectives0"] > 300, dict(ret)
+    # every rank issued the same number of collectives and adopted the same plan.  ResNet-18: 40 encoder + 48 head
+    # BatchNorm modules, each called for 2 views, forward and backward: 352 exchanges one by one (round 3).  Heads: both
+    # views in one message (96 instead of 192).  Encoders: 160 with one pass after the other (the two-stream schedule of
+    # the 2-rank case), 80 with the views in lockstep (4-rank case, from the second step on; the first step's context
+    # passes run singly: +20, and the plan collective: +1)
+    assert len({ret[f"collectives{r}"] for r in range(world)}) == 1, dict(ret)
+    assert len({ret[f"collectives_steady{r}"] for r in range(world)}) == 1, dict(ret)
+    want = {2: (257, 256), 4: (197, 176)}[world]
+    assert (ret["collectives0"], ret["collectives_steady0"]) == want, (ret["collectives0"], ret["collectives_steady0"], want)
+    assert ("views-lockstep" in ret["plan0"]) == (world == 4), ret["plan0"]
+    # gradient exchange: context_, target_ and the fuser heads' 8 per-scale buckets (projector + predictor x 4 scales)
+    assert ret["grad_msgs0"] == 10, ret["grad_msgs0"]
     assert len({ret[f"plan{r}"] for r in range(world)}) == 1
     print(f"world {world}: {ret['collectives0']} engine collectives per step, plan {ret['plan0']}")
 
@@ -232,8 +251,25 @@ def _ft_worker(rank, world, port, ret):
         x1, x2, m1, m2 = _inputs(B=4)
         lo, hi = shard_range(4, world, rank)
         ts = FinetuneStep(model, lr=1e-3, batch_size=4, lam=0.75, dtype=torch.float32, use_scaler=False, sync_bn=True)
+        # this rank's LOCAL gradient, taken right before the reducer sends it, and the averaged one right after the wait
+        launch, wait, snap = ts.reducer.launch, ts.reducer.wait, {}
+
+        def spy_launch(*a, **k):
+            torch.cuda.synchronize()
+            snap["local"] = ts.flats.g[0].detach().clone()
+            return launch(*a, **k)
+
+        def spy_wait():
+            wait()
+            torch.cuda.synchronize()
+            snap["avg"] = ts.flats.g[0].detach().clone()
+
+        ts.reducer.launch, ts.reducer.wait = spy_launch, spy_wait
         loss, _ = ts.step((x1[lo:hi].cuda(), x2[lo:hi].cuda()), (m1[lo:hi].cuda(), m2[lo:hi].cuda()))
         torch.cuda.synchronize()
+        ret[f"g_local{rank}"] = snap["local"].cpu()
+        ret[f"g_avg{rank}"] = snap["avg"].cpu()
+        ret[f"w{rank}"] = ts.flats.w[0].detach().cpu()
         if rank == 0:
             ret["sd"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             ret["collectives"] = ts.engine.collectives_last_step
@@ -255,6 +291,13 @@ def test_finetune_step_two_ranks_match_single_process(hip_lib):
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_ft_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["collectives"] > 100
+    # the gradient exchange: what every rank steps on is the MEAN of the two ranks' local gradients -- not a
+    # local gradient (exchange missing) and not their sum -- and both ranks end with identical weights
+    mean = (ret["g_local0"].double() + ret["g_local1"].double()) / 2
+    assert float((ret["g_local0"] - ret["g_local1"]).abs().max()) > 0, "the shards must produce different local gradients"
+    for r in range(2):
+        assert float((ret[f"g_avg{r}"].double() - mean).abs().max()) <= 1e-6 * float(mean.abs().max()), r
+    assert torch.equal(ret["w0"], ret["w1"])
     sd2 = ret["sd"]
     for k, v in sd2.items():
         if k.endswith("num_batches_tracked"):

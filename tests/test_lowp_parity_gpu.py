@@ -26,12 +26,16 @@ def term_scale(spread_terms):
     return np.maximum(sp, np.sqrt((sp ** 2).mean(axis=1, keepdims=True))).reshape(-1)
 
 
-def lowp_step(case, dtype, mutate=None):
+def lowp_step(case, dtype, mutate=None, model=None):
     """the reference loop's statements (tools/ssl_train.py:441-472) under torch.autocast("cuda", dtype) on the product;
-    returns the gate inputs.  mutate(model): test hook applied before the step (fault injection)."""
+    returns the gate inputs.  mutate(model): test hook applied before the step (fault injection).  model: a product model
+    of the case built by the caller (repeated runs of one step: gradients are cleared here)"""
     vec, man = load_golden(case)
     oc = oracle_case(case)
-    model = build_case(man).cuda().train()
+    if model is None:
+        model = build_case(man).cuda().train()
+    for p in model.parameters():
+        p.grad = None
     (c1, c2), (t1, t2), idx = case_batch(man)
     scale = FP16_LOSS_SCALE if dtype == torch.float16 else 1.0
     if mutate is not None:
@@ -48,9 +52,9 @@ def lowp_step(case, dtype, mutate=None):
     return vec, man, oc, outs, terms.cpu().double(), grads
 
 
-def gate_lowp_step(case, dtype, what, mutate=None):
+def gate_lowp_step(case, dtype, what, mutate=None, model=None):
     tag, floor = LOWP_TAG[dtype], LOWP_FLOOR[dtype]
-    vec, man, oc, outs, terms, grads = lowp_step(case, dtype, mutate)
+    vec, man, oc, outs, terms, grads = lowp_step(case, dtype, mutate, model)
     # ---- outputs p / z: per tensor against the fp64 oracle, allowance from the reference under autocast
     fo, fr = flat_outputs(outs), flat_outputs(oc["outs64"])
     keys = list(fo)

@@ -170,7 +170,29 @@ def case_dma():
         del x, y
 
 
-CASES = {"epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+def case_deep():
+    """MFMA-bound layers: 3x3 and deep 1x1, forward / input gradient / weight gradient (the A/B shapes of the
+    MSFWSI_FETCH_FIRST order)"""
+    for H, Cn, K, R in ((14, 256, 256, 3), (7, 512, 512, 3), (28, 128, 128, 3), (14, 1024, 256, 1), (7, 512, 2048, 1)):
+        N = NIMG
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cn, K, R, R, 1, R // 2)
+        x = rnd(M, Cn)
+        w = rnd(K, R * R * Cn, scale=0.05)
+        y = torch.empty(M, K, dtype=DT, device="cuda")
+        dy = rnd(M, K, scale=0.05)
+        dx = torch.empty(M, Cn, dtype=DT, device="cuda")
+        dw = torch.zeros(K, R * R * Cn, device="cuda")
+        fl = 2.0 * M * Cn * K * R * R
+        nb = (M * Cn + M * K) * 2
+        report(f"deep {H}x{H} C{Cn}->K{K} {R}x{R} fwd (+stats)",
+               timeit(lambda: kn.conv_fwd(d, x, w, y, stats=kn.new_stats(K, 2, "cuda"))), nb, fl)
+        report(f"deep {H}x{H} C{Cn}->K{K} {R}x{R} dgrad", timeit(lambda: kn.conv_dgrad(d, dy, w, dx)), nb, fl)
+        report(f"deep {H}x{H} C{Cn}->K{K} {R}x{R} wgrad", timeit(lambda: kn.conv_wgrad(d, x, dy, dw)), nb + dw.numel() * 4, fl)
+        del x, y, dy, dx, dw
+
+
+CASES = {"deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():

@@ -1,6 +1,7 @@
 """Summarise hipcc's -Rpass-analysis=kernel-resource-usage remarks: one line per kernel (VGPRs, AGPRs, SGPRs, scratch,
 occupancy, LDS).  usage: hipcc ... -Rpass-analysis=kernel-resource-usage -c x.hip 2> log; python tools/resource_usage.py log
-Exit code 1 when a kernel named by --no-scratch PATTERN carries scratch (make check-scratch)."""
+Exit code 1 when a kernel named by --no-scratch PATTERN carries scratch and no --allow PATTERN (matched against the mangled
+name) accepts it (make check-scratch)."""
 import re
 import subprocess
 import sys
@@ -41,6 +42,11 @@ def main():
         i = args.index("--no-scratch")
         pats.append(args[i + 1])
         del args[i:i + 2]
+    allow = []
+    while "--allow" in args:
+        i = args.index("--allow")
+        allow.append(args[i + 1])
+        del args[i:i + 2]
     bad = 0
     for path in args:
         rows = parse(path)
@@ -50,7 +56,10 @@ def main():
             n = re.sub(r"\(.*", "", n)
             flag = ""
             if r.get("scratch", 0) > 0 and any(re.search(p, n) for p in pats):
-                flag, bad = "  <-- SCRATCH on a hot-path kernel", bad + 1
+                if any(re.search(p, r["name"]) for p in allow):
+                    flag = "  (scratch: accepted, see the Makefile)"
+                else:
+                    flag, bad = "  <-- SCRATCH on a hot-path kernel", bad + 1
             print(f"{r.get('vgpr', -1):4d}v {r.get('agpr', -1):4d}a {r.get('sgpr', -1):4d}s  scratch {r.get('scratch', -1):4d}  "
                   f"occ {r.get('occ', -1)}  lds {r.get('lds', -1):6d}  {n}{flag}")
     return 1 if bad else 0
