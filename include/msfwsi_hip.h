@@ -132,6 +132,12 @@ int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* 
  * Replaces: convolution_backward(weight) / linear backward(weight), tools/ssl_train.py:472. */
 int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* pro_scale,
                       const float* pro_shift, int target_blocks, void* stream);
+/* dw[K][R][S][C] (fp32) = dy^T * x, STORED (not accumulated): one workgroup per gradient tile over all pixels, no
+ * atomics, dw need not be cleared.  For gradients with ONE launch per step and few rows -- the heads' Linear layers
+ * (both views stacked), whose fp32 matrices (fuser: 1.36 GB each) are then written once instead of cleared, read and
+ * written.  Same results as msfwsi_conv_wgrad on a cleared dw up to the order of the fp32 sums.
+ * Replaces: linear backward(weight), tools/ssl_train.py:472 (+ optimizer.zero_grad for these tensors, :471). */
+int msfwsi_conv_wgrad_store(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, void* stream);
 /* Gram matrix A64[C][C] (fp64) += a^T a over the N*H*W pixels of the NHWC activation a (d: the 1x1 / stride-1 conv C -> C
  * whose weight gradient with x = dy = a it is; same MFMA kernels as msfwsi_conv_wgrad, the pixel splits accumulate in
  * fp64).  The folded Bottleneck tail takes bn3's batch statistics from it (sum c^2 = diag(W A W^T)); the fp64

@@ -49,6 +49,7 @@ struct WgradParams {
     int rows_per_split;
     int ntile_i;
     FastDiv div_pq, div_q;
+    int store;     // 1: ONE pixel split, the tile is STORED (dw = ..., no atomics, dw need not be cleared): msfwsi_conv_wgrad_store
 };
 
 constexpr int wgrad_waves(int bi, int bj) { return (bi == 256 && bj == 256) ? MSFWSI_WGRAD_BIG_WAVES : 4; }
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
                 const int co = i0 + (wi * TI + ti) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
                 if (co < prm.K && j < prm.Jtot) {
                     if (prm.dw64 != nullptr) atomicAdd(prm.dw64 + (long)co * prm.Jtot + j, (double)acc[ti][tj][reg]);
+                    else if (prm.store) prm.dw[(long)co * prm.Jtot + j] = acc[ti][tj][reg];
                     else atomicAdd(prm.dw + (long)co * prm.Jtot + j, acc[ti][tj][reg]);
                 }
             }
@@ -755,6 +757,7 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
     const long max_splits = (prm.M + Cfg::BKM - 1) / Cfg::BKM;
     if (splits > max_splits) splits = max_splits;
     if (g_wgrad_max_splits > 0 && splits > g_wgrad_max_splits) splits = g_wgrad_max_splits;
+    if (prm.store) splits = 1;  // the tile is written, not added: one workgroup owns it
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
     long rows = (prm.M + splits - 1) / splits;
@@ -809,9 +812,10 @@ extern "C" int msfwsi_stem_wgrad_bnbwd(const msfwsi_conv_desc* d, const void* x,
 }
 
 static int wgrad_generic(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, double* dw64,
-                         const float* pro_scale, const float* pro_shift, int target_blocks, hipStream_t st) {
+                         const float* pro_scale, const float* pro_shift, int target_blocks, hipStream_t st,
+                         int store = 0) {
     WgradParams prm{};
-    prm.x = x; prm.dy = dy; prm.dw = dw; prm.dw64 = dw64;
+    prm.x = x; prm.dy = dy; prm.dw = dw; prm.dw64 = dw64; prm.store = store;
     prm.pro_scale = pro_scale; prm.pro_shift = pro_shift;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C;
     prm.P = d->P; prm.Q = d->Q; prm.K = d->K;
@@ -858,6 +862,21 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
         return launch_wgrad_os<_Float16>(d, x, dy, dw, pro_scale, pro_shift, st0);
     }
     return wgrad_generic(d, x, dy, dw, nullptr, pro_scale, pro_shift, target_blocks, reinterpret_cast<hipStream_t>(stream));
+}
+
+// dw = dy^T x, STORED: every gradient tile is computed by one workgroup over all pixels and written once -- no atomics,
+// no read-modify-write of dw, dw need not be zero beforehand.  For weight gradients that receive exactly one launch per
+// step and have few rows: the heads' Linear layers (both views stacked: 512 / 8192 rows), above all the fuser's
+// 18432 x 18432 matrices (1.36 GB of fp32 each: accumulated, they are read and written; stored, written -- and the
+// step's clear of the flat gradient buffer skips them).
+extern "C" int msfwsi_conv_wgrad_store(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+    if (d == nullptr || x == nullptr || dy == nullptr || dw == nullptr) return MSFWSI_EINVAL;
+    if (!msfwsi_dtype_ok(d->dtype)) return MSFWSI_EUNSUPPORTED;
+    const int vec = msfwsi_vec_of(d->dtype);
+    if (d->C % vec != 0 || d->K % vec != 0) return MSFWSI_EUNSUPPORTED;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->P <= 0 || d->Q <= 0 || d->R <= 0 || d->S <= 0) return MSFWSI_EINVAL;
+    if ((long)d->N * d->P * d->Q > 0x7fffffffL || (long)d->N * d->H * d->W > 0x7fffffffL) return MSFWSI_EINVAL;
+    return wgrad_generic(d, x, dy, dw, nullptr, nullptr, nullptr, 0, reinterpret_cast<hipStream_t>(stream), 1);
 }
 
 // Gram matrix A += a^T a of an NHWC activation (d: the 1x1 / stride-1 conv C -> C whose "weight gradient" with x = dy = a

@@ -125,6 +125,7 @@ class FlatGroups:
             self.w16.append(torch.zeros(total, dtype=lowp_dtype, device=dev) if with_bf16 else None)
         self._grad_views: Dict[int, torch.Tensor] = {}
         self._w16_views: Dict[int, torch.Tensor] = {}
+        self._stored: Dict[int, set] = {}
         for gi, plist in enumerate(self.params):
             for p, off in zip(plist, self.offsets[gi]):
                 phys_shape = self.physical_shape(p)
@@ -158,8 +159,28 @@ class FlatGroups:
         return (self._logical(self.m[gi][off:off + n].view(shp), p), self._logical(self.v[gi][off:off + n].view(shp), p))
 
     def zero_grads(self):
-        for g in self.g:
-            g.zero_()
+        """clear the gradient accumulators -- except the ranges `mark_stored` named: tensors whose gradient is WRITTEN by
+        one launch per step (msfwsi_conv_wgrad_store: the fuser heads' 18432-wide matrices, 4 GB of fp32 together)"""
+        for gi, g in enumerate(self.g):
+            skip = sorted(self._stored.get(gi, ()))
+            if not skip:
+                g.zero_()
+                continue
+            pos = 0
+            for lo, hi in skip + [(g.numel(), g.numel())]:
+                if lo > pos:
+                    g[pos:lo].zero_()
+                pos = max(pos, hi)
+
+    def mark_stored(self, p: torch.Tensor):
+        """the engine stores (not accumulates) this parameter's gradient, every step: zero_grads may leave it alone"""
+        for gi, plist in enumerate(self.params):
+            for pi, q in enumerate(plist):
+                if q is p:
+                    lo = self.offsets[gi][pi]
+                    self._stored.setdefault(gi, set()).add((lo, lo + p.numel()))
+                    return
+        raise KeyError("parameter is not part of the flat groups")
 
     def range_of(self, gi: int, name_prefix: str) -> Tuple[int, int]:
         """[lo, hi) element range of group gi's flat buffers that holds the parameters whose names start with

@@ -324,6 +324,8 @@ class Engine:
         self.pair_head_fwd = os.environ.get("MSFWSI_PAIR_HEAD_FWD", "1") != "0"  # ... and one forward GEMM per layer
         # gradient exchange of the fuser heads in per-scale buckets, each launched when its weight gradients are complete
         self.bucket_inter = os.environ.get("MSFWSI_BUCKET_INTER", "1") != "0"
+        # the heads' big Linear weight gradients (one launch per step for both views) stored instead of accumulated
+        self.store_head_wgrad = os.environ.get("MSFWSI_STORE_HEAD_WGRAD", "1") != "0"
         # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
         # stem_pool_bwd + bn_bwd_apply (the pool-backward window logic is VALU-bound, not byte-bound): off
         self.stem_two_pass = os.environ.get("MSFWSI_STEM_TWO_PASS", "0") != "0"
@@ -1571,7 +1573,14 @@ class Engine:
                     kn.copy2d(u.x, 0, Cin, xcat, off * Cin, Cin, rows[v], Cin)
                 off += rows[v]
             dpair = kn.conv_desc(dtype, sum(rows), 1, 1, Cin, Kout, 1, 1, 1, 0)
-            kn.conv_wgrad(dpair, xcat, dcat, grads.get(u0.op.weight))
+            if self.store_head_wgrad and sum(rows) <= 1024 and Kout * Cin >= (1 << 22):
+                # few rows, a big matrix, and this is its ONLY launch of the step: the gradient is stored, not added --
+                # no atomics, no read-modify-write of up to 1.36 GB of fp32, and the trainer's clear skips the tensor
+                kn.conv_wgrad_store(dpair, xcat, dcat, grads.get(u0.op.weight))
+                if hasattr(grads, "mark_stored"):
+                    grads.mark_stored(u0.op.weight)
+            else:
+                kn.conv_wgrad(dpair, xcat, dcat, grads.get(u0.op.weight))
             bias = getattr(u0.op, "bias", None)
             if bias is not None:
                 cs = torch.zeros(Kout, dtype=torch.float64, device=dev)

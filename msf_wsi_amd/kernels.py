@@ -514,6 +514,18 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=0):
     return dw
 
 
+def conv_wgrad_store(d: ConvDesc, x, dy, dw):
+    """dw = dy^T x, stored (no atomics, dw need not be cleared): one launch per step and tensor -- the heads' Linear layers"""
+    lib = _lib.load()
+    dt = x.dtype
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
+    _req(dw, "dw", torch.float32, d.K * d.R * d.S * d.C)
+    _timed("conv_wgrad", d, x.element_size(), lambda: _lib.check(
+        lib.msfwsi_conv_wgrad_store(C.byref(d), _p(x), _p(dy), _p(dw), _stream()), "conv_wgrad_store"), dtype=dt)
+    return dw
+
+
 def gram(d: ConvDesc, a, A):
     """A[C][1][1][C] (fp32, zeroed by the caller) = a^T a over the pixels of the NHWC activation `a`; the pixel splits
     accumulate in fp64 (msfwsi_gram) so that the BatchNorm statistics the folded tails derive from A do not depend on the

@@ -37,6 +37,7 @@ class _FlatGradStore(GradStore):
     def __init__(self, flats: FlatGroups):
         super().__init__()
         self.flats = flats
+        self._marked: set = set()
 
     def get(self, param):
         return self.flats.grad_view(param)
@@ -44,6 +45,12 @@ class _FlatGradStore(GradStore):
     def logical(self, param):
         b = self.flats.grad_view(param)
         return b.permute(0, 3, 1, 2) if param.dim() == 4 else b
+
+    def mark_stored(self, param):
+        """the engine writes this gradient with a storing launch every step (Engine.chain_backward_pair)"""
+        if id(param) not in self._marked:
+            self._marked.add(id(param))
+            self.flats.mark_stored(param)
 
 
 class FlatAdamScaler:

@@ -388,6 +388,26 @@ def test_conv_wgrad(hip_lib, dt, geom, pro):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,Cin,K", [(512, 512, 256), (96, 320, 136), (40, 64, 64), (1000, 256, 768)])
+def test_conv_wgrad_store(hip_lib, dt, rows, Cin, K):
+    """msfwsi_conv_wgrad_store: the Linear weight gradient WRITTEN by one launch (no atomics, no clear beforehand) -- the
+    buffer starts full of NaN, every element must be overwritten with dy^T x (whole and ragged 256 / 128 / 64 tiles)"""
+    from msf_wsi_amd import kernels as kn
+
+    g = torch.Generator().manual_seed(31)
+    d = kn.conv_desc(dt, rows, 1, 1, Cin, K, 1, 1, 1, 0)
+    x = rnd((rows, Cin), dt, g)
+    dy = rnd((rows, K), dt, g, 0.1)
+    ref = dy.double().t() @ x.double()
+    dw = torch.full((K, Cin), float("nan"), dtype=torch.float32, device="cuda")
+    kn.conv_wgrad_store(d, x.to(dt).cuda(), dy.to(dt).cuda(), dw)
+    kn.conv_wgrad_store(d, x.to(dt).cuda(), dy.to(dt).cuda(), dw)  # a second launch REPLACES, it does not add
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all()
+    assert rel(dw.cpu(), ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("shape", [(300, 64), (7, 144), (5000, 16), (64, 2304)])
 def test_batchnorm_train_fwd_bwd(hip_lib, dt, shape):
     """conv-epilogue stats -> bn_finalize -> bn_act, then act_bwd_reduce -> bn_bwd_finalize -> bn_bwd_apply

@@ -151,6 +151,8 @@ def case_fuser():
         report(f"fuser dgrad {rows}x{K} -> {Cin}", timeit(lambda: kn.conv_dgrad(d, dy, w, dx)), wb + (dy.numel() + dx.numel()) * 2, flop)
         dw = torch.zeros(K, Cin, device="cuda")
         report(f"fuser wgrad {rows}: {K}x{Cin}", timeit(lambda: kn.conv_wgrad(d, x, dy, dw)), K * Cin * 8 + (x.numel() + dy.numel()) * 2, flop)
+        report(f"fuser wgrad {rows}: {K}x{Cin} STORED", timeit(lambda: kn.conv_wgrad_store(d, x, dy, dw)),
+               K * Cin * 4 + (x.numel() + dy.numel()) * 2, flop)
         del x, w, y, dy, dx, dw
 
 

@@ -18,6 +18,7 @@ rm -rf $OUT/prof_${TAG}_kt
 timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_kt -o kt --output-format csv -- \
     python3 $R/bench.py --steps 4 --warmup 2 $ARGS > $OUT/prof_${TAG}_kt.log 2>&1 || { echo "kernel-trace pass failed"; tail -5 $OUT/prof_${TAG}_kt.log; exit 1; }
 cp $(find $OUT/prof_${TAG}_kt -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+if [ "${KT_ONLY:-0}" = "1" ]; then rm -rf $OUT/prof_${TAG}_kt; exit 0; fi   # kernel trace only (e.g. a second stream mode)
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
