@@ -556,9 +556,11 @@ def main():
         }
         if timer is not None and args.layer_report:
             rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1][1])
-            nst = args.steps - timed_from
+            nst = ev_nst if ev_nst is not None else args.steps - timed_from
             with open(args.layer_report, "w") as f:
-                f.write(f"# per event-timed step ({nst} steps averaged); ms, TFLOP/s, GB/s are algorithmic\n")
+                f.write(f"# per event-timed step ({nst} steps averaged"
+                        + (", the extra ONE-STREAM step after the timed region" if ev_nst is not None else "")
+                        + "); ms, TFLOP/s, GB/s are algorithmic\n")
                 f.write("kind\tms_per_step\tlaunches_per_step\tTFLOP/s\tGB/s\tshape\tsymbol\n")
                 for (kind, shape, sym), (n, sec, fl, by) in rows:
                     f.write(f"{kind}\t{1e3 * sec / nst:.3f}\t{n / nst:.1f}\t{fl / sec / 1e12:.1f}\t{by / sec / 1e9:.0f}\t"

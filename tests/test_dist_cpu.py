@@ -100,9 +100,17 @@ def _worker(rank, world, port, ret):
             gsrc = grads[n].float()
             gv.copy_(gsrc.permute(0, 2, 3, 1) if gsrc.dim() == 4 else gsrc)
         red = GradReducer(flats)
-        for name in ("inter", "target", "context"):  # the order the backward schedule releases them
+        # the order the backward schedule releases them (Engine.model_backward): the fuser heads per scale from the widest
+        # down -- predictor bucket, projector bucket -- then whatever of inter_ no bucket covered, then target_, context_
+        for s_ in (3, 2, 1, 0):
+            red.launch("inter", part=f"inter_predictor.{s_}.")
+            red.launch("inter", part=f"inter_projector.{s_}.")
+        for name in ("inter", "target", "context"):
             red.launch(name)
         red.wait()
+        if rank == 0:
+            ret["grad_msgs"] = red.launches_last_step
+            ret["grad_bytes"] = red.bytes_last_step
         lsum = torch.tensor([float(loss)], dtype=torch.float64)
         dist.all_reduce(lsum)
         if rank == 0:
@@ -120,6 +128,74 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _pair_worker(rank, world, port, ret):
+    """two 'view' threads per rank meet at every exchange (engine._ViewPair); the second to arrive issues ONE all-reduce
+    over both views' rows"""
+    import threading
+
+    from msf_wsi_amd.dist import sync_sums
+    from msf_wsi_amd.engine import _ViewPair
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        pair, n, rounds = _ViewPair(), 6, 7
+        both = torch.zeros(2, n, dtype=torch.float64)
+        calls, got, order = [], {0: [], 1: []}, []
+
+        def collective():
+            calls.append(threading.current_thread().name)
+            sync_sums(both.view(-1))
+
+        def view(v):
+            for r in range(rounds):
+                both[v] = float(100 * rank + 10 * v + r)          # this view's packed statistics of exchange r
+                pair.exchange(v, collective)
+                got[v].append(both[v].clone())
+                pair.turn_wait(v)                                  # view 0's running-statistics update goes first
+                order.append((r, v))
+                pair.turn_done(v)
+
+        t = threading.Thread(target=view, args=(1,), name="view1")
+        t.start()
+        view(0)
+        t.join()
+        want = lambda v, r: sum(100 * k + 10 * v + r for k in range(world))
+        ok = all(float(got[v][r][0]) == want(v, r) for v in (0, 1) for r in range(rounds))
+        turn_ok = all(order.index((r, 0)) < order.index((r, 1)) for r in range(rounds))
+        ret[rank] = (len(calls), ok, turn_ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_view_pair_one_collective_per_exchange():
+    """the lockstep rendezvous of the two views (more than one rank: one SyncBatchNorm message per BatchNorm for both views)
+    on CPU tensors over gloo: one collective per exchange whichever view arrives last, each view reads its own row of
+    the summed message, view 0 passes every turn point before view 1; a failing view fails its partner instead of
+    leaving it waiting"""
+    import threading
+
+    from msf_wsi_amd.engine import _ViewPair
+
+    ret = mp.Manager().dict()
+    mp.spawn(_pair_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == (7, True, True) and ret[1] == (7, True, True), dict(ret)
+    pair, seen = _ViewPair(), []
+
+    def partner():
+        try:
+            pair.exchange(1, lambda: None)
+            pair.exchange(1, lambda: None)  # view 0 has failed by now: this must raise, not hang
+        except RuntimeError as e:
+            seen.append(str(e))
+
+    t = threading.Thread(target=partner)
+    t.start()
+    pair.exchange(0, lambda: None)
+    pair.fail(ValueError("view 0 broke"))
+    t.join(timeout=30)
+    assert not t.is_alive() and seen and "other view pass" in seen[0]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -133,6 +209,7 @@ def test_two_ranks_equal_full_batch():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert abs(ret["loss"][0] - ret["loss"][1]) < 1e-9, ret["loss"]
+    assert ret["grad_msgs"] == 10, ret["grad_msgs"]  # 8 per-scale buckets of inter_ + target_ + context_
     assert ret["worst"] < 1e-5, ret["worst"]  # grads travelled as fp32 through the flat buffers
 
 
