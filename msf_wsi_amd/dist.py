@@ -158,19 +158,24 @@ class FlatGroups:
         shp = self.physical_shape(p)
         return (self._logical(self.m[gi][off:off + n].view(shp), p), self._logical(self.v[gi][off:off + n].view(shp), p))
 
-    def zero_grads(self):
+    def zero_grads(self, skip_groups: Sequence[int] = ()):
         """clear the gradient accumulators -- except the ranges `mark_stored` named: tensors whose gradient is WRITTEN by
         one launch per step (msfwsi_conv_wgrad_store: the fuser heads' 18432-wide matrices, 4 GB of fp32 together)"""
-        for gi, g in enumerate(self.g):
-            skip = sorted(self._stored.get(gi, ()))
-            if not skip:
-                g.zero_()
-                continue
-            pos = 0
-            for lo, hi in skip + [(g.numel(), g.numel())]:
-                if lo > pos:
-                    g[pos:lo].zero_()
-                pos = max(pos, hi)
+        for gi in range(len(self.g)):
+            if gi not in skip_groups:
+                self.zero_group(gi)
+
+    def zero_group(self, gi: int):
+        g = self.g[gi]
+        skip = sorted(self._stored.get(gi, ()))
+        if not skip:
+            g.zero_()
+            return
+        pos = 0
+        for lo, hi in skip + [(g.numel(), g.numel())]:
+            if lo > pos:
+                g[pos:lo].zero_()
+            pos = max(pos, hi)
 
     def mark_stored(self, p: torch.Tensor):
         """the engine stores (not accumulates) this parameter's gradient, every step: zero_grads may leave it alone"""

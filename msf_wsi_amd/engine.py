@@ -364,11 +364,23 @@ class Engine:
         # (the fused trainers: train.PretrainStep sets this); the process-wide default engine behind the plain model API
         # accumulates into lazily created buffers from autograd's thread and stays on one stream
         self.allow_multistream = False
+        self.before_heads = None  # callable run on the launch stream right before the heads of a forward
         # ... and with two streams active, the two CONTEXT passes (1/17 of the images, launches too small to fill the chip:
         # 45 ms of a 545 ms step for 6 % of the work) run on a THIRD stream beside the target passes, forward and backward
         # (different encoder, different parameters: no ordering between them and the target passes).  Needs the
         # memory calibration of an earlier step of the same shape (`_calib`).  MSFWSI_CTX_STREAM=0 turns it off.
         self.ctx_stream = os.environ.get("MSFWSI_CTX_STREAM", "1") != "0"
+        # STAGGER of the two target streams.  Two passes that start together run the same layer at the same time: both
+        # HBM-bound in layer1-2, both MFMA-bound in layer3-4 -- the streams share a bottleneck instead of complementing
+        # each other.  With the stagger view 1 starts when view 0 has finished stage `stagger_fwd` of its forward (its
+        # backward: when view 0's backward has come down through stage `stagger_bwd`), so one stream's MFMA-bound deep
+        # layers run beside the other's HBM-bound shallow ones.  -1 = start together.  MSFWSI_STAGGER="f,b".
+        # OFF by default: measured (A/B on one box, two rounds, profiles/r04_ab_stagger.txt) 518.3 / 517.0 ms with "1,2",
+        # 514.0 / 515.0 with "0,3", 521.8 / 523.8 with "2,1", 513.6 / 512.3 with "-1,2" against 516.2 / 513.2 without: what
+        # the complementary middle gains, the head and tail where one stream runs alone lose again.
+        st = os.environ.get("MSFWSI_STAGGER", "-1,-1").split(",")
+        self.stagger_fwd, self.stagger_bwd = int(st[0]), int(st[1] if len(st) > 1 else st[0])
+        self._stage_mark: Optional[tuple] = None
         self._calib: Dict[tuple, Tuple[float, float]] = {}
         self._side: Dict[str, torch.cuda.Stream] = {}
         self._bn_order: Optional[Tuple[str, dict]] = None
@@ -1013,6 +1025,9 @@ class Engine:
             f = torch.empty(N, y.shape[-1], dtype=dtype, device=x.device)
             kn.gap_fwd(y, f, N, h * w, y.shape[-1])
             feats.append(f)
+            mark = self._stage_mark
+            if mark is not None and mark[0] == "fwd" and mark[1] == si:  # see Engine.stagger
+                mark[2].record(torch.cuda.current_stream(x.device))
         if not save:
             return EncPass(enc, N, H, W, None, None, None, None, [], feats, x_src=x, saved=False)
         return EncPass(enc, N, H, W, xin, stem, pooled, amax, blocks, feats)
@@ -1150,6 +1165,10 @@ class Engine:
             dy, pre = self._block_bwd(rec, dy, gapg, grads, dtype, pre=pre, gate=gate)
             rec.units = []  # release activations
             rec.ds = None
+            mark = self._stage_mark
+            if (mark is not None and mark[0] == "bwd" and mark[1] == rec.stage
+                    and (i == 0 or ps.blocks[i - 1].stage != rec.stage)):  # the first block of that stage is done
+                mark[2].record(torch.cuda.current_stream(dy.device))
         self._stem_bwd(ps, dy, grads, dtype, dstem)
 
     def _stem_bwd(self, ps: EncPass, dy: torch.Tensor, grads: GradStore, dtype: torch.dtype,
@@ -1702,7 +1721,14 @@ class Engine:
                         self._bn_order = ("follow", ev_c)
                         rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
                 self._bn_order = ("lead", ev_t)
-                rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
+                go = torch.cuda.Event() if 0 <= self.stagger_fwd < 3 else None
+                self._stage_mark = ("fwd", self.stagger_fwd, go) if go is not None else None
+                try:
+                    rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
+                finally:
+                    self._stage_mark = None
+                if go is not None:
+                    side.wait_event(go)  # view 1 starts when view 0 has left the HBM-bound stages (Engine.stagger)
                 with torch.cuda.stream(side):
                     self._bn_order = ("follow", ev_t)
                     rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype, save="t1" not in nosave)
@@ -1717,6 +1743,8 @@ class Engine:
         rec.dual = dual
         rec.tri = tri
         self.last_shape = (B, K, shape_key)
+        if self.before_heads is not None:
+            self.before_heads()  # a trainer's hook: e.g. wait for the previous step's Adam pass over the heads' weights
         rec.nosave = nosave
         rec.pair_bwd = self._pair_bwd
         outs = {}
@@ -1808,16 +1836,29 @@ class Engine:
         tri = dual and rec.tri
         third = self._side_stream(dev, "ctx") if tri else None
 
+        go_b = torch.cuda.Event() if (dual and 0 < self.stagger_bwd <= 3) else None
+
         def run(name, df):
             st = third if (tri and name.startswith("c")) else (side if dual and name.endswith("1") else None)
             if st is not None:
                 for d in df:
                     if d is not None:
                         d.record_stream(st)
+                if st is side and go_b is not None and go_b_set[0]:
+                    side.wait_event(go_b)  # view 1's backward starts when view 0's has come down to the shallow stages
                 with torch.cuda.stream(st):
                     self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
             else:
-                self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
+                mark = go_b is not None and name == "t0" and rec.enc[name].saved
+                self._stage_mark = ("bwd", self.stagger_bwd, go_b) if mark else None
+                try:
+                    self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
+                finally:
+                    self._stage_mark = None
+                if mark:
+                    go_b_set[0] = True
+
+        go_b_set = [False]
 
         if dual:
             side.wait_stream(main)  # the heads' backward produced the feature gradients

@@ -27,15 +27,62 @@ def poison(gib=6):
     del blocks
 
 
+def trainer_mode(arch, B, size, dtype, reps, mode):
+    """the FUSED trainer: `reps` times a freshly built, identically seeded model + PretrainStep run 4 steps (the first on
+    one stream, the others on three, the inter_ group's Adam pass under the next step's encoder passes), free blocks
+    poisoned between steps; the 4 losses and every updated weight are compared BITWISE with the first repetition.  Run it
+    with MSFWSI_WGRAD_MAX_SPLITS=1 (the reproducible mode): then any difference is a race between streams -- a missing
+    event, a block handed to another stream too early -- not the order of atomic additions."""
+    from msf_wsi_amd.train import PretrainStep
+    from oracle import msfwsi_oracle as orc
+
+    first, bad = None, 0
+    for r in range(reps):
+        model = build_product(arch, residual_gain=0.1).cuda().train()
+        ts = PretrainStep(model, lr=1e-3, global_batch=B, dtype=dtype, arch=arch)
+        losses, plans = [], []
+        for t in range(4):
+            (c1, c2), (t1, t2), idx = orc.make_batch("diverse", B, size, 16, t)
+            losses.append(ts.step(((c1.cuda(), c2.cuda()), (t1.cuda(), t2.cuda()), idx)))
+            plans.append(ts.engine.last_plan)
+            if "poison" in mode:
+                torch.cuda.synchronize()
+                poison(2)
+        torch.cuda.synchronize()
+        cur = {"loss": torch.stack(losses).cpu().clone()}
+        cur.update({n: p.detach().float().cpu().clone() for n, p in model.named_parameters()})
+        if r == 0:
+            first = cur
+            print(f"  plans of the 4 steps: {plans}; losses {[round(float(x), 6) for x in cur['loss'].ravel()]}", flush=True)
+        else:
+            # weights: bitwise.  The loss is an fp64 accumulator filled by atomic additions of 24 cosine kernels: their
+            # order moves it by ~1e-16 relative (measured), which no weight ever sees
+            diff = [k for k in cur if k != "loss" and not torch.equal(cur[k], first[k])]
+            if not torch.allclose(cur["loss"], first["loss"], rtol=1e-12, atol=1e-15):
+                diff.append("loss")
+            if diff or not torch.isfinite(cur["loss"]).all():
+                bad += 1
+                k = diff[0] if diff else "loss"
+                d = float((cur[k].double() - first[k].double()).norm() / (first[k].double().norm() + 1e-30))
+                print(f"  repetition {r}: {len(diff)}/{len(cur)} tensors differ from repetition 0; first {k}: rel {d:.2e}", flush=True)
+        del ts, model
+    print(f"[race_check trainer {arch} B={B} size={size} {mode} splits-cap={os.environ.get('MSFWSI_WGRAD_MAX_SPLITS', 'none')}] "
+          f"{reps} repetitions of 4 steps: {bad} not bitwise equal to the first", flush=True)
+    return bad
+
+
 def main():
     arch = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     size = int(sys.argv[3]) if len(sys.argv) > 3 else 64
     dname = sys.argv[4] if len(sys.argv) > 4 else "bf16"
     reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
-    mode = sys.argv[6] if len(sys.argv) > 6 else "train"  # "train" | "nograd" (forward only under torch.no_grad) | +"-poison"
+    mode = sys.argv[6] if len(sys.argv) > 6 else "train"  # "train" | "nograd" (forward only under torch.no_grad) | "trainer" (fused multi-stream step) | +"-poison"
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dname]
     from oracle import msfwsi_oracle as orc  # inputs only (this is a test tool)
+
+    if mode.startswith("trainer"):
+        sys.exit(1 if trainer_mode(arch, B, size, dtype, reps, mode) else 0)
 
     (c1, c2), (t1, t2), idx = orc.make_batch("diverse", B, size, 16, 0)
     model = build_product(arch, residual_gain=0.1).cuda().train()
