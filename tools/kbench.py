@@ -198,7 +198,12 @@ CASES = {"deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide,
 
 
 def main():
-    _lib.load()
+    lib = _lib.load()
+    for kv in os.environ.get("KBENCH_TUNE", "").split(","):  # e.g. KBENCH_TUNE="0=1073741824" (msfwsi_set_tuning keys)
+        if kv:
+            k, v = kv.split("=")
+            lib.msfwsi_set_tuning(int(k), int(v))
+            print(f"# msfwsi_set_tuning({k}, {v})", flush=True)
     for name in (sys.argv[1:] or list(CASES)):
         CASES[name]()
 
