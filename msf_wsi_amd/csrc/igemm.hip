@@ -35,6 +35,9 @@
 #ifndef MSFWSI_STAGGER
 #define MSFWSI_STAGGER 0  // 1: the second half of a workgroup's waves (the SIMD partners of the first half) issue the DMA requests AFTER their MFMAs
 #endif
+#ifndef MSFWSI_ABLATE
+#define MSFWSI_ABLATE 0  // diagnostic builds (tools/build_variant.sh): 1 = pure-DMA kernel without its k loop (epilogue only),
+#endif                   // 2 = without the epilogue's global loads / stores (k loop + LDS transposition only).  WRONG RESULTS.
 #ifndef MSFWSI_FETCH_FIRST
 #define MSFWSI_FETCH_FIRST 1  // DMA requests of slab kt+2 before the MFMAs of slab kt (0: after them; A/B: make EXTRA=-DMSFWSI_FETCH_FIRST=0)
 #endif
@@ -195,7 +198,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
     const int cc = tid % CPR;
     const int rr = tid / CPR;
     const int ncol = n0 + cc * VEC;
-    const bool col_ok = ncol < prm.Nout;
+    const bool col_ok = MSFWSI_ABLATE == 2 ? (ncol < 0) : (ncol < prm.Nout);
     T* __restrict__ out = reinterpret_cast<T*>(prm.out);
     const T* __restrict__ resid = reinterpret_cast<const T*>(prm.resid);
     float ssum[VEC], ssq[VEC];
@@ -1035,10 +1038,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     };
 
     // ---------------- main loop: TWO slabs in flight, counted vmcnt ----------------
-    const int nk = prm.Ktot / BK;
+    const int nk = MSFWSI_ABLATE == 1 ? 0 : prm.Ktot / BK;
     constexpr int DMA_PER_SLAB = A_IT + NB;
     static_assert(DMA_PER_SLAB >= 2 && DMA_PER_SLAB <= 6, "unexpected DMA count per slab");
-    fetch(0);
+    if (nk > 0) fetch(0);
     if (nk > 1) fetch(1);
     int st_c = 0, st_f = 2;
     for (int kt = 0; kt < nk; ++kt) {
