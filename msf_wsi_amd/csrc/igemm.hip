@@ -1220,10 +1220,6 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
         g_small_grid_blocks = value;
         return MSFWSI_OK;
     }
-    if (key == 5) {
-        g_s2_parity = value;
-        return MSFWSI_OK;
-    }
     if (key == 0) {
         g_big_tile_min_blocks = value;
         return MSFWSI_OK;
