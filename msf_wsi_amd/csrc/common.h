@@ -284,7 +284,8 @@ __device__ __forceinline__ int fresh_lane() {
 // RULE: a kernel stages EITHER through this asm path OR through the compiler-tracked builtin
 // (__builtin_amdgcn_global_load_lds: wdma16 / dma16 of the register-address kernels), never both in one instance: the
 // asm loads are invisible to SIInsertWaitcnts, so a mixed kernel's compiler-inserted waits would under-count.  The
-// -DMSFWSI_ASM_DMA=0 build (make asmdma0) is the A/B correctness reference of the hand-counted waits.
+// -DMSFWSI_ASM_DMA=0 build (tools/build_variant.sh asmdma0 "-DMSFWSI_ASM_DMA=0", then MSFWSI_LIB=ab/libmsfwsi_asmdma0.so) is the A/B
+// correctness reference of the hand-counted waits: the kernel and production test files pass on it unchanged (round 4).
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef MSFWSI_ASM_DMA
 #define MSFWSI_ASM_DMA 1
