@@ -172,6 +172,7 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+_TIMER_LOCK = threading.Lock()
 
 
 _TCODE = {4: "f", 2: "DF16b"}  # Itanium codes of float / __bf16 (fp16 "DF16_" is set by the caller's dtype)
@@ -240,9 +241,10 @@ def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = 
         esize if kind != "conv_wgrad" else 4) * (d.K * d.R * d.S * d.C + nout * extra_k)
     tcode = "DF16_" if dtype == torch.float16 else _TCODE[esize]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = fn()
-    e1.record()
+    with _TIMER_LOCK:  # two view passes in lockstep share the stream: the pair must bracket exactly this launch
+        e0.record()
+        r = fn()
+        e1.record()
     shape = f"N{d.N} {d.H}x{d.W} C{d.C}->K{d.K} {d.R}x{d.S}/s{d.stride}" + (" +src2" if two else "") + (
         f" epi{epi}" if epi else "") + (f" +{extra_elems * esize >> 20}MiB epilogue" if extra_elems else "")
     TIMER.records.append((kind, symbol_override or _symbol(kind, d, tcode, pro, halo, epi, two), flops, nbytes, e0, e1,
@@ -255,9 +257,10 @@ def _stream_timed(name: str, nbytes: float, fn):
     if TIMER is None or TIMER.stream_records is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = fn()
-    e1.record()
+    with _TIMER_LOCK:
+        e0.record()
+        r = fn()
+        e1.record()
     TIMER.stream_records.append((name, float(nbytes), e0, e1))
     return r
 
