@@ -151,6 +151,34 @@ def test_rccl_path_executes_single_rank():
     assert abs(c["config"]["loss"] - b["config"]["loss"]) <= 1e-4 * max(1.0, abs(b["config"]["loss"]))
 
 
+def test_bench_line_contract_with_streams():
+    """the driver-facing contract of bench.py on the default (three-stream) schedule: ONE JSON line with the metric fields,
+    a `roofline` object measured on the extra one-stream step (an event pair on a shared stream brackets queueing), the
+    plan of the run and the plan an 8-rank run would choose, and a `cpu_baseline` object on the CPUs the cgroup grants"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--arch", "resnet18", "--batch",
+           "16", "--size", "64", "--cpu-budget", "1"]
+    r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["vs_baseline"] is None and d["value"] > 0
+    assert "workload" in d["config"] and "dual-stream+context-stream" in d["config"]["recompute_plan"], d["config"]
+    assert d["config"]["plan_at_8_ranks"].startswith("keep-all")
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "measured_on"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and rf["concurrent_streams_in_timed_region"] == 3
+    assert "ONE stream" in rf["measured_on"] and 0.02 < rf["timed_fraction_of_step"] <= 1.05, rf
+    cb = d["cpu_baseline"]
+    from oracle.hostcpu import usable_cpus
+
+    assert cb["kind"] == "port" and cb["cores"] == usable_cpus() and cb["value"] > 0
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(8, 64), (4096, 512), (130, 2304)])
 def test_colstats_survives_cancellation(hip_lib, dt, shape):
