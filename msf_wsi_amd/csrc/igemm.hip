@@ -37,7 +37,8 @@
 #endif
 #ifndef MSFWSI_ABLATE
 #define MSFWSI_ABLATE 0  // diagnostic builds (tools/build_variant.sh): 1 = pure-DMA kernel without its k loop (epilogue only),
-#endif                   // 2 = without the epilogue's global loads / stores (k loop + LDS transposition only).  WRONG RESULTS.
+#endif                   // 2 = without the epilogue's global loads / stores (k loop + LDS transposition only), 3 = 3x3 launches
+                         // without the activation DMA pieces of the filter taps s = 1, 2.  WRONG RESULTS.
 #ifndef MSFWSI_FETCH_FIRST
 #define MSFWSI_FETCH_FIRST 1  // DMA requests of slab kt+2 before the MFMAs of slab kt (0: after them; A/B: make EXTRA=-DMSFWSI_FETCH_FIRST=0)
 #endif
@@ -954,6 +955,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         char* Ab = As + buf * Cfg::A_BYTES + wave * 1024;
         char* Bb = Bs + buf * Cfg::B_BYTES + wave * 1024;
         const int soff_a = soff_tap + tap_c * ES;
+#if MSFWSI_ABLATE == 3  // diagnostic: what would a 3x3 launch cost if the taps s = 1, 2 of a filter row re-used the staged rows of s = 0
+        if (!(RS == 9 && tap_s != 0))
+#endif
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) dma16_buf(srd_a, Ab + i * NW * 1024, voff_eff[i], soff_a);
         // weight rows of this slab: channel tap_c, tap tap_t of the [k][r][s][n] tensor (parity mode: the 3x3 tensor's tap
