@@ -109,6 +109,43 @@ int msfwsi_conv_dgrad2(const msfwsi_conv_desc* d, const void* dy, const void* w_
                        const float* bias, const void* mask_c, const float* mask_scale, const float* mask_shift,
                        double* sums, int nshard, void* stream);
 
+/* ---- activation-stationary ("panel") 1x1 convolutions: short k, wide output (csrc/panel.hip) -------------------
+ * For the w -> 4w / 4w <- w convolutions of a Bottleneck (src/models/resnet.py:124,131): the [128 x k] operand panel of
+ * a workgroup is read from HBM once, optionally TRANSFORMED on the way into LDS -- the BatchNorm+ReLU of the producer
+ * (resnet.py:128-130) or the BatchNorm backward dc = k1*g + k2*c + k3 -- and stays resident while every 32-channel
+ * output block streams past it; weights come pre-packed in MFMA fragment order.  16-bit storage types, 1x1 / stride 1,
+ * k in {64, 128, 256, 512}, output channels >= 128 and a multiple of 32; otherwise MSFWSI_EUNSUPPORTED (callers then
+ * use msfwsi_conv_fwd_post / msfwsi_conv_dgrad). */
+
+/* 1 if the panel kernels serve the 1x1 convolution d (dgrad = 0: forward, k = d->C, outputs d->K; 1: input gradient,
+ * k = d->K, outputs d->C). */
+int msfwsi_panel_supported(const msfwsi_conv_desc* d, int dgrad);
+
+/* wpk[n/32][k/16][64][8] <- W(n, k) = w[n * stride_n + k * stride_k]: the weight operand in MFMA fragment order (one
+ * contiguous KiB per 32-channel block and 16-deep k step).  Forward of W[K][C]: Nout = K, K = C, strides (C, 1); input
+ * gradient (the same tensor read as [k = K][n = C]): Nout = C, K = K, strides (1, C).  Nout % 32 == 0, K % 16 == 0. */
+int msfwsi_panel_pack_weights(int dtype, const void* w, void* wpk, int Nout, int K, long stride_n, long stride_k,
+                              void* stream);
+
+/* y = [relu]( round(act(x) . W^T) * post_scale + post_shift + ident ) with act(x) = relu(pro_scale*x + pro_shift) when
+ * pro_* != NULL (x is then the producer's RAW conv output: bn2 + ReLU of resnet.py:128-130 applied while the panel is
+ * staged), else x itself.  Everything else as msfwsi_conv_fwd_post.  Replaces conv3 + bn3 + residual + ReLU,
+ * src/models/resnet.py:131-138, without the normalised operand ever being stored. */
+int msfwsi_panel_fwd_post(const msfwsi_conv_desc* d, const void* x, const float* pro_scale, const float* pro_shift,
+                          const void* wpk, void* y, const float* post_scale, const float* post_shift, const void* ident,
+                          int relu, unsigned char* gate_out, void* stream);
+
+/* dx = gate( round(dc . W) + resid + gap_scale * gapg[image] ), sums[shard][0][C] += dx   (msfwsi_conv_dgrad's epilogue
+ * with mask_bits), where dc = k1*dy + k2*c + k3 per channel when c != NULL -- the BatchNorm backward
+ * (msfwsi_bn_bwd_apply) of the layer whose raw output is c, formed while the panel is staged; dc_out (nullable) receives
+ * dc [N,P,Q,K] for the weight gradient.  c == NULL: dc = dy.  resid_stride 2: low-resolution residual as in
+ * msfwsi_conv_dgrad.  Replaces batch_norm_backward + convolution_backward(input) of conv1 / bn1 of a Bottleneck
+ * (src/models/resnet.py:124-126) reached through scaler.scale(loss).backward(), tools/ssl_train.py:472. */
+int msfwsi_panel_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c, const float* k1, const float* k2,
+                       const float* k3, void* dc_out, const void* wpk, void* dx, const void* resid, int resid_stride,
+                       const void* gapg, float gap_scale, const unsigned char* mask_bits, double* sums, int nshard,
+                       void* stream);
+
 /* Specialised 3x3 / stride 1 / pad 1 path: the input patch of 256 raster pixels (+ halo) is staged once per
  * channel slab in LDS and reused by all nine taps (see csrc/conv3x3.hip).  Same results as msfwsi_conv_fwd /
  * msfwsi_conv_dgrad without prologue/bias/gapg; `supported` tells whether a geometry qualifies.

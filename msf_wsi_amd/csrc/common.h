@@ -138,6 +138,35 @@ __device__ __forceinline__ uint4 pack16<_Float16>(const float* f) {
     return __builtin_bit_cast(uint4, h);
 }
 
+// ReLU gate of one STORED 16-byte chunk: bit e = (element e > 0), taken from the packed value so that the bits equal
+// the sign test of the tensor in memory bit for bit (an fp32 value that rounds to zero in the storage type is closed)
+template <typename T>
+__device__ __forceinline__ unsigned gate_bits_of(const uint4& v);
+template <>
+__device__ __forceinline__ unsigned gate_bits_of<float>(const uint4& v) {
+    return (__uint_as_float(v.x) > 0.f ? 1u : 0u) | (__uint_as_float(v.y) > 0.f ? 2u : 0u) |
+           (__uint_as_float(v.z) > 0.f ? 4u : 0u) | (__uint_as_float(v.w) > 0.f ? 8u : 0u);
+}
+__device__ __forceinline__ unsigned gate_bits16(const uint4& v) {
+    // a 16-bit float is > 0 exactly when its bit pattern, read as a signed 16-bit integer, is > 0 (NaNs aside)
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned b = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        b |= ((short)(w[i] & 0xffffu) > 0 ? 1u : 0u) << (2 * i);
+        b |= ((int)w[i] > 0xffff ? 1u : 0u) << (2 * i + 1);
+    }
+    return b;
+}
+template <>
+__device__ __forceinline__ unsigned gate_bits_of<__bf16>(const uint4& v) {
+    return gate_bits16(v);
+}
+template <>
+__device__ __forceinline__ unsigned gate_bits_of<_Float16>(const uint4& v) {
+    return gate_bits16(v);
+}
+
 // value of one element after a round trip through the storage type T
 template <typename T>
 __device__ __forceinline__ float round_to(float f);

@@ -314,10 +314,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 if (gate_out != nullptr) {
                     // one byte per 16-byte chunk: the ReLU gate of this output for the backward pass (read there
                     // instead of the 16 bytes of the activation itself)
-                    unsigned b = 0;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
-                    gate_out[pixm * (prm.Nout / VEC) + (ncol / VEC)] = (unsigned char)b;
+                    gate_out[pixm * (prm.Nout / VEC) + (ncol / VEC)] = (unsigned char)gate_bits_of<T>(v);
                 }
             }
             if (mask_c != nullptr) {
@@ -1222,6 +1219,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 4) {
         g_small_grid_blocks = value;
+        return MSFWSI_OK;
+    }
+    if (key == 5) {
+        g_s2_parity = value;
         return MSFWSI_OK;
     }
     if (key == 0) {

@@ -187,6 +187,22 @@ class FlatGroups:
                     return
         raise KeyError("parameter is not part of the flat groups")
 
+    def unmark_stored(self, p: torch.Tensor) -> bool:
+        """the engine ACCUMULATES into this parameter's gradient this step: if an earlier step stored it, zero_grads has
+        skipped its range and it still holds that step's gradient -- clear it now and let zero_grads cover it again.
+        True when the parameter had been marked."""
+        for gi, plist in enumerate(self.params):
+            for pi, q in enumerate(plist):
+                if q is p:
+                    lo = self.offsets[gi][pi]
+                    rng = (lo, lo + p.numel())
+                    if rng in self._stored.get(gi, ()):
+                        self._stored[gi].discard(rng)
+                        self.g[gi][rng[0]:rng[1]].zero_()
+                        return True
+                    return False
+        raise KeyError("parameter is not part of the flat groups")
+
     def range_of(self, gi: int, name_prefix: str) -> Tuple[int, int]:
         """[lo, hi) element range of group gi's flat buffers that holds the parameters whose names start with
         `name_prefix` (e.g. "inter_projector.3."): they are adjacent in named_parameters() order, hence contiguous"""

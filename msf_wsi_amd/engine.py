@@ -1599,6 +1599,8 @@ class Engine:
                 if hasattr(grads, "mark_stored"):
                     grads.mark_stored(u0.op.weight)
             else:
+                if hasattr(grads, "unmark_stored"):
+                    grads.unmark_stored(u0.op.weight)  # stored on an earlier step: holds stale values, not zeros
                 kn.conv_wgrad(dpair, xcat, dcat, grads.get(u0.op.weight))
             bias = getattr(u0.op, "bias", None)
             if bias is not None:

@@ -461,6 +461,100 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mas
     return dx
 
 
+# ---- activation-stationary ("panel") 1x1 kernels (csrc/panel.hip) -----------------------------------------------
+def panel_supported(d: ConvDesc, dgrad: bool) -> bool:
+    return bool(_lib.load().msfwsi_panel_supported(C.byref(d), int(bool(dgrad))))
+
+
+def panel_pack_weights(w, wpk, nout: int, k: int, stride_n: int, stride_k: int):
+    """wpk[n/32][k/16][64][8] <- W(n, k) = w.flat[n*stride_n + k*stride_k] (MFMA fragment order)"""
+    lib = _lib.load()
+    dt = w.dtype
+    _req(w, "w", dt, nout * k)
+    _req(wpk, "wpk", dt, nout * k)
+    _lib.check(lib.msfwsi_panel_pack_weights(dt_of(w), _p(w), _p(wpk), int(nout), int(k), int(stride_n), int(stride_k),
+                                             _stream()), "panel_pack_weights")
+    return wpk
+
+
+def _panel_symbol(d: ConvDesc, dt, k: int, pro: int, epi: int) -> str:
+    tcode = "DF16_" if dt == torch.float16 else "DF16b"
+    return f"panel_kernelI{tcode}Li{k}ELi{64 if k == 512 else 128}ELi{pro}ELi{epi}E"
+
+
+def panel_fwd_post(d: ConvDesc, x, wpk, y, post_scale, post_shift, pro=None, ident=None, relu=True, gate_out=None) -> bool:
+    """y = [relu](round(act(x) . W^T) * post_scale + post_shift + ident), act = relu(pro_scale*x + pro_shift) when pro is
+    given (x = the producer's raw conv output); False if the library has no panel kernel for the shape"""
+    lib = _lib.load()
+    dt = x.dtype
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(wpk, "wpk", dt, d.K * d.C)
+    _req(y, "y", dt, d.N * d.P * d.Q * d.K)
+    _req(post_scale, "post_scale", torch.float32, d.K)
+    _req(post_shift, "post_shift", torch.float32, d.K)
+    ps = psh = None
+    if pro is not None:
+        ps, psh = pro
+        _req(ps, "pro_scale", torch.float32, d.C)
+        _req(psh, "pro_shift", torch.float32, d.C)
+    _opt(ident, "ident", dt, d.N * d.P * d.Q * d.K)
+    _opt(gate_out, "gate_out", torch.uint8, d.N * d.P * d.Q * (d.K // vec_of(dt)))
+    rc = _timed("conv_fwd", d, x.element_size(), lambda: lib.msfwsi_panel_fwd_post(
+        C.byref(d), _p(x), _p(ps), _p(psh), _p(wpk), _p(y), _p(post_scale), _p(post_shift), _p(ident), int(bool(relu)),
+        _p(gate_out), _stream()), extra_elems=ident.numel() if ident is not None else 0, dtype=dt, epi=1,
+        symbol_override=_panel_symbol(d, dt, d.C, 1 if pro is not None else 0, 1))
+    if rc == -2:
+        return False
+    _lib.check(rc, "panel_fwd_post")
+    return True
+
+
+def panel_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, resid=None, resid_stride=1, gapg=None, gap_scale=0.0,
+                mask_bits=None, sums=None) -> bool:
+    """dx = gate(round(dc . W) + resid + gap_scale*gapg), sums slot 0 += dx; dc = k1*dy + k2*c + k3 when bnbwd = (c, k1,
+    k2, k3) (written to dc_out if given), else dy.  False if the library has no panel kernel for the shape"""
+    lib = _lib.load()
+    dt = dy.dtype
+    _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
+    _req(wpk, "wpk", dt, d.K * d.C)
+    _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
+    c = k1 = k2 = k3 = None
+    if bnbwd is not None:
+        c, k1, k2, k3 = bnbwd
+        _req(c, "c", dt, d.N * d.P * d.Q * d.K)
+        for nm, t in (("k1", k1), ("k2", k2), ("k3", k3)):
+            _req(t, nm, torch.float32, d.K)
+        _opt(dc_out, "dc_out", dt, d.N * d.P * d.Q * d.K)
+    elif dc_out is not None:
+        raise ValueError("dc_out without bnbwd")
+    if resid_stride > 1:
+        _req(resid, "resid", dt, d.N * ((d.H - 1) // resid_stride + 1) * ((d.W - 1) // resid_stride + 1) * d.C)
+    else:
+        _opt(resid, "resid", dt, d.N * d.H * d.W * d.C)
+    _opt(gapg, "gapg", dt, d.N * d.C)
+    nsh = 1
+    if mask_bits is not None:
+        _req(mask_bits, "mask_bits", torch.uint8, d.N * d.H * d.W * (d.C // vec_of(dt)))
+        _req(sums, "sums", torch.float64)
+        nsh = sums.numel() // (2 * d.C)
+        if nsh * 2 * d.C != sums.numel():
+            raise ValueError("sums must be [nshard,2,C]")
+    elif sums is not None:
+        raise ValueError("sums without mask_bits")
+    extra = (resid.numel() if resid is not None else 0) + (dx.numel() // 16 if mask_bits is not None else 0)
+    if bnbwd is not None:
+        extra += dy.numel() * (2 if dc_out is not None else 1)  # c read, dc written
+    rc = _timed("conv_dgrad", d, dy.element_size(), lambda: lib.msfwsi_panel_dgrad(
+        C.byref(d), _p(dy), _p(c), _p(k1), _p(k2), _p(k3), _p(dc_out), _p(wpk), _p(dx), _p(resid), int(resid_stride),
+        _p(gapg), float(gap_scale), _p(mask_bits), _p(sums), nsh, _stream()), extra_elems=extra, dtype=dt,
+        epi=3 if resid_stride > 1 else 0,
+        symbol_override=_panel_symbol(d, dt, d.K, 2 if bnbwd is not None else 0, 3 if resid_stride > 1 else 0))
+    if rc == -2:
+        return False
+    _lib.check(rc, "panel_dgrad")
+    return True
+
+
 def conv_dgrad2(d: ConvDesc, dy, w_cat, dx, src2, bias=None, mask=None, sums=None) -> bool:
     """dx = gate(dy . w_cat[0:K] + src2 . w_cat[K:] + bias) in one launch (1x1 only); False if the library has no
     kernel for this shape (the caller then adds the second product as a residual)"""

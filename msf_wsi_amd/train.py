@@ -52,6 +52,13 @@ class _FlatGradStore(GradStore):
             self._marked.add(id(param))
             self.flats.mark_stored(param)
 
+    def unmark_stored(self, param):
+        """this step ACCUMULATES into the gradient (more rows than the storing launch takes, or the knob was flipped): a
+        tensor stored on an earlier step still holds that step's values -- clear it and hand it back to zero_grads"""
+        if id(param) in self._marked:
+            self._marked.discard(id(param))
+            self.flats.unmark_stored(param)
+
 
 class FlatAdamScaler:
     """The optimizer half of a fused step, shared by PretrainStep and finetune.FinetuneStep: flat per-group fp32

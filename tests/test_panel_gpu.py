@@ -1,0 +1,198 @@
+"""Activation-stationary ("panel") 1x1 kernels (csrc/panel.hip) on a real MI355X, through the C ABI, against a plain
+PyTorch fp64 CPU reference of the same operator chain on the same seeded, storage-rounded inputs -- the conv3 + bn3 +
+identity + ReLU tail of a Bottleneck (reference src/models/resnet.py:128-138) and the bn1-backward + conv1 input gradient
+(resnet.py:124-126 backwards).  bf16 storage <= 1.5e-2, fp16 storage <= 2e-3 rel-L2 (the bounds of test_kernels_gpu.py);
+gate bits and the written-back BatchNorm-backward operand are compared exactly where the arithmetic allows it."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def tol(dt):
+    return {torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dt]
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def rnd(shape, dt, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dt)
+
+
+def unpack_bits(bits, M, Nout):
+    """[M][Nout/8] bytes -> bool [M][Nout] (bit e of a byte = element e of that chunk)"""
+    b = bits.view(M, Nout // 8).cpu().to(torch.int32)
+    return ((b.unsqueeze(-1) >> torch.arange(8)) & 1).bool().view(M, Nout)
+
+
+# N, H, W, k (operand channels), Nout: ragged last panel (M % 128 != 0), every supported k, one wave idle (Nout 96 -> unsupported)
+GEOMS = [
+    (3, 7, 9, 64, 256),
+    (2, 14, 14, 128, 512),
+    (5, 7, 7, 256, 1024),
+    (3, 5, 5, 512, 2048),
+    (1, 11, 13, 256, 160),   # 5 output blocks: waves with 2 and 1 blocks
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("pro", [False, True])
+@pytest.mark.parametrize("with_ident", [False, True])
+def test_panel_fwd_post(hip_lib, dt, geom, pro, with_ident):
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cn, K = geom
+    M = N * H * W
+    g = torch.Generator().manual_seed(11)
+    x = rnd((M, Cn), dt, g)
+    w = rnd((K, Cn), dt, g, 1.0 / math.sqrt(Cn))
+    ident = rnd((M, K), dt, g)
+    ps = torch.rand(K, generator=g) + 0.5
+    pb = torch.randn(K, generator=g) * 0.2
+    sc = torch.rand(Cn, generator=g) + 0.5
+    sh = torch.randn(Cn, generator=g) * 0.3
+    d = kn.conv_desc(dt, N, H, W, Cn, K, 1, 1, 1, 0)
+    assert kn.panel_supported(d, False)
+    wd = w.cuda()
+    wpk = kn.panel_pack_weights(wd, torch.empty_like(wd), K, Cn, Cn, 1)
+    y = torch.empty(M, K, dtype=dt, device="cuda")
+    bits = kn.gate_bytes(M, K, dt, "cuda")
+    assert kn.panel_fwd_post(d, x.cuda(), wpk, y, ps.cuda(), pb.cuda(), pro=(sc.cuda(), sh.cuda()) if pro else None,
+                             ident=ident.cuda() if with_ident else None, relu=True, gate_out=bits)
+    torch.cuda.synchronize()
+    # fp64 reference of the same chain (the normalised operand rounded to the storage type, as the kernel stages it)
+    a = x.double()
+    if pro:
+        a = torch.relu(a * sc.double() + sh.double()).to(dt).double()
+    ref = (a @ w.double().t()) * ps.double() + pb.double()
+    if with_ident:
+        ref = ref + ident.double()
+    ref = torch.relu(ref)
+    assert rel(y, ref) < tol(dt)
+    # gate bits are the sign of the STORED output, bit for bit
+    assert torch.equal(unpack_bits(bits, M, K), y.cpu().float() > 0)
+    # and the gather kernel's epilogue gives the same tensor up to the summation order
+    y2 = torch.empty_like(y)
+    bits2 = kn.gate_bytes(M, K, dt, "cuda")
+    xin = x.cuda()
+    if pro:
+        xin = torch.empty_like(xin)
+        kn.bn_act(x.cuda(), sc.cuda(), sh.cuda(), xin, relu=True)
+    kn.conv_fwd_post(d, xin, wd, y2, ps.cuda(), pb.cuda(), ident=ident.cuda() if with_ident else None, relu=True,
+                     gate_out=bits2)
+    torch.cuda.synchronize()
+    assert rel(y, y2.float()) < tol(dt)
+    assert torch.equal(unpack_bits(bits2, M, K), y2.cpu().float() > 0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("bnbwd", [False, True])
+@pytest.mark.parametrize("epi", ["plain", "resid", "bits", "bits+resid+gap"])
+def test_panel_dgrad(hip_lib, dt, geom, bnbwd, epi):
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Kc, Cin = geom  # forward conv: x [.., Cin] -> y [.., Kc]; the gradient maps dY [M, Kc] -> dX [M, Cin]
+    M = N * H * W
+    g = torch.Generator().manual_seed(12)
+    dy = rnd((M, Kc), dt, g, 0.1)
+    c = rnd((M, Kc), dt, g)
+    w = rnd((Kc, Cin), dt, g, 1.0 / math.sqrt(Kc))
+    k1 = torch.rand(Kc, generator=g) + 0.5
+    k2 = torch.randn(Kc, generator=g) * 0.05
+    k3 = torch.randn(Kc, generator=g) * 0.05
+    resid = rnd((M, Cin), dt, g, 0.1)
+    gapg = rnd((N, Cin), dt, g, 0.1)
+    bits = torch.randint(0, 256, (M, Cin // 8), dtype=torch.uint8, generator=g)
+    d = kn.conv_desc(dt, N, H, W, Cin, Kc, 1, 1, 1, 0)
+    assert kn.panel_supported(d, True)
+    wd = w.cuda()
+    wpk = kn.panel_pack_weights(wd, torch.empty_like(wd), Cin, Kc, 1, Cin)  # W read as [k = Kc][n = Cin]
+    dx = torch.empty(M, Cin, dtype=dt, device="cuda")
+    dc_out = torch.empty(M, Kc, dtype=dt, device="cuda") if bnbwd else None
+    kw = {}
+    if "resid" in epi:
+        kw["resid"] = resid.cuda()
+    if "gap" in epi:
+        kw.update(gapg=gapg.cuda(), gap_scale=1.0 / (H * W))
+    sums = None
+    if "bits" in epi:
+        sums = kn.new_stats(Cin, 2, "cuda")
+        kw.update(mask_bits=bits.cuda(), sums=sums)
+    assert kn.panel_dgrad(d, dy.cuda(), wpk, dx, bnbwd=(c.cuda(), k1.cuda(), k2.cuda(), k3.cuda()) if bnbwd else None,
+                          dc_out=dc_out, **kw)
+    torch.cuda.synchronize()
+    dc = dy.double()
+    if bnbwd:
+        dc = (k1.double() * dy.double() + k2.double() * c.double() + k3.double()).to(dt).double()
+        # the written-back operand is exactly msfwsi_bn_bwd_apply's result
+        ref_dc = torch.empty(M, Kc, dtype=dt, device="cuda")
+        kn.bn_bwd_apply(dy.cuda(), c.cuda(), k1.cuda(), k2.cuda(), k3.cuda(), ref_dc)
+        torch.cuda.synchronize()
+        assert torch.equal(dc_out.cpu(), ref_dc.cpu())
+        assert rel(dc_out, dc) < tol(dt)
+    ref = dc @ w.double()
+    if "resid" in epi:
+        ref = ref + resid.double()
+    if "gap" in epi:
+        ref = ref + (gapg.double() / (H * W)).repeat_interleave(H * W, dim=0)
+    if "bits" in epi:
+        ref = ref * unpack_bits(bits, M, Cin).double()
+    assert rel(dx, ref) < tol(dt)
+    if sums is not None:
+        got = sums.sum(dim=0)[0].cpu()
+        want = dx.double().sum(dim=0).cpu()  # sums of the STORED gradient
+        assert (got - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+        assert sums[:, 1].abs().max().item() == 0.0  # slot 1 is left alone
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(3, 8, 8, 128, 256), (2, 14, 14, 256, 512), (2, 6, 10, 64, 128)])
+def test_panel_dgrad_lowres_residual(hip_lib, dt, geom):
+    """the strided-downsample residual, added on the even pixels only, equals msfwsi_conv_dgrad's resid_stride = 2"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Kc, Cin = geom
+    M = N * H * W
+    g = torch.Generator().manual_seed(13)
+    dy = rnd((M, Kc), dt, g, 0.1).cuda()
+    w = rnd((Kc, Cin), dt, g, 1.0 / math.sqrt(Kc)).cuda()
+    lo = rnd((N * (H // 2) * (W // 2), Cin), dt, g, 0.1).cuda()
+    gapg = rnd((N, Cin), dt, g, 0.1).cuda()
+    bits = torch.randint(0, 256, (M, Cin // 8), dtype=torch.uint8, generator=g).cuda()
+    d = kn.conv_desc(dt, N, H, W, Cin, Kc, 1, 1, 1, 0)
+    wpk = kn.panel_pack_weights(w, torch.empty_like(w), Cin, Kc, 1, Cin)
+    a, b = torch.empty(M, Cin, dtype=dt, device="cuda"), torch.empty(M, Cin, dtype=dt, device="cuda")
+    sa, sb = kn.new_stats(Cin, 2, "cuda"), kn.new_stats(Cin, 2, "cuda")
+    assert kn.panel_dgrad(d, dy, wpk, a, resid=lo, resid_stride=2, gapg=gapg, gap_scale=1.0 / (H * W), mask_bits=bits, sums=sa)
+    kn.conv_dgrad(d, dy, w, b, resid=lo, resid_stride=2, gapg=gapg, gap_scale=1.0 / (H * W), mask_bits=bits, sums=sb)
+    torch.cuda.synchronize()
+    # fp64 reference
+    full = torch.zeros(N, H, W, Cin, dtype=torch.float64)
+    full[:, ::2, ::2, :] = lo.cpu().double().view(N, H // 2, W // 2, Cin)
+    ref = dy.cpu().double() @ w.cpu().double() + full.view(M, Cin) + (gapg.cpu().double() / (H * W)).repeat_interleave(H * W, dim=0)
+    ref = ref * unpack_bits(bits, M, Cin).double()
+    assert rel(a, ref) < tol(dt)
+    assert rel(a, b.float()) < tol(dt)
+    assert (sa.sum(0)[0] - sb.sum(0)[0]).abs().max().item() <= 2e-3 * max(1.0, sb.sum(0)[0].abs().max().item())
+
+
+def test_panel_unsupported_shapes(hip_lib):
+    """fp32, ragged k, narrow outputs and non-1x1 geometry are refused (the engine then keeps the gather kernel)"""
+    from msf_wsi_amd import kernels as kn
+
+    ok = kn.conv_desc(torch.bfloat16, 2, 7, 7, 256, 1024, 1, 1, 1, 0)
+    assert kn.panel_supported(ok, False) and kn.panel_supported(ok, True) is False  # dgrad: k = 1024 is not a panel width
+    assert not kn.panel_supported(kn.conv_desc(torch.float32, 2, 7, 7, 256, 1024, 1, 1, 1, 0), False)
+    assert not kn.panel_supported(kn.conv_desc(torch.bfloat16, 2, 7, 7, 96, 1024, 1, 1, 1, 0), False)
+    assert not kn.panel_supported(kn.conv_desc(torch.bfloat16, 2, 7, 7, 256, 64, 1, 1, 1, 0), False)
+    assert not kn.panel_supported(kn.conv_desc(torch.bfloat16, 2, 7, 7, 256, 256, 3, 3, 1, 1), False)
+    assert not kn.panel_supported(kn.conv_desc(torch.bfloat16, 2, 8, 8, 256, 512, 1, 1, 2, 0), False)

@@ -528,10 +528,10 @@ def test_stride2_dgrad_by_parity(hip_lib, dt, geom, big):
         w = nhwc(rnd((K, Cc, R, R), dt, g, 0.05)).to(dt).cuda()
         a, b = torch.empty(N, H, W, Cc, dtype=dt, device="cuda"), torch.empty(N, H, W, Cc, dtype=dt, device="cuda")
         kn.conv_dgrad(d, dy, w, a)
-        hip_lib.msfwsi_set_tuning(5, 0)
+        assert hip_lib.msfwsi_set_tuning(5, 0) == 0
         kn.conv_dgrad(d, dy, w, b)
         torch.cuda.synchronize()
         assert rel(a.float(), b.float()) < (1e-6 if dt == torch.float32 else tol(dt))
     finally:
-        hip_lib.msfwsi_set_tuning(5, 1)
-        hip_lib.msfwsi_set_tuning(0, 1024)
+        assert hip_lib.msfwsi_set_tuning(5, 1) == 0
+        assert hip_lib.msfwsi_set_tuning(0, 1024) == 0

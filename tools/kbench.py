@@ -116,6 +116,66 @@ def case_wide():
         del a, y, ident, bits
 
 
+def case_panel():
+    """the activation-stationary kernels (csrc/panel.hip) at the shapes of case `wide` / `epi3`: forward tail with and
+    without the fused BatchNorm+ReLU prologue, conv1 input gradient with and without the fused BatchNorm backward"""
+    for H, Cn, Kw in ((14, 256, 1024), (28, 128, 512), (7, 512, 2048), (56, 64, 256)):
+        N = NIMG
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cn, Kw, 1, 1, 1, 0)
+        a = rnd(M, Cn)
+        w = rnd(Kw, Cn, scale=0.05)
+        wpk = kn.panel_pack_weights(w, torch.empty_like(w), Kw, Cn, Cn, 1)
+        y = torch.empty(M, Kw, dtype=DT, device="cuda")
+        ident = rnd(M, Kw)
+        ps, pb = torch.ones(Kw, device="cuda"), torch.zeros(Kw, device="cuda")
+        sc, sh = torch.ones(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
+        bits = kn.gate_bytes(M, Kw, DT, "cuda")
+        nb = (M * Cn + 2 * M * Kw) * 2 + M * Kw // 8
+        fl = 2.0 * M * Cn * Kw
+        report(f"panel {H}x{H} fwd C{Cn}->K{Kw} post (bn+ident+relu+bits)",
+               timeit(lambda: kn.panel_fwd_post(d, a, wpk, y, ps, pb, ident=ident, relu=True, gate_out=bits)), nb, fl)
+        report(f"panel {H}x{H} fwd C{Cn}->K{Kw} post + bn2/relu prologue",
+               timeit(lambda: kn.panel_fwd_post(d, a, wpk, y, ps, pb, pro=(sc, sh), ident=ident, relu=True, gate_out=bits)), nb, fl)
+        # conv1 input gradient: dY [M][Cn] -> dX [M][Kw]
+        d1 = kn.conv_desc(DT, N, H, H, Kw, Cn, 1, 1, 1, 0)
+        w1 = rnd(Cn, Kw, scale=0.05)
+        wpk1 = kn.panel_pack_weights(w1, torch.empty_like(w1), Kw, Cn, 1, Kw)
+        c1 = rnd(M, Cn)
+        dc = torch.empty(M, Cn, dtype=DT, device="cuda")
+
+        def run(bn):
+            sums = kn.new_stats(Kw, 2, "cuda")
+            kn.panel_dgrad(d1, a, wpk1, y, bnbwd=(c1, sc, sh, sh) if bn else None, dc_out=dc if bn else None, resid=ident,
+                           mask_bits=bits, sums=sums)
+        report(f"panel {H}x{H} dgrad dY{Cn}->dX{Kw} (+resid, bits, sums)", timeit(lambda: run(False)), nb, fl)
+        report(f"panel {H}x{H} dgrad dY{Cn}->dX{Kw} (+resid, bits, sums) + bn1 backward, dc written",
+               timeit(lambda: run(True)), nb + 2 * M * Cn * 2, fl)
+        # what the fused forms replace: the stand-alone passes
+        t = torch.empty_like(a)
+        report(f"      bn_act {H}x{H} C{Cn}", timeit(lambda: kn.bn_act(a, sc, sh, t, relu=True)), 2 * M * Cn * 2)
+        report(f"      bn_bwd_apply {H}x{H} C{Cn}", timeit(lambda: kn.bn_bwd_apply(a, c1, sc, sh, sh, t)), 3 * M * Cn * 2)
+        del a, y, ident, bits, c1, dc, t
+    # the strided-residual class
+    for H, C, K in ((56, 256, 128), (28, 512, 256), (14, 1024, 512)):
+        N = NIMG
+        d = kn.conv_desc(DT, N, H, H, C, K, 1, 1, 1, 0)
+        M = N * H * H
+        dy = rnd(M, K, scale=0.05)
+        w = rnd(K, C, scale=0.05)
+        wpk = kn.panel_pack_weights(w, torch.empty_like(w), C, K, 1, C)
+        dx = torch.empty(M, C, dtype=DT, device="cuda")
+        lo = rnd(N * (H // 2) * (H // 2), C, scale=0.05)
+        bits = torch.randint(0, 256, (M * C // 8,), dtype=torch.uint8, device="cuda")
+
+        def run3():
+            sums = kn.new_stats(C, 2, "cuda")
+            kn.panel_dgrad(d, dy, wpk, dx, resid=lo, resid_stride=2, mask_bits=bits, sums=sums)
+        report(f"panel epi3 {H}x{H} dY{K}->dX{C}: bits+sums+lowres residual", timeit(run3),
+               (M * K + M * C) * 2 + M * C // 8 + lo.numel() * 2, 2.0 * M * K * C)
+        del dy, dx, lo, bits
+
+
 def case_pool():
     N, H, C = NIMG, 112, 64
     P = H // 2
@@ -194,7 +254,7 @@ def case_deep():
         del x, y, dy, dx, dw
 
 
-CASES = {"deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+CASES = {"panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():
