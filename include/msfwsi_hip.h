@@ -461,6 +461,8 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * smallest padded raster the stem's weight-gradient kernel takes, key 14 = 1 the max-pool backward by 2x2 input
  * patches (default 0, measured slower), key 16 = 0 the column-walk max-pool forward / backward (default 1; 0 = one thread per
  * window / pixel) (A/B measurements, tests).
+ * key 17 = 0 runs the panel kernels (csrc/panel.hip) on compiler-counted waits instead of the hand-counted ones (same
+ * arithmetic, bit-identical results: the A/B reference of tools/check_hand_waits.py's static audit).
  * One knob trades speed for run-to-run reproducibility: key 15 = cap on the pixel splits of the gather weight-gradient
  * kernel (0 = none; 1 = each gradient tile summed by one workgroup in pixel order instead of fp32 atomics in arrival
  * order -- the results then differ from the default's by rounding, 4e-7, and are the same on every run). */

@@ -1175,6 +1175,7 @@ extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_os_min(lon
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_patch(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_max_splits(long v);
 extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_walk(long v);
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_panel_set_hand(long v);
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
     if (key == 2) {
@@ -1215,6 +1216,10 @@ extern "C" int msfwsi_set_tuning(int key, long value) {
     }
     if (key == 16) {
         msfwsi_pool_bwd_set_walk(value);
+        return MSFWSI_OK;
+    }
+    if (key == 17) {
+        msfwsi_panel_set_hand(value);
         return MSFWSI_OK;
     }
     if (key == 4) {

@@ -28,6 +28,10 @@
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
+#ifndef MSFWSI_PANEL_ABLATE
+#define MSFWSI_PANEL_ABLATE 0  // diagnostic builds (tools/build_variant.sh), WRONG RESULTS: bit 0 = no output / gate stores, bit 1 = no
+#endif                         // MFMAs, bit 2 = no weight-fragment reloads, bit 3 = no epilogue-operand loads, bit 4 = no staging loads
+
 namespace {
 
 struct PanelParams {
@@ -75,22 +79,309 @@ __device__ __forceinline__ uint2 pack4<_Float16>(float a, float b, float c, floa
     return make_uint2(pack2_f16(a, b), pack2_f16(c, d));
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ uint4 as_uint4(const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); }
+
+// Global loads of the block loop, in two forms.  HAND = true (whole panels: every workgroup but possibly the last): inline
+// asm, invisible to hipcc's wait-count pass, completion tracked by hand-counted `s_waitcnt vmcnt(N)` statements that name the
+// destination "+v" (so that no consumer is scheduled above the wait; form (ii) of the HIP guide's inline-asm section).
+// Why: the loop is software-pipelined ACROSS iterations (operands of block j+1 are requested during block j), and for
+// loads whose results cross the loop's back edge hipcc falls back to `vmcnt(<small>)` at the first use -- every block
+// began by draining the queue, i.e. by waiting for the identity loads issued a moment earlier (1.0 -> 1.25 ms per launch).
+// HAND = false (the ragged last panel): plain loads, hipcc's own waits.
+template <bool HAND>
+__device__ __forceinline__ void pl_load16(u32x4& dst, const void* sbase, unsigned voff) {
+    if constexpr (HAND) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    } else {
+        dst = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(sbase) + voff);
+    }
+}
+template <bool HAND>
+__device__ __forceinline__ void pl_load4(unsigned& dst, const void* sbase, unsigned voff) {
+    if constexpr (HAND) {
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    } else {
+        dst = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(sbase) + voff);
+    }
+}
+// at most N vector-memory operations younger than the one that fills `r` may still be outstanding
+template <bool HAND, int N>
+__device__ __forceinline__ void pl_wait(u32x4& r) {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
+}
+template <bool HAND, int N>
+__device__ __forceinline__ void pl_wait(u32x4& r, unsigned& r2) {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r), "+v"(r2) : "n"(N) : "memory");
+}
+
+// The block loop of one wave.  Vector-memory operations per block, in program order (HAND mode: all unconditional):
+//   k loop     : KS weight-fragment loads (the NEXT block's)
+//   epilogue   : per row group t -- [gate-byte load], operand load (both the next block's), [gate store], output store;
+//                then (forward) four loads of the next block's BatchNorm scale / shift chunks
+// so every load is followed by exactly KS - 1 + NL + NS younger operations before its first consumer (NL loads, NS
+// stores per epilogue): ONE constant serves every hand-counted wait.
+template <typename T, int K, int BM, int EPI, bool HAND>
+__device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel, char* scratch, float* colsum, long m0,
+                                             int rows_left, int wave, int lane) {
+    constexpr int NW = 4;
+    constexpr int TM = BM / 32, NG = TM * 2, KS = K / 16, ROWB = K * 2;
+    constexpr int SCR_PITCH = 80;
+    constexpr bool FWD = EPI == 1, LORES = EPI == 3;
+    typedef typename MmaFrag<T>::type frag_t;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nblk = prm.Nout >> 5;
+    // per-lane constants of the transposed epilogue: chunk q = lane & 3 of rows (lane >> 2) and 16 + (lane >> 2).
+    // Every global access of the loop is "wave-uniform 64-bit base + 32-bit lane offset" (saddr form: one VGPR of address
+    // for all row tiles instead of a 64-bit pair each -- with per-lane 64-bit addresses the 256-channel instances spilled)
+    const int q = lane & 3, r4 = lane >> 2;
+    const int nbyte = prm.Nout >> 3;  // gate bytes per row
+    const int PQ = prm.P * prm.Q;
+    const char* eop_wg = reinterpret_cast<const char*>(FWD ? prm.ident : prm.resid);
+    const bool has_eop = eop_wg != nullptr;
+    if (!LORES && has_eop) eop_wg += m0 * prm.Nout * 2;
+    char* out_wg = reinterpret_cast<char*>(prm.out) + m0 * prm.Nout * 2;
+    const unsigned char* mb_wg = (!FWD && prm.mask_bits != nullptr) ? prm.mask_bits + m0 * nbyte : nullptr;
+    unsigned char* go_wg = (FWD && prm.gate_out != nullptr) ? prm.gate_out + m0 * nbyte : nullptr;
+    const unsigned row_off = (unsigned)r4 * (unsigned)prm.Nout * 2u + (unsigned)q * 16u;  // byte offset of (row r4, chunk q)
+    const unsigned bit_off = (unsigned)r4 * (unsigned)nbyte;
+    // HAND mode is entered only with an operand tensor / gate bytes present wherever the epilogue class has them: its
+    // operation counts are compile-time constants
+    constexpr int NL = NG * (FWD ? 1 : 2) + (FWD ? 4 : 0);  // loads per epilogue
+    constexpr int NS = NG * (FWD ? 2 : 1);                  // stores per epilogue (forward: gate dword + output)
+    constexpr int NWAIT = KS - 1 + NL + NS;
+    static_assert(NWAIT <= 63, "operation count per block exceeds the vmcnt range");
+
+    // The epilogue operands (identity / residual chunk, gate bytes) of row group t of output block cb.  Loads are
+    // unconditional: a lane past the tensor's end re-reads row 0 of the panel, and in LORES mode an odd pixel reads the
+    // value of its even neighbour and drops it (a divergent branch around a load makes hipcc drain the whole queue).
+    u32x4 er[NG];
+    unsigned ebw[FWD ? 1 : NG];  // the dword holding this row's four gate bytes of the block
+    u32x4 pq[FWD ? 4 : 1];       // forward: scale[0:4], scale[4:8], shift[0:4], shift[4:8] of this lane's 8 output channels
+    unsigned ehave = 0;          // LORES: bit t = row group t carries a residual (the same for every block)
+    auto request = [&](int t, int cb) __attribute__((always_inline)) {
+        const int rbase = (t >> 1) * 32 + (t & 1) * 16;  // first row of the group (wave-uniform)
+        const bool ok = HAND || rbase + r4 < rows_left;
+        if (MSFWSI_PANEL_ABLATE & 8) return;
+        if constexpr (!FWD) {
+            if (HAND || mb_wg != nullptr) {  // the four lanes of a row read the same dword: one request
+                const unsigned boff = (ok ? (unsigned)rbase * (unsigned)nbyte + bit_off : 0u) + (unsigned)cb * 4u;
+                pl_load4<HAND>(ebw[t], mb_wg, boff);
+            }
+        }
+        if (HAND || has_eop) {
+            if constexpr (LORES) {
+                const unsigned m = (unsigned)(m0 + (ok ? rbase + r4 : 0));
+                const unsigned n = fast_div(m, prm.div_pq);
+                const unsigned rem = m - n * (unsigned)PQ;
+                const unsigned h = fast_div(rem, prm.div_q);
+                const unsigned w = rem - h * (unsigned)prm.Q;
+                const int Pl = (prm.P + 1) >> 1, Ql = (prm.Q + 1) >> 1;
+                // (32-bit byte offset from the tensor base: the entry point refuses low-resolution tensors of 4 GiB or more)
+                const unsigned lo = (((n * (unsigned)Pl + (h >> 1)) * (unsigned)Ql + (w >> 1)) * (unsigned)prm.Nout +
+                                     (unsigned)(cb * 32 + q * 8)) * 2u;
+                pl_load16<HAND>(er[t], eop_wg, lo);
+                if (((h | w) & 1u) == 0) ehave |= 1u << t;
+            } else {
+                const unsigned off = (ok ? (unsigned)rbase * (unsigned)prm.Nout * 2u + row_off : (unsigned)q * 16u) + (unsigned)cb * 64u;
+                pl_load16<HAND>(er[t], eop_wg, off);
+            }
+        }
+    };
+    auto request_post = [&](int cb) __attribute__((always_inline)) {
+        if constexpr (FWD) {
+            const unsigned o = (unsigned)(cb * 32 + q * 8) * 4u;
+            pl_load16<HAND>(pq[0], prm.post_scale, o);
+            pl_load16<HAND>(pq[1], prm.post_scale, o + 16u);
+            pl_load16<HAND>(pq[2], prm.post_shift, o);
+            pl_load16<HAND>(pq[3], prm.post_shift, o + 16u);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        er[t] = (u32x4){0u, 0u, 0u, 0u};
+        if constexpr (!FWD) ebw[t] = 0xffffffffu;
+    }
+    const int cb0 = wave < nblk ? wave : nblk - 1;  // (a wave without a block -- fewer than 4 blocks -- loads and drops)
+#pragma unroll
+    for (int t = 0; t < NG; ++t) request(t, cb0);
+    request_post(cb0);
+    // weight fragments of this wave's first block
+    const char* wpk = reinterpret_cast<const char*>(prm.wpk);
+    u32x4 wf[KS];
+    {
+        const char* wb = wpk + (long)cb0 * KS * 1024;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) pl_load16<HAND>(wf[ks], wb, (unsigned)(ks * 1024 + lane * 16));
+    }
+    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once per workgroup; the loop's waits are counted
+
+    // per-lane constants of the fragment reads: row tm*32 + l31, chunk (2 ks + lh) ^ swz(row) = (2 ks) ^ (lh ^ swz)
+    const int xv = lh ^ panel_swz<K>(l31);
+    const char* prow = panel + l31 * ROWB;
+
+    for (int cb = wave; cb < nblk; cb += NW) {
+        const int ncol = cb * 32 + q * 8;
+        const unsigned lane_off = row_off + (unsigned)cb * 64u;
+        const int cbn = cb + NW < nblk ? cb + NW : cb;  // (the last block re-requests its own operands: no branch)
+
+        // ---- MFMAs of this block; the weight fragment just consumed is replaced by the next block's, the activation
+        //      fragment just consumed by the next k step's (one register set: a read is four MFMAs ahead of its use) ----
+        f32x16 acc[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+        const char* wn = wpk + (long)cbn * KS * 1024;
+        frag_t xc[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) xc[tm] = *reinterpret_cast<const frag_t*>(prow + tm * 32 * ROWB + ((0 ^ xv) << 4));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pl_wait<HAND, NWAIT>(wf[ks]);
+            const frag_t wfr = __builtin_bit_cast(frag_t, wf[ks]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                if (!(MSFWSI_PANEL_ABLATE & 2) || ks == 0) mma32<T>(acc[tm], wfr, xc[tm]);
+                if (ks + 1 < KS)
+                    xc[tm] = *reinterpret_cast<const frag_t*>(prow + tm * 32 * ROWB + (((2 * (ks + 1)) ^ xv) << 4));
+            }
+            if (!(MSFWSI_PANEL_ABLATE & 4)) pl_load16<HAND>(wf[ks], wn, (unsigned)(ks * 1024 + lane * 16));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA of step ks ...
+                if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then one fragment read of step ks+1
+            }
+            __builtin_amdgcn_sched_barrier(0);  // nothing moves across k steps (hipcc otherwise interchanges the loops:
+                                                // all k steps of one row tile, each read right before its MFMA)
+        }
+
+        // ---- epilogue: transpose each 32 x 32 tile through the wave's scratch, then 16-byte row chunks; each row group's
+        //      operand registers are re-requested for the NEXT block as soon as they are consumed ----
+        if constexpr (FWD) {
+            // the four post loads close the previous epilogue: only the k loop's KS weight loads are younger
+            pl_wait<HAND, KS>(pq[0]);
+            pl_wait<HAND, KS>(pq[1]);
+            pl_wait<HAND, KS>(pq[2]);
+            pl_wait<HAND, KS>(pq[3]);
+        }
+        float ssum[FWD ? 1 : 8];
+        if constexpr (!FWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ssum[e] = 0.f;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            // lane (l31, lh) holds pixel l31, channels 8g + 4 lh + e in accumulator register 4g + e
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2*>(scratch + l31 * SCR_PITCH + (8 * g + 4 * lh) * 2) =
+                    pack4<T>(acc[tm][4 * g], acc[tm][4 * g + 1], acc[tm][4 * g + 2], acc[tm][4 * g + 3]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int t = tm * 2 + i;
+                const int rbase = tm * 32 + i * 16;
+                const uint4 cv = *reinterpret_cast<const uint4*>(scratch + (i * 16 + r4) * SCR_PITCH + q * 16);
+                const bool ok = HAND || rbase + r4 < rows_left;
+                float f[8];
+                unpack16<T>(cv, f);
+                uint4 pk;
+                // this group's operands were requested NWAIT operations ago (one block's worth, as the weights)
+                // (input gradient: the gate-byte load of the group is issued BEFORE its operand load, so one operation fewer
+                //  is younger than the operand -- and the wait for the operand covers the gate bytes)
+                if constexpr (FWD) pl_wait<HAND, NWAIT>(er[t]);
+                else pl_wait<HAND, NWAIT - 1>(er[t], ebw[t]);
+                if constexpr (FWD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        f[e] = fmaf(f[e], __uint_as_float(pq[e >> 2][e & 3]), __uint_as_float(pq[2 + (e >> 2)][e & 3]));
+                    if (HAND || has_eop) {
+                        float id[8];
+                        unpack16<T>(as_uint4(er[t]), id);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += id[e];
+                    }
+                    if (prm.post_relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                    }
+                    pk = pack16<T>(f);
+                } else {
+                    const bool addr = LORES ? ((ehave >> t) & 1u) != 0 : (HAND || has_eop);
+                    if (addr) {
+                        float rs[8];
+                        unpack16<T>(as_uint4(er[t]), rs);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += rs[e];
+                    }
+                    if (!HAND && prm.gapg != nullptr) {  // (stage-end blocks only: they run on hipcc's own waits, see launch_panel)
+                        const long m = m0 + (ok ? rbase + r4 : 0);
+                        const long img = LORES ? (long)fast_div((unsigned)m, prm.div_pq) : m / PQ;
+                        float gp[8];
+                        unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) + img * prm.Nout + ncol), gp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
+                    }
+                    const unsigned b = (ebw[t] >> (8 * q)) & 0xffu;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (!((b >> e) & 1u)) f[e] = 0.f;
+                        if (ok) ssum[e] += f[e];
+                    }
+                    pk = pack16<T>(f);
+                }
+                request(t, cbn);  // this row group's operands of the wave's next block (registers just consumed)
+                if constexpr (FWD) {
+                    if (HAND || go_wg != nullptr) {
+                        const unsigned gb = gate_bits_of<T>(pk);
+                        // the four lanes of a row hold four consecutive gate bytes: every one of them stores the same dword
+                        // (HAND mode counts its stores: no lane-dependent branch around one)
+                        unsigned dw = gb << (8 * q);
+                        dw |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)dw, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+                        dw |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)dw, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+                        if ((HAND || (ok && q == 0)) && !(MSFWSI_PANEL_ABLATE & 1))
+                            *reinterpret_cast<unsigned*>(go_wg + ((unsigned)rbase * (unsigned)nbyte + bit_off + (unsigned)cb * 4u)) = dw;
+                    }
+                }
+                if (ok && !(MSFWSI_PANEL_ABLATE & 1)) *reinterpret_cast<uint4*>(out_wg + ((unsigned)rbase * (unsigned)prm.Nout * 2u + lane_off)) = pk;
+            }
+        }
+        request_post(cbn);
+        if constexpr (!FWD) {
+            if (prm.sums != nullptr) {
+                // lanes with equal q hold the same 8 channels for different rows; every channel of the panel is owned by
+                // exactly one wave, so the column sums land in LDS by plain stores
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                    for (int off = 4; off < 64; off <<= 1) ssum[e] += __shfl_xor(ssum[e], off, 64);
+                }
+                if (lane < 4) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 4)
+                        *reinterpret_cast<float4*>(colsum + ncol + e) = make_float4(ssum[e], ssum[e + 1], ssum[e + 2], ssum[e + 3]);
+                }
+            }
+        }
+    }
+    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's re-requested operands: nobody reads them
+}
+
 // PRO: 0 none, 1 relu(scale*c + shift), 2 k1*g + k2*c + k3.   EPI: 1 forward post, 0 input gradient, 3 input gradient with
 // the low-resolution (stride 2) residual.
-template <typename T, int K, int BM, int PRO, int EPI>
-__global__ __launch_bounds__(256, 2) void panel_kernel(const PanelParams prm) {
+template <typename T, int K, int BM, int PRO, int EPI, bool HAND>
+__global__ __launch_bounds__(256, HAND ? 2 : 1) void panel_kernel(const PanelParams prm) {
     constexpr int NT = 256, NW = 4;
     constexpr int CPR = K / 8;       // 16-byte chunks per operand row
     constexpr int RPP = NT / CPR;    // rows staged per pass
     constexpr int NPASS = BM / RPP;
-    constexpr int TM = BM / 32;      // 32-row MFMA tiles per wave (every wave covers all BM rows)
-    constexpr int KS = K / 16;       // MFMA k steps
     constexpr int ROWB = K * 2;
-    constexpr int SCR_PITCH = 80;    // bytes per scratch row (32 channels = 64 bytes + 16: keeps ds_read_b128 aligned)
-    constexpr int SCR_BYTES = 32 * SCR_PITCH;
-    constexpr bool FWD = EPI == 1, LORES = EPI == 3;
+    constexpr int SCR_BYTES = 32 * 80;  // per wave: 32 rows x (32 channels = 64 bytes + 16: keeps ds_read_b128 aligned)
+    constexpr bool FWD = EPI == 1;
     static_assert(K % 64 == 0 && BM % RPP == 0 && NT % CPR == 0 && BM % 32 == 0, "panel geometry");
-    typedef typename MmaFrag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* panel = smem;  // [BM][ROWB], chunk index XOR-swizzled by panel_swz(row)
@@ -98,15 +389,14 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const PanelParams prm) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lh = lane >> 5;
-    char* scratch = smem + BM * ROWB + wave * SCR_BYTES;  // [32][SCR_PITCH], private to this wave
+    char* scratch = smem + BM * ROWB + wave * SCR_BYTES;                          // private to this wave
+    float* colsum = reinterpret_cast<float*>(smem + BM * ROWB + NW * SCR_BYTES);  // [Nout] (input gradient with sums)
     const long m0 = (long)blockIdx.x * BM;
-    const int nblk = prm.Nout >> 5;
+    const int rows_left = (int)((long)prm.M - m0 < BM ? (long)prm.M - m0 : BM);  // rows of this panel inside the tensor
 
     // ---------------- stage the operand panel: every pass requested up front, transformed in registers ----------------
     // (loads are unconditional from a clamped row -- a row past the tensor's end re-reads the last valid one and its
     //  results are never stored: a divergent branch around each load made hipcc drain the queue between passes)
-    const int rows_left = (int)((long)prm.M - m0 < BM ? (long)prm.M - m0 : BM);  // rows of this panel inside the tensor
     {
         const int cc = tid % CPR, rr = tid / CPR;
         const char* src_wg = reinterpret_cast<const char*>(prm.src) + m0 * ROWB;
@@ -116,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const PanelParams prm) {
         for (int p = 0; p < NPASS; ++p) {
             const int row = rr + p * RPP;
             const unsigned off = (unsigned)(row < rows_left ? row : rows_left - 1) * ROWB + cc * 16;
-            v[p] = *reinterpret_cast<const uint4*>(src_wg + off);
+            v[p] = (MSFWSI_PANEL_ABLATE & 16) ? make_uint4(off, 1, 2, 3) : *reinterpret_cast<const uint4*>(src_wg + off);
             if constexpr (PRO == 2) vc[p] = *reinterpret_cast<const uint4*>(srcc_wg + off);
         }
         float c0[PRO ? 8 : 1], c1[PRO ? 8 : 1], c2[PRO == 2 ? 8 : 1];
@@ -152,203 +442,18 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const PanelParams prm) {
             *reinterpret_cast<uint4*>(panel + row * ROWB + ((cc ^ panel_swz<K>(row)) << 4)) = t;
         }
     }
-    // weight fragments of this wave's first block (after the staging loads have left their registers: with both live
-    // the 256-channel input-gradient instances spilled)
-    const T* __restrict__ wpk = reinterpret_cast<const T*>(prm.wpk);
-    frag_t wf[KS];
-    {
-        const int cb0 = wave < nblk ? wave : nblk - 1;
-        const T* wb = wpk + ((long)cb0 * KS * 64 + lane) * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const frag_t*>(wb + ks * 512);
-    }
-    __syncthreads();  // the only workgroup barrier: from here on every wave runs alone
+    __syncthreads();  // the only workgroup barrier before the sums: from here on every wave runs alone
 
-    // per-lane constants of the fragment reads: row tm*32 + l31, chunk (2 ks + lh) ^ swz(row) = (2 ks) ^ (lh ^ swz)
-    const int xv = lh ^ panel_swz<K>(l31);
-    const char* prow = panel + l31 * ROWB;
-    // per-lane constants of the transposed epilogue: chunk q = lane & 3 of rows (lane >> 2) and 16 + (lane >> 2).
-    // Every global access of the loop is "wave-uniform 64-bit base + 32-bit lane offset" (saddr form: one VGPR of address
-    // for all row tiles instead of a 64-bit pair each -- with per-lane 64-bit addresses the 256-channel instances spilled)
-    const int q = lane & 3, r4 = lane >> 2;
-    const int nbyte = prm.Nout >> 3;  // gate bytes per row
-    const int PQ = prm.P * prm.Q;
-    const char* eop_wg = reinterpret_cast<const char*>(FWD ? prm.ident : prm.resid);
-    const bool has_eop = eop_wg != nullptr;
-    if (!LORES && has_eop) eop_wg += m0 * prm.Nout * 2;
-    char* out_wg = reinterpret_cast<char*>(prm.out) + m0 * prm.Nout * 2;
-    const unsigned char* mb_wg = (!FWD && prm.mask_bits != nullptr) ? prm.mask_bits + m0 * nbyte : nullptr;
-    unsigned char* go_wg = (FWD && prm.gate_out != nullptr) ? prm.gate_out + m0 * nbyte : nullptr;
-    const unsigned row_off = (unsigned)r4 * (unsigned)prm.Nout * 2u + (unsigned)q * 16u;  // byte offset of (row r4, chunk q)
-    const unsigned bit_off = (unsigned)r4 * (unsigned)nbyte;
+    // HAND (chosen by the launcher): every panel whole and every optional operand of the epilogue class present
+    panel_blocks<T, K, BM, EPI, HAND>(prm, panel, scratch, colsum, m0, rows_left, wave, lane);
 
-    for (int cb = wave; cb < nblk; cb += NW) {
-        const int ncol = cb * 32 + q * 8;
-        const unsigned lane_off = row_off + (unsigned)cb * 64u;
-        // ---- epilogue operands of this block: in flight during its MFMAs ----
-        uint4 er[TM * 2];
-        unsigned ebits[2] = {0xffffffffu, 0xffffffffu};  // gate bytes of the TM*2 row groups, packed four to a register
-        unsigned ehave = 0;                              // LORES: bit t = row group t has a residual
-#pragma unroll
-        for (int t = 0; t < TM * 2; ++t) {
-            const int rbase = (t >> 1) * 32 + (t & 1) * 16;  // first row of the group (wave-uniform)
-            const bool ok = rbase + r4 < rows_left;          // (a lane past the end re-reads row 0 of the panel)
-            er[t] = make_uint4(0, 0, 0, 0);
-            if (has_eop) {
-                if constexpr (LORES) {
-                    const unsigned m = (unsigned)(m0 + (ok ? rbase + r4 : 0));
-                    const unsigned n = fast_div(m, prm.div_pq);
-                    const unsigned rem = m - n * (unsigned)PQ;
-                    const unsigned h = fast_div(rem, prm.div_q);
-                    const unsigned w = rem - h * (unsigned)prm.Q;
-                    const int Pl = (prm.P + 1) >> 1, Ql = (prm.Q + 1) >> 1;
-                    // (odd pixels carry no residual: they read the value of the even pixel above / left and drop it)
-                    // (32-bit byte offset from the tensor base: the entry point refuses low-resolution tensors of 4 GiB or more)
-                    const unsigned lo = (((n * (unsigned)Pl + (h >> 1)) * (unsigned)Ql + (w >> 1)) * (unsigned)prm.Nout + (unsigned)ncol) * 2u;
-                    er[t] = *reinterpret_cast<const uint4*>(eop_wg + lo);
-                    if (((h | w) & 1u) == 0) ehave |= 1u << t;
-                } else {
-                    const unsigned off = ok ? (unsigned)rbase * (unsigned)prm.Nout * 2u + lane_off : (unsigned)cb * 64u + (unsigned)q * 16u;
-                    er[t] = *reinterpret_cast<const uint4*>(eop_wg + off);
-                }
-            }
-            if constexpr (!FWD) {
-                if (mb_wg != nullptr) {  // the four lanes of a row read the same dword: one request
-                    const unsigned boff = (ok ? (unsigned)rbase * (unsigned)nbyte + bit_off : 0u) + (unsigned)cb * 4u;
-                    const unsigned dw = *reinterpret_cast<const unsigned*>(mb_wg + boff);
-                    const unsigned b = (dw >> (8 * q)) & 0xffu;
-                    ebits[t >> 2] = (ebits[t >> 2] & ~(0xffu << (8 * (t & 3)))) | (b << (8 * (t & 3)));
-                }
-            }
-        }
-        float psc[FWD ? 8 : 1], psh[FWD ? 8 : 1];
-        if constexpr (FWD) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                psc[e] = prm.post_scale[ncol + e];
-                psh[e] = prm.post_shift[ncol + e];
-            }
-        }
-
-        // ---- MFMAs of this block; the fragment just consumed is replaced by the next block's ----
-        f32x16 acc[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
-        const int cbn = cb + NW < nblk ? cb + NW : cb;  // (the last block re-requests its own fragments: no branch)
-        const T* wn = wpk + (long)cbn * KS * 512;
-        // activation fragments of step ks+1 are read while the MFMAs of step ks run (hipcc left to itself put each
-        // ds_read_b128 right in front of the MFMA that consumes it, with a full lgkmcnt(0) wait between them)
-        frag_t xc[TM], xn[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) xc[tm] = *reinterpret_cast<const frag_t*>(prow + tm * 32 * ROWB + ((0 ^ xv) << 4));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-                    xn[tm] = *reinterpret_cast<const frag_t*>(prow + tm * 32 * ROWB + (((2 * (ks + 1)) ^ xv) << 4));
-            }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) mma32<T>(acc[tm], wf[ks], xc[tm]);
-            wf[ks] = *reinterpret_cast<const frag_t*>(wn + ks * 512 + lane * 8);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA of step ks ...
-                if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then one fragment read of step ks+1
-            }
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // the next block's weight fragment for this step
-            __builtin_amdgcn_sched_barrier(0);  // nothing moves across k steps (hipcc otherwise interchanges the loops:
-                                                // all k steps of one row tile, each read right before its MFMA)
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) xc[tm] = xn[tm];
-            }
-        }
-
-        // ---- epilogue: transpose each 32 x 32 tile through the wave's scratch, then 16-byte row chunks ----
-        float ssum[FWD ? 1 : 8];
-        if constexpr (!FWD) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ssum[e] = 0.f;
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            // lane (l31, lh) holds pixel l31, channels 8g + 4 lh + e in accumulator register 4g + e
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<uint2*>(scratch + l31 * SCR_PITCH + (8 * g + 4 * lh) * 2) =
-                    pack4<T>(acc[tm][4 * g], acc[tm][4 * g + 1], acc[tm][4 * g + 2], acc[tm][4 * g + 3]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int t = tm * 2 + i;
-                const int rbase = tm * 32 + i * 16;
-                const uint4 cv = *reinterpret_cast<const uint4*>(scratch + (i * 16 + r4) * SCR_PITCH + q * 16);
-                const bool ok = rbase + r4 < rows_left;
-                float f[8];
-                unpack16<T>(cv, f);
-                if constexpr (FWD) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], psc[e], psh[e]);
-                    if (has_eop) {
-                        float id[8];
-                        unpack16<T>(er[t], id);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] += id[e];
-                    }
-                    if (prm.post_relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
-                    }
-                    if (go_wg != nullptr) {
-                        const unsigned gb = gate_bits_of<T>(pack16<T>(f));  // (the pack is shared with the store below)
-                        // the four lanes of a row hold four consecutive gate bytes: one dword store by the first of them
-                        unsigned dw = gb << (8 * q);
-                        dw |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)dw, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
-                        dw |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)dw, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
-                        if (ok && q == 0) *reinterpret_cast<unsigned*>(go_wg + ((unsigned)rbase * (unsigned)nbyte + bit_off + (unsigned)cb * 4u)) = dw;
-                    }
-                } else {
-                    const bool addr = LORES ? ((ehave >> t) & 1u) != 0 : has_eop;
-                    if (addr) {
-                        float rs[8];
-                        unpack16<T>(er[t], rs);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] += rs[e];
-                    }
-                    if (prm.gapg != nullptr) {
-                        const long m = m0 + (ok ? rbase + r4 : 0);
-                        const long img = LORES ? (long)fast_div((unsigned)m, prm.div_pq) : m / PQ;
-                        float gp[8];
-                        unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) + img * prm.Nout + ncol), gp);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
-                    }
-                    const unsigned b = (ebits[t >> 2] >> (8 * (t & 3))) & 0xffu;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if (!((b >> e) & 1u)) f[e] = 0.f;
-                        if (ok) ssum[e] += f[e];
-                    }
-                }
-                if (ok) *reinterpret_cast<uint4*>(out_wg + ((unsigned)rbase * (unsigned)prm.Nout * 2u + lane_off)) = pack16<T>(f);
-            }
-        }
-        if constexpr (!FWD) {
-            if (prm.sums != nullptr) {
-                // lanes with equal q hold the same 8 channels for different rows
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-#pragma unroll
-                    for (int off = 4; off < 64; off <<= 1) ssum[e] += __shfl_xor(ssum[e], off, 64);
-                }
-                if (lane < 4) {
-                    double* dst = prm.sums + (long)(blockIdx.x % prm.nshard) * 2 * prm.Nout + ncol;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) atomicAdd(dst + e, (double)ssum[e]);
-                }
-            }
+    if constexpr (!FWD) {
+        if (prm.sums != nullptr) {
+            // one coalesced pass of fp64 atomics per workgroup (512 contiguous bytes per wave instruction; issued per
+            // block by four lanes, the same adds cost the workgroup more than its HBM traffic)
+            __syncthreads();
+            double* dst = prm.sums + (long)(blockIdx.x % prm.nshard) * 2 * prm.Nout;
+            for (int n = tid; n < prm.Nout; n += NT) atomicAdd(dst + n, (double)colsum[n]);
         }
     }
 }
@@ -370,10 +475,17 @@ __global__ void panel_pack_kernel(const T* __restrict__ w, T* __restrict__ wpk, 
     wpk[i] = w[n * stride_n + k * stride_k];
 }
 
+long g_panel_hand = 1;  // msfwsi_set_tuning(17, .): 0 = every launch on hipcc's own waits (the A/B reference of the hand-counted ones)
+
 template <typename T, int K, int BM, int PRO, int EPI>
 int launch_panel(const PanelParams& prm, hipStream_t stream) {
-    constexpr int LDS = BM * K * 2 + 4 * 32 * 80;
-    void (*kern)(const PanelParams) = panel_kernel<T, K, BM, PRO, EPI>;
+    const int LDS = BM * K * 2 + 4 * 32 * 80 + (EPI != 1 && prm.sums != nullptr ? prm.Nout * 4 : 0);
+    // hand-counted loads (panel_blocks) need a fixed number of vector-memory operations per block: whole panels only, and
+    // every optional operand of the epilogue class present (the engine's launches all are: M = N*H*W with N a multiple of
+    // 128 tiles, identity + gate bytes / residual + gate bytes + sums)
+    const bool hand = g_panel_hand && prm.M % BM == 0 && (EPI == 1 ? (prm.ident != nullptr && prm.gate_out != nullptr)
+                                                   : (prm.resid != nullptr && prm.mask_bits != nullptr && prm.gapg == nullptr));
+    void (*kern)(const PanelParams) = hand ? panel_kernel<T, K, BM, PRO, EPI, true> : panel_kernel<T, K, BM, PRO, EPI, false>;
     if (LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
@@ -405,6 +517,8 @@ bool is_1x1(const msfwsi_conv_desc* d) {
 }
 
 }  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) void msfwsi_panel_set_hand(long v) { g_panel_hand = v; }
 
 extern "C" int msfwsi_panel_supported(const msfwsi_conv_desc* d, int dgrad) {
     if (!is_1x1(d)) return 0;

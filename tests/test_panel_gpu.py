@@ -148,9 +148,13 @@ def test_panel_dgrad(hip_lib, dt, geom, bnbwd, epi):
         ref = ref * unpack_bits(bits, M, Cin).double()
     assert rel(dx, ref) < tol(dt)
     if sums is not None:
+        # column sums of the gated gradient (taken in fp32 before the store's rounding): within the rounding noise of M
+        # storage-type values of the fp64 sums
         got = sums.sum(dim=0)[0].cpu()
-        want = dx.double().sum(dim=0).cpu()  # sums of the STORED gradient
-        assert (got - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+        want = ref.sum(dim=0)
+        eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        bound = 4.0 * eps * math.sqrt(M) * ref.pow(2).mean().sqrt().item() + 1e-6
+        assert (got - want).abs().max().item() <= bound
         assert sums[:, 1].abs().max().item() == 0.0  # slot 1 is left alone
 
 
@@ -182,7 +186,10 @@ def test_panel_dgrad_lowres_residual(hip_lib, dt, geom):
     ref = ref * unpack_bits(bits, M, Cin).double()
     assert rel(a, ref) < tol(dt)
     assert rel(a, b.float()) < tol(dt)
-    assert (sa.sum(0)[0] - sb.sum(0)[0]).abs().max().item() <= 2e-3 * max(1.0, sb.sum(0)[0].abs().max().item())
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    bound = 4.0 * eps * math.sqrt(M) * ref.pow(2).mean().sqrt().item() + 1e-6
+    assert (sa.sum(0)[0].cpu() - ref.sum(0)).abs().max().item() <= bound
+    assert (sb.sum(0)[0].cpu() - ref.sum(0)).abs().max().item() <= bound
 
 
 def test_panel_unsupported_shapes(hip_lib):
@@ -196,3 +203,56 @@ def test_panel_unsupported_shapes(hip_lib):
     assert not kn.panel_supported(kn.conv_desc(torch.bfloat16, 2, 7, 7, 256, 64, 1, 1, 1, 0), False)
     assert not kn.panel_supported(kn.conv_desc(torch.bfloat16, 2, 7, 7, 256, 256, 3, 3, 1, 1), False)
     assert not kn.panel_supported(kn.conv_desc(torch.bfloat16, 2, 8, 8, 256, 512, 1, 1, 2, 0), False)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(64, 14, 14, 256, 1024), (32, 28, 28, 128, 512), (128, 7, 7, 512, 2048), (16, 56, 56, 64, 256)])
+def test_hand_counted_waits_equal_compiler_waits(hip_lib, dt, geom):
+    """whole panels at production channel counts (hundreds of workgroups, every wave with several blocks): the
+    hand-counted `s_waitcnt vmcnt(N)` instances (msfwsi_set_tuning(17, 1), the default) give the SAME BITS as the instances
+    whose loads hipcc counts itself -- a register read before its load has landed would differ (the dynamic counterpart of
+    tools/check_hand_waits.py's static audit), forward with the fused BatchNorm+ReLU prologue and input gradient with the
+    fused BatchNorm backward, three times each"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cn, Kw = geom
+    M = N * H * W
+    assert M % 128 == 0
+    g = torch.Generator().manual_seed(14)
+    a = rnd((M, Cn), dt, g).cuda()
+    c1 = rnd((M, Cn), dt, g).cuda()
+    w = rnd((Kw, Cn), dt, g, 1.0 / math.sqrt(Cn)).cuda()
+    w1 = rnd((Cn, Kw), dt, g, 1.0 / math.sqrt(Cn)).cuda()
+    ident = rnd((M, Kw), dt, g).cuda()
+    ps, pb = (torch.rand(Kw, generator=g) + 0.5).cuda(), (torch.randn(Kw, generator=g) * 0.2).cuda()
+    sc, sh = (torch.rand(Cn, generator=g) + 0.5).cuda(), (torch.randn(Cn, generator=g) * 0.3).cuda()
+    k3 = (torch.randn(Cn, generator=g) * 0.05).cuda()
+    bits_in = torch.randint(0, 256, (M, Kw // 8), dtype=torch.uint8, generator=g).cuda()
+    d = kn.conv_desc(dt, N, H, W, Cn, Kw, 1, 1, 1, 0)
+    d1 = kn.conv_desc(dt, N, H, W, Kw, Cn, 1, 1, 1, 0)
+    wpk = kn.panel_pack_weights(w, torch.empty_like(w), Kw, Cn, Cn, 1)
+    wpk1 = kn.panel_pack_weights(w1, torch.empty_like(w1), Kw, Cn, 1, Kw)
+
+    def run():
+        y = torch.empty(M, Kw, dtype=dt, device="cuda")
+        bits = kn.gate_bytes(M, Kw, dt, "cuda")
+        assert kn.panel_fwd_post(d, a, wpk, y, ps, pb, pro=(sc, sh), ident=ident, relu=True, gate_out=bits)
+        dx = torch.empty(M, Kw, dtype=dt, device="cuda")
+        dc = torch.empty(M, Cn, dtype=dt, device="cuda")
+        sums = kn.new_stats(Kw, 2, "cuda")
+        assert kn.panel_dgrad(d1, a, wpk1, dx, bnbwd=(c1, sc, sh, k3), dc_out=dc, resid=ident, mask_bits=bits_in, sums=sums)
+        torch.cuda.synchronize()
+        return y, bits, dx, dc, sums.sum(0)[0]
+
+    try:
+        assert hip_lib.msfwsi_set_tuning(17, 0) == 0
+        ref = run()
+        assert hip_lib.msfwsi_set_tuning(17, 1) == 0
+        for _ in range(3):
+            got = run()
+            for name, r, t in zip(("y", "gate bits", "dx", "dc"), ref[:4], got[:4]):
+                assert torch.equal(r, t), f"{name}: hand-counted instance differs from the compiler-counted one"
+            # (the column sums are added by fp64 atomics in an order that varies: equal to fp64 rounding)
+            assert (ref[4] - got[4]).abs().max().item() <= 1e-9 * max(1.0, ref[4].abs().max().item())
+    finally:
+        hip_lib.msfwsi_set_tuning(17, 1)

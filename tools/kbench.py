@@ -119,7 +119,10 @@ def case_wide():
 def case_panel():
     """the activation-stationary kernels (csrc/panel.hip) at the shapes of case `wide` / `epi3`: forward tail with and
     without the fused BatchNorm+ReLU prologue, conv1 input gradient with and without the fused BatchNorm backward"""
+    only = [int(v) for v in os.environ.get("KBENCH_PANEL_H", "").split(",") if v]  # e.g. KBENCH_PANEL_H=14: that shape alone
     for H, Cn, Kw in ((14, 256, 1024), (28, 128, 512), (7, 512, 2048), (56, 64, 256)):
+        if only and H not in only:
+            continue
         N = NIMG
         M = N * H * H
         d = kn.conv_desc(DT, N, H, H, Cn, Kw, 1, 1, 1, 0)
@@ -158,6 +161,8 @@ def case_panel():
         del a, y, ident, bits, c1, dc, t
     # the strided-residual class
     for H, C, K in ((56, 256, 128), (28, 512, 256), (14, 1024, 512)):
+        if only:
+            continue
         N = NIMG
         d = kn.conv_desc(DT, N, H, H, C, K, 1, 1, 1, 0)
         M = N * H * H
