@@ -50,8 +50,11 @@ int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, voi
 /* y = [relu]( round(conv(x, w)) * post_scale[k] + post_shift[k] + ident ): a conv whose consumer BatchNorm
  * statistics are already known (from msfwsi_fold_matvec / msfwsi_fold_dots), so BatchNorm apply, the residual add and
  * the ReLU of src/models/resnet.py:131-138 (bn3 -> += identity -> relu) run in the conv epilogue and the raw conv
- * output never reaches HBM.  ident may be NULL.  gate_out (nullable): [N*P*Q][K/vec] bytes, bit e of a byte = (y > 0)
- * for element e of that 16-byte chunk (vec = 4 fp32 / 8 16-bit) -- the ReLU gate msfwsi_conv_dgrad reads back. */
+ * output never reaches HBM.  ident may be NULL.  gate_out (nullable): one byte per 16-byte chunk of y (vec = 4 fp32 / 8
+ * 16-bit elements, cpr = K/vec chunks per pixel), bit e = (stored y > 0) for element e of the chunk -- the ReLU gate
+ * msfwsi_conv_dgrad reads back.  Layout: the byte of (pixel m, chunk c) is at m*cpr + c when cpr % 4 != 0, otherwise at
+ * ((m/128)*(cpr/4) + c/4)*512 + (m%128)*4 + c%4 -- the four gate bytes of a 32-channel block form a dword and the dwords
+ * of 128 consecutive pixels are contiguous; the tensor then holds ceil(M/128)*128*cpr bytes. */
 int msfwsi_conv_fwd_post(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, const float* post_scale,
                          const float* post_shift, const void* ident, int relu, unsigned char* gate_out, void* stream);
 
@@ -71,7 +74,7 @@ int msfwsi_conv_fwd_post2(const msfwsi_conv_desc* d, const void* x, const void* 
  * a = relu(mask_scale*c + mask_shift): dx is gated by (mask_scale*c + mask_shift > 0) and
  * sums[shard][2][C] += {sum dx, sum dx*c} (what msfwsi_act_bwd_reduce would compute in a second pass).
  * mask_bits != NULL (instead of mask_c): the gate comes from the bytes msfwsi_conv_fwd_post wrote
- * ([N*H*W][C/vec]); sums slot 0 += sum dx, slot 1 is left alone.
+ * (same layout, over [N*H*W] pixels of C/vec chunks); sums slot 0 += sum dx, slot 1 is left alone.
  * resid_stride s = 2 (others: MSFWSI_EUNSUPPORTED): resid is the LOW-resolution tensor [N][(H-1)/s+1][(W-1)/s+1][C] and is added only at pixels
  * with h % s == w % s == 0 -- the input gradient of a stride-s downsample branch without its zero-stuffed copy.
  * Replaces: autograd's convolution_backward(input) / linear backward(input) (+ threshold_backward and the

@@ -138,6 +138,18 @@ __device__ __forceinline__ uint4 pack16<_Float16>(const float* f) {
     return __builtin_bit_cast(uint4, h);
 }
 
+// Gate-byte tensor of a [M][cpr chunks] activation (one byte per 16-byte chunk, msfwsi_conv_fwd_post's gate_out): byte offset
+// of (pixel m, chunk c).  BLOCKED when a row holds whole dwords of gate bytes (cpr % 4 == 0: every ResNet width):
+// [m / 128][c / 4][m % 128][c % 4] -- the four gate bytes of one pixel's 32-channel block form a dword, and the dwords of 128
+// consecutive pixels are contiguous (512 bytes).  A wave of the panel kernels owns a 32-channel block of 128 pixels: its
+// gate traffic is then 64 contiguous bytes per 16 pixels instead of 16 partial-line requests of 4 bytes each (which cost
+// a 14x14 forward launch 0.29 of 1.24 ms: the L2 handles requests, not bytes).  Otherwise linear [m][c].
+// The tensor holds msfwsi_gate_numel(M, cpr) bytes (rows padded to 128 in the blocked form).
+__host__ __device__ __forceinline__ long gate_off(long m, int c, int cpr) {
+    if (cpr & 3) return m * cpr + c;
+    return ((m >> 7) * (long)(cpr >> 2) + (c >> 2)) * 512 + (m & 127) * 4 + (c & 3);
+}
+
 // ReLU gate of one STORED 16-byte chunk: bit e = (element e > 0), taken from the packed value so that the bits equal
 // the sign test of the tensor in memory bit for bit (an fp32 value that rounds to zero in the storage type is closed)
 template <typename T>

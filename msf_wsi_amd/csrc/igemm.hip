@@ -70,7 +70,7 @@ struct IgemmParams {
     int s_run;               //   is a run of s_run pixels x pix_stride channels, padded to C = a multiple of the slab)
     const void* src2;        // DGRAD 1x1 only, nullable: second source [M][C2] whose k-range follows the first
     int C2;                  //   (out = src . W[0:C] + src2 . W[C:C+C2]; Ktot = C + C2)
-    unsigned char* gate_out;        // [M][Nout/VEC], nullable: bit e of a byte = (out[m][VEC*chunk+e] > 0)
+    unsigned char* gate_out;        // gate bytes of [M][Nout/VEC] chunks (layout: gate_off, common.h), nullable: bit e = (out[m][VEC*chunk+e] > 0)
     const unsigned char* mask_bits; // same layout, nullable: gates this gradient instead of mask_c (stats = {sum g, 0})
     int N, H, W, C;          // source tensor
     int P, Q, Nout;          // output tensor
@@ -272,7 +272,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 }
             }
             if (mask_c != nullptr) r_msk[pi] = *reinterpret_cast<const uint4*>(mask_c + off);
-            else if (mask_bits != nullptr) r_bits[pi] = mask_bits[pixm * (prm.Nout / VEC) + (ncol / VEC)];
+            else if (mask_bits != nullptr) r_bits[pi] = mask_bits[gate_off(pixm, ncol / VEC, prm.Nout / VEC)];
         }
     }
     if (grp == 0) __syncthreads();  // the transposed tile is complete in LDS
@@ -314,7 +314,7 @@ __device__ __forceinline__ void igemm_epilogue(Acc& acc /* f32x16 [TN][TM] */, c
                 if (gate_out != nullptr) {
                     // one byte per 16-byte chunk: the ReLU gate of this output for the backward pass (read there
                     // instead of the 16 bytes of the activation itself)
-                    gate_out[pixm * (prm.Nout / VEC) + (ncol / VEC)] = (unsigned char)gate_bits_of<T>(v);
+                    gate_out[gate_off(pixm, ncol / VEC, prm.Nout / VEC)] = (unsigned char)gate_bits_of<T>(v);
                 }
             }
             if (mask_c != nullptr) {

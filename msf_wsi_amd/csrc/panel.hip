@@ -30,9 +30,24 @@
 
 #ifndef MSFWSI_PANEL_ABLATE
 #define MSFWSI_PANEL_ABLATE 0  // diagnostic builds (tools/build_variant.sh), WRONG RESULTS: bit 0 = no output / gate stores, bit 1 = no
-#endif                         // MFMAs, bit 2 = no weight-fragment reloads, bit 3 = no epilogue-operand loads, bit 4 = no staging loads
+#endif                         // MFMAs, bit 2 = no weight-fragment reloads, bit 3 = no epilogue-operand loads, bit 4 = no staging loads,
+                               // bit 5 = no epilogue arithmetic, bit 6 = no gate bits, bit 7 = epilogue loads / stores as 8 rows x 128 B per
+                               // instruction (same bytes, half the L2 requests; wrong addresses)
+
+#ifndef MSFWSI_PANEL_NT
+#define MSFWSI_PANEL_NT 0  // 1: output / gate stores non-temporal (A/B: tools/build_variant.sh nt "-DMSFWSI_PANEL_NT=1")
+#endif
 
 namespace {
+
+template <typename V>
+__device__ __forceinline__ void pl_store(V* p, const V& v) {
+#if MSFWSI_PANEL_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 struct PanelParams {
     const void* src;    // [M][K]: PRO 0 the operand itself, PRO 1 the producer's raw conv output, PRO 2 the gated gradient g
@@ -48,12 +63,12 @@ struct PanelParams {
     const float* post_shift;
     const void* ident;  // [M][Nout], nullable
     int post_relu;
-    unsigned char* gate_out;  // [M][Nout/8], nullable
+    unsigned char* gate_out;  // gate bytes of the [M][Nout/8] chunks (layout: gate_off, common.h), nullable
     // EPI 0 / 3 (input gradient): out = gate( round(acc) + resid + gap_scale * gapg[image] ), sums[shard][0][n] += out
     const void* resid;  // [M][Nout] (EPI 3: [N][P/2][Q/2][Nout], added where h % 2 == w % 2 == 0), nullable
     const void* gapg;   // [N][Nout], nullable
     float gap_scale;
-    const unsigned char* mask_bits;  // [M][Nout/8], nullable
+    const unsigned char* mask_bits;  // same layout, nullable
     double* sums;                    // [nshard][2][Nout], nullable (slot 0)
     int nshard;
     int M, Nout, P, Q;
@@ -138,16 +153,21 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
     // Every global access of the loop is "wave-uniform 64-bit base + 32-bit lane offset" (saddr form: one VGPR of address
     // for all row tiles instead of a 64-bit pair each -- with per-lane 64-bit addresses the 256-channel instances spilled)
     const int q = lane & 3, r4 = lane >> 2;
-    const int nbyte = prm.Nout >> 3;  // gate bytes per row
     const int PQ = prm.P * prm.Q;
     const char* eop_wg = reinterpret_cast<const char*>(FWD ? prm.ident : prm.resid);
     const bool has_eop = eop_wg != nullptr;
     if (!LORES && has_eop) eop_wg += m0 * prm.Nout * 2;
     char* out_wg = reinterpret_cast<char*>(prm.out) + m0 * prm.Nout * 2;
-    const unsigned char* mb_wg = (!FWD && prm.mask_bits != nullptr) ? prm.mask_bits + m0 * nbyte : nullptr;
-    unsigned char* go_wg = (FWD && prm.gate_out != nullptr) ? prm.gate_out + m0 * nbyte : nullptr;
+    // gate bytes (blocked layout, gate_off in common.h): the dwords of this panel's rows for block cb are contiguous
+    const long gbase = ((m0 >> 7) * (long)nblk) * 512 + (m0 & 127) * 4;
+    const unsigned char* mb_wg = (!FWD && prm.mask_bits != nullptr) ? prm.mask_bits + gbase : nullptr;
+    unsigned char* go_wg = (FWD && prm.gate_out != nullptr) ? prm.gate_out + gbase : nullptr;
+#if MSFWSI_PANEL_ABLATE & 128
+    const unsigned row_off = (unsigned)(lane >> 3) * (unsigned)prm.Nout * 2u + (unsigned)(lane & 7) * 16u;
+#else
     const unsigned row_off = (unsigned)r4 * (unsigned)prm.Nout * 2u + (unsigned)q * 16u;  // byte offset of (row r4, chunk q)
-    const unsigned bit_off = (unsigned)r4 * (unsigned)nbyte;
+#endif
+    const unsigned bit_off = (unsigned)r4 * 4u;  // this lane's row inside a 16-row group of gate dwords
     // HAND mode is entered only with an operand tensor / gate bytes present wherever the epilogue class has them: its
     // operation counts are compile-time constants
     constexpr int NL = NG * (FWD ? 1 : 2) + (FWD ? 4 : 0);  // loads per epilogue
@@ -168,7 +188,7 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
         if (MSFWSI_PANEL_ABLATE & 8) return;
         if constexpr (!FWD) {
             if (HAND || mb_wg != nullptr) {  // the four lanes of a row read the same dword: one request
-                const unsigned boff = (ok ? (unsigned)rbase * (unsigned)nbyte + bit_off : 0u) + (unsigned)cb * 4u;
+                const unsigned boff = (ok ? (unsigned)rbase * 4u + bit_off : 0u) + (unsigned)cb * 512u;
                 pl_load4<HAND>(ebw[t], mb_wg, boff);
             }
         }
@@ -186,7 +206,8 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
                 pl_load16<HAND>(er[t], eop_wg, lo);
                 if (((h | w) & 1u) == 0) ehave |= 1u << t;
             } else {
-                const unsigned off = (ok ? (unsigned)rbase * (unsigned)prm.Nout * 2u + row_off : (unsigned)q * 16u) + (unsigned)cb * 64u;
+                const unsigned off = (ok ? (unsigned)(MSFWSI_PANEL_ABLATE & 128 ? rbase / 2 + (cb & 1) * 64 : rbase) * (unsigned)prm.Nout * 2u + row_off : (unsigned)q * 16u) +
+                                     (unsigned)(MSFWSI_PANEL_ABLATE & 128 ? (cb & ~1) : cb) * 64u;
                 pl_load16<HAND>(er[t], eop_wg, off);
             }
         }
@@ -294,7 +315,9 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
                 //  is younger than the operand -- and the wait for the operand covers the gate bytes)
                 if constexpr (FWD) pl_wait<HAND, NWAIT>(er[t]);
                 else pl_wait<HAND, NWAIT - 1>(er[t], ebw[t]);
-                if constexpr (FWD) {
+                if constexpr (MSFWSI_PANEL_ABLATE & 32) {
+                    pk = cv;
+                } else if constexpr (FWD) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         f[e] = fmaf(f[e], __uint_as_float(pq[e >> 2][e & 3]), __uint_as_float(pq[2 + (e >> 2)][e & 3]));
@@ -335,7 +358,7 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
                 }
                 request(t, cbn);  // this row group's operands of the wave's next block (registers just consumed)
                 if constexpr (FWD) {
-                    if (HAND || go_wg != nullptr) {
+                    if ((HAND || go_wg != nullptr) && !(MSFWSI_PANEL_ABLATE & 64)) {
                         const unsigned gb = gate_bits_of<T>(pk);
                         // the four lanes of a row hold four consecutive gate bytes: every one of them stores the same dword
                         // (HAND mode counts its stores: no lane-dependent branch around one)
@@ -343,10 +366,13 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
                         dw |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)dw, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
                         dw |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)dw, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
                         if ((HAND || (ok && q == 0)) && !(MSFWSI_PANEL_ABLATE & 1))
-                            *reinterpret_cast<unsigned*>(go_wg + ((unsigned)rbase * (unsigned)nbyte + bit_off + (unsigned)cb * 4u)) = dw;
+                            pl_store(reinterpret_cast<unsigned*>(go_wg + ((unsigned)rbase * 4u + bit_off + (unsigned)cb * 512u)), dw);
                     }
                 }
-                if (ok && !(MSFWSI_PANEL_ABLATE & 1)) *reinterpret_cast<uint4*>(out_wg + ((unsigned)rbase * (unsigned)prm.Nout * 2u + lane_off)) = pk;
+                if (ok && !(MSFWSI_PANEL_ABLATE & 1))
+                    pl_store(reinterpret_cast<u32x4*>(out_wg + ((unsigned)(MSFWSI_PANEL_ABLATE & 128 ? rbase / 2 + (cb & 1) * 64 : rbase) * (unsigned)prm.Nout * 2u +
+                                                        (MSFWSI_PANEL_ABLATE & 128 ? row_off + (unsigned)(cb & ~1) * 64u : lane_off))),
+                             (u32x4){pk.x, pk.y, pk.z, pk.w});
             }
         }
         request_post(cbn);

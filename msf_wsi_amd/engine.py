@@ -317,6 +317,12 @@ class Engine:
         # ... which also emits the block's closing ReLU gate as one byte per 16-byte chunk for the backward pass
         self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
         self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
+        # activation-stationary ("panel") kernels for the short-k 1x1 convs of a Bottleneck (csrc/panel.hip): conv3's fused
+        # tail reads conv2's RAW output (bn2 + ReLU applied while the panel is staged), conv1's input gradient forms bn1's
+        # backward dc1 = k1*g + k2*c1 + k3 in its staging and writes it back once for the weight gradient
+        self.panel_fwd = os.environ.get("MSFWSI_PANEL_FWD", "1") != "0"
+        self.panel_dgrad = os.environ.get("MSFWSI_PANEL_DGRAD", "1") != "0"
+        self.panel_fwd_min_k = int(os.environ.get("MSFWSI_PANEL_FWD_MIN_K", "128"))  # 56x56 / 64 channels: the gather kernel is at the HBM roof
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
         self.stem_s2d = os.environ.get("MSFWSI_STEM_S2D", "1") != "0"  # ... in space-to-depth form (4x4 / stride 1)
         self.stem_fuse_bnbwd = os.environ.get("MSFWSI_STEM_FUSE_BNBWD", "1") != "0"  # bn1 backward inside the stem's dW
@@ -453,6 +459,9 @@ class Engine:
                         self._unit_gate(m.weight.shape[0], dev)
                         if dtype != torch.float32 and isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1):
                             self._f32_of(w)  # the fold algebra's fp32 copy (_gram_stats), shared by both streams
+                            if m.stride == (1, 1) and m.bias is None:
+                                self._panel_weights(m, w, dtype, dgrad=False)
+                                self._panel_weights(m, w, dtype, dgrad=True)
 
     def _msg_buf(self, kind: str, n: int, dev) -> torch.Tensor:
         """pre-allocated fp64 message buffer of the cross-replica BatchNorm exchange, one per (direction, length).
@@ -794,6 +803,19 @@ class Engine:
         kn.fold_dots(Wq, WA, stats[0, 1])
         return self._bn_finalize(stats, count, bn)
 
+    def _panel_weights(self, op: nn.Module, w: torch.Tensor, dtype, dgrad: bool) -> Optional[torch.Tensor]:
+        """the 1x1 conv weight [K][1][1][C] in MFMA fragment order for the panel kernels (msfwsi_panel_pack_weights), shared
+        by the passes of a step (dropped by invalidate_weights); None where the panel kernels do not serve the layer"""
+        if dtype == torch.float32 or not isinstance(op, nn.Conv2d):
+            return None
+        K, Cn = op.out_channels, op.in_channels
+        nout, kk = (Cn, K) if dgrad else (K, Cn)
+        if kk not in (64, 128, 256, 512) or nout < 128 or nout % 32:
+            return None
+        if dgrad:  # the forward tensor read as the [k = K][n = C] operand
+            return self.weights.derived("panel_dgrad", w, lambda t: kn.panel_pack_weights(t, torch.empty_like(t), Cn, K, 1, Cn))
+        return self.weights.derived("panel_fwd", w, lambda t: kn.panel_pack_weights(t, torch.empty_like(t), K, Cn, Cn, 1))
+
     def _f32_of(self, w16: torch.Tensor) -> torch.Tensor:
         """fp32 copy of a 16-bit weight tensor, shared by the passes of one step (dropped by invalidate_weights)"""
         return self.weights.derived("f32", w16, kn.upcast_f32)
@@ -866,7 +888,11 @@ class Engine:
         st = self._gram_stats(w, A, sa, bn, N * H * W, dtype)
         y = torch.empty(N, H, W, K, dtype=dtype, device=dev)
         bits = kn.gate_bytes(N * H * W, K, dtype, dev) if want_bits else None
-        kn.conv_fwd_post(d, a, w, y, st.scale, st.shift, ident=ident, relu=True, gate_out=bits)
+        wpk = self._panel_weights(conv, w, dtype, dgrad=False) if self.panel_fwd and Cw >= self.panel_fwd_min_k else None
+        # panel kernel: conv3 reads conv2's RAW output, bn2 + ReLU are applied while its operand panel is staged
+        if wpk is None or not kn.panel_fwd_post(d, c_in, wpk, y, st.scale, st.shift, pro=(pro.scale, pro.shift), ident=ident,
+                                                relu=True, gate_out=bits):
+            kn.conv_fwd_post(d, a, w, y, st.scale, st.shift, ident=ident, relu=True, gate_out=bits)
         u = Unit(conv, bn, False, d, c_in, pro, None, st, gram=(A, sa) if A is not None else None)
         return u, y, bits
 
@@ -1387,11 +1413,21 @@ class Engine:
             torch.cuda.current_stream(dev).synchronize()  # first use only: both streams may read them from now on
         return self._gate_vecs[key]
 
+    def _panel_dgrad_ok(self, first: Unit, resid, gate) -> bool:
+        """conv1's input gradient on the panel kernel: 16-bit 1x1 / stride 1 with a panel-sized k range, the gate (if any)
+        as bits; the stem-side conv of a BasicBlock (3x3) never qualifies"""
+        if not self.panel_dgrad or first.x_pro is not None or getattr(first.op, "bias", None) is not None or first.s2d:
+            return False
+        if gate is not None and gate[3] is None:  # the previous block's gate only as its activation: gather kernel
+            return False
+        return kn.panel_supported(first.desc, True)
+
     def _block_bwd_tail(self, rec: BlockRec, cur, top: int, resid, grads: GradStore, dtype, last_xmat=None,
                         gate=None, resid_stride: int = 1):
         """units[top] .. units[0]: weight gradient, input gradient with the producer's ReLU gate + BatchNorm sums
         fused into its epilogue, BatchNorm backward; the first unit adds the identity-path gradient `resid`"""
         dev = cur.device
+        fused = None
         for i in range(top, 0, -1):
             u, prev = rec.units[i], rec.units[i - 1]
             self._unit_wgrad(u, cur, grads, dtype, x_mat=last_xmat)
@@ -1400,9 +1436,27 @@ class Engine:
             # ReLU gate of prev and its BatchNorm-backward sums are fused into the dgrad epilogue
             da = self._unit_dgrad(u, cur, dtype, mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2)
             kp = self._bn_bwd_coeffs(s2, 2, 1, prev.bn, prev.st, grads)
-            kn.bn_bwd_apply(da, prev.c, kp[0], kp[1], kp[2], da)
+            if i == 1 and self._panel_dgrad_ok(rec.units[0], resid, gate):
+                fused = (da, prev.c, kp)  # bn1's backward is formed inside conv1's input-gradient launch below
+            else:
+                kn.bn_bwd_apply(da, prev.c, kp[0], kp[1], kp[2], da)
             cur = da
         first = rec.units[0]
+        if fused is not None or (top == 0 and self._panel_dgrad_ok(first, resid, gate)):
+            # panel kernel: dc1 = k1*g + k2*c1 + k3 while the operand panel is staged, written back IN PLACE for the weight
+            # gradient (a workgroup reads exactly the rows it rewrites); epilogue as msfwsi_conv_dgrad's
+            d1 = first.desc
+            wpk = self._panel_weights(first.op, self.weights.get(first.op.weight, dtype), dtype, dgrad=True)
+            dx = torch.empty(d1.N, d1.H, d1.W, d1.C, dtype=dtype, device=dev)
+            y_prev, gapg_prev, hw_prev, bits_prev = gate if gate is not None else (None, None, 1, None)
+            sg = kn.new_stats(d1.C, 2, dev) if bits_prev is not None else None
+            bn = (fused[1], fused[2][0], fused[2][1], fused[2][2]) if fused is not None else None
+            if kn.panel_dgrad(d1, cur, wpk, dx, bnbwd=bn, dc_out=cur if bn is not None else None, resid=resid,
+                              resid_stride=resid_stride, gapg=gapg_prev, gap_scale=1.0 / hw_prev, mask_bits=bits_prev, sums=sg):
+                self._unit_wgrad(first, cur, grads, dtype)
+                return dx, sg
+            if fused is not None:  # (not reached: _panel_dgrad_ok asked the library) -- the stand-alone pass after all
+                kn.bn_bwd_apply(cur, fused[1], fused[2][0], fused[2][1], fused[2][2], cur)
         self._unit_wgrad(first, cur, grads, dtype)
         if gate is None:
             return self._unit_dgrad(first, cur, dtype, resid=resid, resid_stride=resid_stride), None

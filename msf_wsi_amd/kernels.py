@@ -291,9 +291,38 @@ def conv_fwd(d: ConvDesc, x, w, y, pro=None, bias=None, stats=None):
     return y
 
 
+def gate_numel(rows: int, Cn: int, dtype) -> int:
+    """bytes of the gate-byte tensor of a [rows][Cn] activation (csrc/common.h gate_off: rows padded to 128 in the blocked
+    form, which every width with whole dwords of gate bytes per row uses)"""
+    cpr = Cn // vec_of(dtype)
+    return int(rows) * cpr if cpr % 4 else (int(rows) + 127) // 128 * 128 * cpr
+
+
 def gate_bytes(d_or_rows, Cn: int = 0, dtype=None, device="cuda") -> torch.Tensor:
-    """uint8 [rows][C/vec] buffer for the ReLU-gate bits of a [rows][C] activation (vec = 4 fp32 / 8 16-bit)"""
-    return torch.empty(int(d_or_rows), Cn // vec_of(dtype), dtype=torch.uint8, device=device)
+    """flat uint8 buffer for the ReLU-gate bits of a [rows][C] activation: one byte per 16-byte chunk (vec = 4 fp32 /
+    8 16-bit elements), laid out by gate_off (csrc/common.h); gate_unpack / gate_pack convert from / to [rows][C/vec]"""
+    return torch.empty(gate_numel(int(d_or_rows), Cn, dtype), dtype=torch.uint8, device=device)
+
+
+def _gate_index(rows: int, cpr: int, device) -> torch.Tensor:
+    m = torch.arange(rows, device=device, dtype=torch.int64).view(-1, 1)
+    c = torch.arange(cpr, device=device, dtype=torch.int64).view(1, -1)
+    if cpr % 4:
+        return m * cpr + c
+    return ((m >> 7) * (cpr >> 2) + (c >> 2)) * 512 + (m & 127) * 4 + (c & 3)
+
+
+def gate_unpack(buf: torch.Tensor, rows: int, Cn: int, dtype) -> torch.Tensor:
+    """the gate bytes as a [rows][C/vec] uint8 tensor (tests / diagnostics: plain torch indexing)"""
+    return buf.view(-1)[_gate_index(rows, Cn // vec_of(dtype), buf.device)]
+
+
+def gate_pack(linear: torch.Tensor, Cn: int, dtype) -> torch.Tensor:
+    """[rows][C/vec] uint8 -> a gate-byte buffer in the kernels' layout (tests)"""
+    rows = linear.shape[0]
+    buf = torch.zeros(gate_numel(rows, Cn, dtype), dtype=torch.uint8, device=linear.device)
+    buf[_gate_index(rows, Cn // vec_of(dtype), linear.device)] = linear.to(torch.uint8)
+    return buf
 
 
 def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad, P: int = 0, Q: int = 0) -> bool:
@@ -342,7 +371,7 @@ def conv_fwd_post(d: ConvDesc, x, w, y, post_scale, post_shift, ident=None, relu
     _req(post_scale, "post_scale", torch.float32, d.K)
     _req(post_shift, "post_shift", torch.float32, d.K)
     _opt(ident, "ident", dt, d.N * d.P * d.Q * d.K)
-    _opt(gate_out, "gate_out", torch.uint8, d.N * d.P * d.Q * (d.K // vec_of(dt)))
+    _opt(gate_out, "gate_out", torch.uint8, gate_numel(d.N * d.P * d.Q, d.K, dt))
     _timed("conv_fwd", d, x.element_size(), lambda: _lib.check(
         lib.msfwsi_conv_fwd_post(C.byref(d), _p(x), _p(w), _p(y), _p(post_scale), _p(post_shift), _p(ident),
                                  int(bool(relu)), _p(gate_out), _stream()), "conv_fwd_post"),
@@ -363,7 +392,7 @@ def conv_fwd_post2(d: ConvDesc, x, w_cat, y, src2, post_scale, post_shift, ident
     _req(post_scale, "post_scale", torch.float32, d.K)
     _req(post_shift, "post_shift", torch.float32, d.K)
     _opt(ident, "ident", dt, d.N * d.P * d.Q * d.K)
-    _opt(gate_out, "gate_out", torch.uint8, d.N * d.P * d.Q * (d.K // vec_of(dt)))
+    _opt(gate_out, "gate_out", torch.uint8, gate_numel(d.N * d.P * d.Q, d.K, dt))
     rc = [0]
 
     def run():
@@ -445,7 +474,7 @@ def conv_dgrad(d: ConvDesc, dy, w, dx, resid=None, gapg=None, gap_scale=0.0, mas
         if nsh * 2 * d.C != sums.numel():
             raise ValueError("sums must be [nshard,2,C]")
     elif mask_bits is not None:
-        _req(mask_bits, "mask_bits", torch.uint8, d.N * d.H * d.W * (d.C // vec_of(dt)))
+        _req(mask_bits, "mask_bits", torch.uint8, gate_numel(d.N * d.H * d.W, d.C, dt))
         _req(sums, "sums", torch.float64)
         nsh = sums.numel() // (2 * d.C)
         if nsh * 2 * d.C != sums.numel():
@@ -477,9 +506,12 @@ def panel_pack_weights(w, wpk, nout: int, k: int, stride_n: int, stride_k: int):
     return wpk
 
 
-def _panel_symbol(d: ConvDesc, dt, k: int, pro: int, epi: int) -> str:
+def _panel_symbol(d: ConvDesc, dt, k: int, pro: int, epi: int, hand: bool) -> str:
+    """the template-instance fragment rocprofv3 reports (mirrors launch_panel, csrc/panel.hip)"""
     tcode = "DF16_" if dt == torch.float16 else "DF16b"
-    return f"panel_kernelI{tcode}Li{k}ELi{64 if k == 512 else 128}ELi{pro}ELi{epi}E"
+    bm = 64 if k == 512 else 128
+    hand = hand and (d.N * d.H * d.W) % bm == 0
+    return f"panel_kernelI{tcode}Li{k}ELi{bm}ELi{pro}ELi{epi}ELb{int(hand)}E"
 
 
 def panel_fwd_post(d: ConvDesc, x, wpk, y, post_scale, post_shift, pro=None, ident=None, relu=True, gate_out=None) -> bool:
@@ -498,11 +530,11 @@ def panel_fwd_post(d: ConvDesc, x, wpk, y, post_scale, post_shift, pro=None, ide
         _req(ps, "pro_scale", torch.float32, d.C)
         _req(psh, "pro_shift", torch.float32, d.C)
     _opt(ident, "ident", dt, d.N * d.P * d.Q * d.K)
-    _opt(gate_out, "gate_out", torch.uint8, d.N * d.P * d.Q * (d.K // vec_of(dt)))
+    _opt(gate_out, "gate_out", torch.uint8, gate_numel(d.N * d.P * d.Q, d.K, dt))
     rc = _timed("conv_fwd", d, x.element_size(), lambda: lib.msfwsi_panel_fwd_post(
         C.byref(d), _p(x), _p(ps), _p(psh), _p(wpk), _p(y), _p(post_scale), _p(post_shift), _p(ident), int(bool(relu)),
         _p(gate_out), _stream()), extra_elems=ident.numel() if ident is not None else 0, dtype=dt, epi=1,
-        symbol_override=_panel_symbol(d, dt, d.C, 1 if pro is not None else 0, 1))
+        symbol_override=_panel_symbol(d, dt, d.C, 1 if pro is not None else 0, 1, ident is not None and gate_out is not None))
     if rc == -2:
         return False
     _lib.check(rc, "panel_fwd_post")
@@ -534,7 +566,7 @@ def panel_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, resid=None, r
     _opt(gapg, "gapg", dt, d.N * d.C)
     nsh = 1
     if mask_bits is not None:
-        _req(mask_bits, "mask_bits", torch.uint8, d.N * d.H * d.W * (d.C // vec_of(dt)))
+        _req(mask_bits, "mask_bits", torch.uint8, gate_numel(d.N * d.H * d.W, d.C, dt))
         _req(sums, "sums", torch.float64)
         nsh = sums.numel() // (2 * d.C)
         if nsh * 2 * d.C != sums.numel():
@@ -548,7 +580,8 @@ def panel_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, resid=None, r
         C.byref(d), _p(dy), _p(c), _p(k1), _p(k2), _p(k3), _p(dc_out), _p(wpk), _p(dx), _p(resid), int(resid_stride),
         _p(gapg), float(gap_scale), _p(mask_bits), _p(sums), nsh, _stream()), extra_elems=extra, dtype=dt,
         epi=3 if resid_stride > 1 else 0,
-        symbol_override=_panel_symbol(d, dt, d.K, 2 if bnbwd is not None else 0, 3 if resid_stride > 1 else 0))
+        symbol_override=_panel_symbol(d, dt, d.K, 2 if bnbwd is not None else 0, 3 if resid_stride > 1 else 0,
+                                       resid is not None and mask_bits is not None and gapg is None))
     if rc == -2:
         return False
     _lib.check(rc, "panel_dgrad")

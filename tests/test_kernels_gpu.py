@@ -145,7 +145,7 @@ def test_conv_fwd_post2_two_sources(hip_lib, dt, shape):
     assert rel(y.float().cpu().view(-1, K), ref) < tol(dt)
     vec = 4 if dt == torch.float32 else 8
     want = (y.reshape(-1, K // vec, vec) > 0).to(torch.int32) * (2 ** torch.arange(vec, device="cuda", dtype=torch.int32))
-    assert torch.equal(bits.to(torch.int32), want.sum(-1))
+    assert torch.equal(kn.gate_unpack(bits, y.numel() // K, K, dt).to(torch.int32), want.sum(-1))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -295,7 +295,7 @@ def test_gate_bits_roundtrip(hip_lib, dt):
     kn.conv_fwd_post(d, x, w, y, ps, pb, relu=True, gate_out=bits)
     vec = 4 if dt == torch.float32 else 8
     want = (y.reshape(-1, K // vec, vec) > 0).to(torch.int32) * (2 ** torch.arange(vec, device="cuda", dtype=torch.int32))
-    assert torch.equal(bits.to(torch.int32), want.sum(-1))
+    assert torch.equal(kn.gate_unpack(bits, y.numel() // K, K, dt).to(torch.int32), want.sum(-1))
     # a 1x1 conv K2 -> K whose input gradient is gated by y: bits vs activation
     K2 = 64
     d2 = kn.conv_desc(dt, N, H, H, K, K2, 1, 1, 1, 0)

@@ -27,8 +27,10 @@ def rnd(shape, dt, g, scale=1.0):
 
 
 def unpack_bits(bits, M, Nout):
-    """[M][Nout/8] bytes -> bool [M][Nout] (bit e of a byte = element e of that chunk)"""
-    b = bits.view(M, Nout // 8).cpu().to(torch.int32)
+    """gate-byte buffer -> bool [M][Nout] (bit e of a byte = element e of that chunk)"""
+    from msf_wsi_amd import kernels as kn
+
+    b = kn.gate_unpack(bits, M, Nout, torch.bfloat16).cpu().to(torch.int32)  # (16-bit types: 8 elements per chunk)
     return ((b.unsqueeze(-1) >> torch.arange(8)) & 1).bool().view(M, Nout)
 
 
@@ -111,7 +113,7 @@ def test_panel_dgrad(hip_lib, dt, geom, bnbwd, epi):
     k3 = torch.randn(Kc, generator=g) * 0.05
     resid = rnd((M, Cin), dt, g, 0.1)
     gapg = rnd((N, Cin), dt, g, 0.1)
-    bits = torch.randint(0, 256, (M, Cin // 8), dtype=torch.uint8, generator=g)
+    bits = kn.gate_pack(torch.randint(0, 256, (M, Cin // 8), dtype=torch.uint8, generator=g), Cin, dt)
     d = kn.conv_desc(dt, N, H, W, Cin, Kc, 1, 1, 1, 0)
     assert kn.panel_supported(d, True)
     wd = w.cuda()
@@ -171,7 +173,7 @@ def test_panel_dgrad_lowres_residual(hip_lib, dt, geom):
     w = rnd((Kc, Cin), dt, g, 1.0 / math.sqrt(Kc)).cuda()
     lo = rnd((N * (H // 2) * (W // 2), Cin), dt, g, 0.1).cuda()
     gapg = rnd((N, Cin), dt, g, 0.1).cuda()
-    bits = torch.randint(0, 256, (M, Cin // 8), dtype=torch.uint8, generator=g).cuda()
+    bits = kn.gate_pack(torch.randint(0, 256, (M, Cin // 8), dtype=torch.uint8, generator=g), Cin, dt).cuda()
     d = kn.conv_desc(dt, N, H, W, Cin, Kc, 1, 1, 1, 0)
     wpk = kn.panel_pack_weights(w, torch.empty_like(w), Cin, Kc, 1, Cin)
     a, b = torch.empty(M, Cin, dtype=dt, device="cuda"), torch.empty(M, Cin, dtype=dt, device="cuda")
@@ -227,7 +229,7 @@ def test_hand_counted_waits_equal_compiler_waits(hip_lib, dt, geom):
     ps, pb = (torch.rand(Kw, generator=g) + 0.5).cuda(), (torch.randn(Kw, generator=g) * 0.2).cuda()
     sc, sh = (torch.rand(Cn, generator=g) + 0.5).cuda(), (torch.randn(Cn, generator=g) * 0.3).cuda()
     k3 = (torch.randn(Cn, generator=g) * 0.05).cuda()
-    bits_in = torch.randint(0, 256, (M, Kw // 8), dtype=torch.uint8, generator=g).cuda()
+    bits_in = kn.gate_pack(torch.randint(0, 256, (M, Kw // 8), dtype=torch.uint8, generator=g), Kw, dt).cuda()
     d = kn.conv_desc(dt, N, H, W, Cn, Kw, 1, 1, 1, 0)
     d1 = kn.conv_desc(dt, N, H, W, Kw, Cn, 1, 1, 1, 0)
     wpk = kn.panel_pack_weights(w, torch.empty_like(w), Kw, Cn, Cn, 1)

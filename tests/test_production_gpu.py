@@ -268,7 +268,7 @@ def test_over_2gib_conv1x1_fwd_and_post(hip_lib, freed):
     c = F.conv2d(_nchw(y[pick2]), w2.double()).float().to(dt).double()
     ref2 = F.relu(c * ps.double().view(1, -1, 1, 1) + pb.double().view(1, -1, 1, 1) + _nchw(x[pick2]))
     assert rel(_nchw(out[pick2]), ref2) < tol(dt)
-    got_bits = bits.view(N, H * H, Cx // 8)[pick2].to(torch.int32)
+    got_bits = kn.gate_unpack(bits, N * H * H, Cx, dt).view(N, H * H, Cx // 8)[pick2].to(torch.int32)
     want = ((out[pick2].reshape(len(pick2), H * H, Cx // 8, 8) > 0).to(torch.int32)
             * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(-1)
     assert torch.equal(got_bits, want)
@@ -343,11 +343,13 @@ def test_over_2gib_dgrad_gated_and_two_source(hip_lib, freed):
     s = sums.sum(0)
     assert torch.allclose(s[0], dx.view(-1, Cx).sum(0, dtype=torch.float64), rtol=1e-6, atol=5e-2)
     # gate bits + pooled-feature gradient
-    bits = kn.gate_bytes(N * H * H, Cx, dt)
+    lin = torch.empty(N * H * H, Cx // 8, dtype=torch.uint8, device="cuda")
     vec = torch.arange(8, device="cuda", dtype=torch.int32)
     for i in range(0, N, 256):  # bit e of byte = (y[m][8*chunk+e] > 0)
         blk = (yprev[i:i + 256].reshape(-1, Cx // 8, 8) > 0).to(torch.int32)
-        bits[i * H * H:(i + 256) * H * H] = (blk << vec).sum(-1).to(torch.uint8)
+        lin[i * H * H:(i + 256) * H * H] = (blk << vec).sum(-1).to(torch.uint8)
+    bits = kn.gate_pack(lin, Cx, dt)  # the kernels' (blocked) gate-byte layout
+    del lin
     gapg = _rand_nhwc((N, Cx), dt, 10)
     dx2 = torch.empty_like(resid)
     sums2 = kn.new_stats(Cx)

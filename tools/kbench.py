@@ -50,7 +50,7 @@ def case_epi3():
         dx = torch.empty(M, C, dtype=DT, device="cuda")
         lo = rnd(N * (H // 2) * (H // 2), C, scale=0.05)
         full = rnd(M, C, scale=0.05)
-        bits = torch.randint(0, 256, (M * C // 8,), dtype=torch.uint8, device="cuda")
+        bits = torch.randint(0, 256, (kn.gate_numel(M, C, DT),), dtype=torch.uint8, device="cuda")
         gapg = rnd(N, C, scale=0.05)
         base = (M * K + M * C) * 2 + M * C // 8
         flop = 2.0 * M * K * C
@@ -171,7 +171,7 @@ def case_panel():
         wpk = kn.panel_pack_weights(w, torch.empty_like(w), C, K, 1, C)
         dx = torch.empty(M, C, dtype=DT, device="cuda")
         lo = rnd(N * (H // 2) * (H // 2), C, scale=0.05)
-        bits = torch.randint(0, 256, (M * C // 8,), dtype=torch.uint8, device="cuda")
+        bits = torch.randint(0, 256, (kn.gate_numel(M, C, DT),), dtype=torch.uint8, device="cuda")
 
         def run3():
             sums = kn.new_stats(C, 2, "cuda")
