@@ -149,6 +149,14 @@ int msfwsi_panel_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c,
                        const void* gapg, float gap_scale, const unsigned char* mask_bits, double* sums, int nshard,
                        void* stream);
 
+/* A64[i][j] += sum_p a[p][i]*a[p][j], sums[i] += sum_p a[p][i] for a = relu(scale*c + shift) rounded to the storage type:
+ * msfwsi_bn_act_sum + msfwsi_gram in ONE pass over the raw conv output c [M][C], the normalised activation never
+ * stored (bn3's batch statistics follow from these two, src/models/resnet.py:131-133 with the Gram-matrix algebra of
+ * msfwsi_fold_matvec / msfwsi_fold_dots).  A64 [C][C] and sums [C] fp64, caller zeroes.  16-bit storage types, C in {64,
+ * 128} (the whole C x C matrix lives in one workgroup's accumulators); otherwise MSFWSI_EUNSUPPORTED. */
+int msfwsi_panel_gram(int dtype, const void* c, const float* scale, const float* shift, double* A64, double* sums, long M,
+                      int C, void* stream);
+
 /* Specialised 3x3 / stride 1 / pad 1 path: the input patch of 256 raster pixels (+ halo) is staged once per
  * channel slab in LDS and reused by all nine taps (see csrc/conv3x3.hip).  Same results as msfwsi_conv_fwd /
  * msfwsi_conv_dgrad without prologue/bias/gapg; `supported` tells whether a geometry qualifies.

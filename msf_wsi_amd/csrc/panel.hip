@@ -484,6 +484,158 @@ __global__ __launch_bounds__(256, HAND ? 2 : 1) void panel_kernel(const PanelPar
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Gram matrix and column sums of a = relu(scale*c + shift) straight from the raw conv output c:
+//     A64[i][j] += sum_p a[p][i] a[p][j]        sums[i] += sum_p a[p][i]          (a rounded to the storage type)
+// -- what msfwsi_bn_act_sum + msfwsi_gram produce in two passes with the normalised activation written and re-read in
+// between (the statistics of bn3 follow from them: Engine._gram_stats, resnet.py:131-133).  Persistent workgroups walk
+// 128-row panels: the panel is staged exactly like panel_kernel's (same LDS image), the whole K x K matrix lives in the
+// workgroup's accumulators (K/32 x K/32 MFMA tiles spread over its waves; both operands come from the SAME image by the
+// transposed LDS read), the next panel's loads are in flight while the current one is multiplied; fp64 atomics at the end.
+struct GramParams {
+    const void* src;
+    const float* scale;
+    const float* shift;
+    double* A64;   // [K][K]
+    double* sums;  // [K]
+    long M;
+    int npanel;
+};
+
+// fragment of the panel image for 32 channels starting at col0 and the 16 rows of k group ks (operand of a product that
+// sums over ROWS): ds_read_b64_tr_b16 gathers 4 rows x 16 columns per 16-lane group (csrc/wgrad.hip read_tr_frag, on this
+// file's chunk-swizzled rows)
+template <typename T, int K>
+__device__ __forceinline__ typename MmaFrag<T>::type panel_tr_frag(const char* panel, int ks, int col0, int lane) {
+    typedef typename MmaFrag<T>::type frag_t;
+    constexpr int ROWB = K * 2;
+    const int li = lane & 15, G = lane >> 4;
+    const int q = li >> 2, p = li & 3;
+    const int kb = ks * 16 + (G >> 1) * 8 + q;
+    const int cb = (col0 + (G & 1) * 16 + p * 4) * 2;
+    const int o0 = kb * ROWB + ((((cb >> 4) ^ panel_swz<K>(kb)) << 4) | (cb & 15));
+    const int o1 = (kb + 4) * ROWB + ((((cb >> 4) ^ panel_swz<K>(kb + 4)) << 4) | (cb & 15));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(panel + o0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(panel + o1));
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(frag_t, both);
+}
+
+template <typename T, int K, int NWV>
+__global__ __launch_bounds__(64 * NWV) void panel_gram_kernel(const GramParams prm) {
+    constexpr int BM = 128, NT = 64 * NWV;
+    constexpr int CPR = K / 8, RPP = NT / CPR, NPASS = BM / RPP, ROWB = K * 2;
+    constexpr int TT = K / 32, TPW = TT * TT / NWV;  // MFMA tiles per dimension / per wave
+    static_assert(TT * TT % NWV == 0 && BM % RPP == 0 && NT % CPR == 0, "gram geometry");
+    typedef typename MmaFrag<T>::type frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* panel = smem;
+    float* colsum = reinterpret_cast<float*>(smem + BM * ROWB);  // [K]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cc = tid % CPR, rr = tid / CPR;
+
+    float csum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) csum[e] = 0.f;
+    for (int i = tid; i < K; i += NT) colsum[i] = 0.f;
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    const char* src = reinterpret_cast<const char*>(prm.src);
+    uint4 v[NPASS];
+    auto request = [&](int p) __attribute__((always_inline)) {
+        const long m0 = (long)p * BM;
+        const int rows_left = (int)(prm.M - m0 < BM ? prm.M - m0 : BM);
+        const char* base = src + m0 * ROWB;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = rr + i * RPP;
+            v[i] = *reinterpret_cast<const uint4*>(base + (unsigned)((row < rows_left ? row : rows_left - 1) * ROWB + cc * 16));
+        }
+    };
+    int p = blockIdx.x;
+    if (p < prm.npanel) request(p);
+    for (; p < prm.npanel; p += gridDim.x) {
+        const long m0 = (long)p * BM;
+        const int rows_left = (int)(prm.M - m0 < BM ? prm.M - m0 : BM);
+        // (the BatchNorm map is re-read per panel -- L1 hits -- instead of living in 16 registers beside the accumulators)
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = prm.scale[cc * 8 + e];
+            sh[e] = prm.shift[cc * 8 + e];
+        }
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = rr + i * RPP;
+            float f[8];
+            unpack16<T>(v[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = row < rows_left ? round_to<T>(fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f)) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += f[e];
+            *reinterpret_cast<uint4*>(panel + row * ROWB + ((cc ^ panel_swz<K>(row)) << 4)) = pack16<T>(f);
+        }
+        __syncthreads();
+        if (p + (int)gridDim.x < prm.npanel) request(p + gridDim.x);  // the next panel's rows fly during this one's MFMAs
+#pragma unroll 1  // (unrolled, hipcc hoists every step's transposed reads: the 256-channel instance spilled)
+        for (int ks = 0; ks < BM / 16; ++ks) {
+            const int t0 = wave * TPW;
+            const frag_t af = panel_tr_frag<T, K>(panel, ks, (t0 / TT) * 32, lane);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const frag_t bf = panel_tr_frag<T, K>(panel, ks, ((t0 + i) % TT) * 32, lane);
+                mma32<T>(acc[i], af, bf);
+            }
+        }
+        __syncthreads();  // every wave is done with the image before the next panel overwrites it
+    }
+    // column sums: lanes with the same chunk column add into LDS, then one fp64 atomic per channel
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(colsum + cc * 8 + e, csum[e]);
+    __syncthreads();
+    for (int i = tid; i < K; i += NT) atomicAdd(prm.sums + i, (double)colsum[i]);
+    // D[i][j]: lane -> column j, registers -> rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave * TPW + i;
+        const int r0 = (t / TT) * 32, c0 = (t % TT) * 32;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = r0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            atomicAdd(prm.A64 + (long)row * K + c0 + l31, (double)acc[i][reg]);
+        }
+    }
+}
+
+template <typename T, int K, int NWV>
+int launch_gram(const GramParams& prm, hipStream_t stream) {
+    constexpr int LDS = 128 * K * 2 + K * 4;
+    void (*kern)(const GramParams) = panel_gram_kernel<T, K, NWV>;
+    static int slots = 0;  // workgroups resident on the device at once (the kernel is persistent)
+    if (LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (slots == 0) {
+        int dev = 0, cus = 0, per = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, reinterpret_cast<const void*>(kern), 64 * NWV, LDS) != hipSuccess ||
+            cus <= 0 || per <= 0)
+            return MSFWSI_EUNSUPPORTED;
+        slots = cus * per;
+    }
+    const int grid = prm.npanel < slots ? prm.npanel : slots;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NWV), LDS, stream, prm);
+    return msfwsi_launch_status();
+}
+
 // W(n, k) = w[n * stride_n + k * stride_k]  ->  wpk[n/32][k/16][lane][j] = W(32 (n/32) + (lane & 31), 16 (k/16) + 8 (lane >> 5) + j):
 // the A operand of mfma_f32_32x32x16 for output-channel block n/32 and k step k/16, one contiguous KiB per fragment
 template <typename T>
@@ -616,4 +768,21 @@ extern "C" int msfwsi_panel_dgrad(const msfwsi_conv_desc* d, const void* dy, con
     }
     if (lores) return pro ? dispatch_panel_k<_Float16, 2, 3>(d->K, prm, st) : dispatch_panel_k<_Float16, 0, 3>(d->K, prm, st);
     return pro ? dispatch_panel_k<_Float16, 2, 0>(d->K, prm, st) : dispatch_panel_k<_Float16, 0, 0>(d->K, prm, st);
+}
+
+extern "C" int msfwsi_panel_gram(int dtype, const void* c, const float* scale, const float* shift, double* A64, double* sums,
+                                 long M, int C, void* stream) {
+    MSFWSI_CHECK_ARG(c != nullptr && scale != nullptr && shift != nullptr && A64 != nullptr && sums != nullptr && M > 0);
+    if ((dtype != MSFWSI_DT_BF16 && dtype != MSFWSI_DT_F16) || (C != 64 && C != 128) || M > 0x7fffffffL * 64)
+        return MSFWSI_EUNSUPPORTED;
+    GramParams prm{};
+    prm.src = c; prm.scale = scale; prm.shift = shift; prm.A64 = A64; prm.sums = sums; prm.M = M;
+    prm.npanel = (int)((M + 127) / 128);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MSFWSI_DT_BF16) {
+        if (C == 64) return launch_gram<__bf16, 64, 4>(prm, st);
+        return launch_gram<__bf16, 128, 4>(prm, st);
+    }
+    if (C == 64) return launch_gram<_Float16, 64, 4>(prm, st);
+    return launch_gram<_Float16, 128, 4>(prm, st);
 }

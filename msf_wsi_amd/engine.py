@@ -322,6 +322,7 @@ class Engine:
         # backward dc1 = k1*g + k2*c1 + k3 in its staging and writes it back once for the weight gradient
         self.panel_fwd = os.environ.get("MSFWSI_PANEL_FWD", "1") != "0"
         self.panel_dgrad = os.environ.get("MSFWSI_PANEL_DGRAD", "1") != "0"
+        self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
         self.panel_fwd_min_k = int(os.environ.get("MSFWSI_PANEL_FWD_MIN_K", "128"))  # 56x56 / 64 channels: the gather kernel is at the HBM roof
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
         self.stem_s2d = os.environ.get("MSFWSI_STEM_S2D", "1") != "0"  # ... in space-to-depth form (4x4 / stride 1)
@@ -874,24 +875,34 @@ class Engine:
         K = conv.out_channels
         dev = c_in.device
         d = kn.conv_desc(dtype, N, H, W, Cw, K, 1, 1, 1, 0)
-        a = torch.empty_like(c_in)
-        A = sa = None
+        w = self.weights.get(conv.weight, dtype)
+        # panel kernel (csrc/panel.hip): conv3 reads conv2's RAW output, bn2 + ReLU are applied while its operand panel is
+        # staged; with the fused Gram pass the normalised activation a2 is never written at all
+        wpk = None
+        if self.panel_fwd and kn.panel_supported(d, False):
+            wpk = self._panel_weights(conv, w, dtype, dgrad=False)
+        a = A = sa = None
         if self._bn_frozen(bn):  # eval mode: statistics are the running ones, no Gram matrix needed
-            kn.bn_act(c_in, pro.scale, pro.shift, a, relu=True)
+            if wpk is None:
+                a = torch.empty_like(c_in)
+                kn.bn_act(c_in, pro.scale, pro.shift, a, relu=True)
         else:
             sa = kn.zeros((Cw,), torch.float64, dev)
-            kn.bn_act_sum(c_in, pro.scale, pro.shift, a, sa)
-            dsq = kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0)
             A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)
-            kn.gram(dsq, a, A)
-        w = self.weights.get(conv.weight, dtype)
+            if not (wpk is not None and self.panel_gram and kn.panel_gram(c_in, pro.scale, pro.shift, A, sa)):
+                a = torch.empty_like(c_in)
+                kn.bn_act_sum(c_in, pro.scale, pro.shift, a, sa)
+                kn.gram(kn.conv_desc(dtype, N, H, W, Cw, Cw, 1, 1, 1, 0), a, A)
+                if Cw < self.panel_fwd_min_k:
+                    wpk = None  # a2 exists anyway and the gather kernel is at the HBM roof for these widths
         st = self._gram_stats(w, A, sa, bn, N * H * W, dtype)
         y = torch.empty(N, H, W, K, dtype=dtype, device=dev)
         bits = kn.gate_bytes(N * H * W, K, dtype, dev) if want_bits else None
-        wpk = self._panel_weights(conv, w, dtype, dgrad=False) if self.panel_fwd and Cw >= self.panel_fwd_min_k else None
-        # panel kernel: conv3 reads conv2's RAW output, bn2 + ReLU are applied while its operand panel is staged
-        if wpk is None or not kn.panel_fwd_post(d, c_in, wpk, y, st.scale, st.shift, pro=(pro.scale, pro.shift), ident=ident,
-                                                relu=True, gate_out=bits):
+        if wpk is not None:
+            if not kn.panel_fwd_post(d, c_in, wpk, y, st.scale, st.shift, pro=(pro.scale, pro.shift), ident=ident, relu=True,
+                                     gate_out=bits):
+                raise _lib.MsfwsiHipError("panel_fwd_post refused a geometry msfwsi_panel_supported accepted")
+        else:
             kn.conv_fwd_post(d, a, w, y, st.scale, st.shift, ident=ident, relu=True, gate_out=bits)
         u = Unit(conv, bn, False, d, c_in, pro, None, st, gram=(A, sa) if A is not None else None)
         return u, y, bits

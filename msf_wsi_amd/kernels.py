@@ -506,6 +506,32 @@ def panel_pack_weights(w, wpk, nout: int, k: int, stride_n: int, stride_k: int):
     return wpk
 
 
+def panel_gram(c, scale, shift, A, sums) -> bool:
+    """A[C][1][1][C] (fp32, zeroed) += a^T a and sums [C] (fp64, zeroed) += column sums of a = relu(scale*c + shift), in one
+    pass over the raw conv output c [.., C] (bn_act_sum + gram without the normalised activation); False if the library
+    has no kernel for the width"""
+    lib = _lib.load()
+    Cn = c.shape[-1]
+    M = c.numel() // Cn
+    _req(c, "c", c.dtype)
+    _req(scale, "scale", torch.float32, Cn)
+    _req(shift, "shift", torch.float32, Cn)
+    _req(A, "A", torch.float32, Cn * Cn)
+    _req(sums, "sums", torch.float64, Cn)
+    if c.dtype == torch.float32:
+        return False
+    A64 = ARENA.zeros((Cn * Cn,), torch.float64, c.device)
+    d = conv_desc(c.dtype, M, 1, 1, Cn, Cn, 1, 1, 1, 0)
+    rc = _timed("conv_wgrad", d, c.element_size(), lambda: lib.msfwsi_panel_gram(
+        dt_of(c), _p(c), _p(scale), _p(shift), _p(A64), _p(sums), M, Cn, _stream()), dtype=c.dtype, same_operand=True,
+        symbol_override=f"panel_gram_kernelI{'DF16_' if c.dtype == torch.float16 else 'DF16b'}Li{Cn}ELi4EE")
+    if rc == -2:
+        return False
+    _lib.check(rc, "panel_gram")
+    add_f64_to_f32(A64, A)
+    return True
+
+
 def _panel_symbol(d: ConvDesc, dt, k: int, pro: int, epi: int, hand: bool) -> str:
     """the template-instance fragment rocprofv3 reports (mirrors launch_panel, csrc/panel.hip)"""
     tcode = "DF16_" if dt == torch.float16 else "DF16b"

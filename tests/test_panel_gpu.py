@@ -258,3 +258,35 @@ def test_hand_counted_waits_equal_compiler_waits(hip_lib, dt, geom):
             assert (ref[4] - got[4]).abs().max().item() <= 1e-9 * max(1.0, ref[4].abs().max().item())
     finally:
         hip_lib.msfwsi_set_tuning(17, 1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(3, 7, 9, 64), (2, 14, 14, 128), (700, 8, 8, 64), (300, 8, 8, 128)])
+def test_panel_gram(hip_lib, dt, geom):
+    """Gram matrix + column sums of relu(scale*c + shift) in one pass over the raw conv output (msfwsi_panel_gram): against
+    fp64 on the rounded activation, and against the two-pass form it replaces (msfwsi_bn_act_sum + msfwsi_gram); ragged last
+    panel, more panels than resident workgroups (persistent loop)"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cn = geom
+    M = N * H * W
+    g = torch.Generator().manual_seed(15)
+    c = rnd((M, Cn), dt, g).cuda()
+    sc = (torch.rand(Cn, generator=g) + 0.5).cuda()
+    sh = (torch.randn(Cn, generator=g) * 0.3).cuda()
+    A = kn.zeros((Cn, 1, 1, Cn), torch.float32, "cuda")
+    sa = kn.zeros((Cn,), torch.float64, "cuda")
+    assert kn.panel_gram(c, sc, sh, A, sa)
+    a2 = torch.empty_like(c)
+    sb = kn.zeros((Cn,), torch.float64, "cuda")
+    kn.bn_act_sum(c, sc, sh, a2, sb)
+    B = kn.zeros((Cn, 1, 1, Cn), torch.float32, "cuda")
+    kn.gram(kn.conv_desc(dt, M, 1, 1, Cn, Cn, 1, 1, 1, 0), a2, B)
+    torch.cuda.synchronize()
+    a64 = a2.double().cpu()  # the rounded activation both forms multiply
+    ref = a64.t() @ a64
+    assert rel(A.view(Cn, Cn), ref) < 1e-6
+    assert rel(B.view(Cn, Cn), ref) < 1e-6
+    assert rel(sa, a64.sum(0)) < 1e-6 and rel(sb, a64.sum(0)) < 1e-6
+    assert not kn.panel_gram(rnd((64, 256), dt, g).cuda(), torch.ones(256).cuda(), torch.zeros(256).cuda(),
+                             kn.zeros((256, 1, 1, 256), torch.float32, "cuda"), kn.zeros((256,), torch.float64, "cuda"))
