@@ -140,8 +140,8 @@ __device__ __forceinline__ void pl_wait(u32x4& r, unsigned& r2) {
 // so every load is followed by exactly KS - 1 + NL + NS younger operations before its first consumer (NL loads, NS
 // stores per epilogue): ONE constant serves every hand-counted wait.
 template <typename T, int K, int BM, int EPI, bool HAND>
-__device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel, char* scratch, float* colsum, long m0,
-                                             int rows_left, int wave, int lane) {
+__device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel, char* scratch, float* colsum,
+                                             const char* gapl, long m0, int rows_left, int wave, int lane) {
     constexpr int NW = 4;
     constexpr int TM = BM / 32, NG = TM * 2, KS = K / 16, ROWB = K * 2;
     constexpr int SCR_PITCH = 80;
@@ -154,6 +154,7 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
     // for all row tiles instead of a 64-bit pair each -- with per-lane 64-bit addresses the 256-channel instances spilled)
     const int q = lane & 3, r4 = lane >> 2;
     const int PQ = prm.P * prm.Q;
+    const unsigned img0 = FWD ? 0u : fast_div((unsigned)m0, prm.div_pq);  // first image of the panel (gapl's first row)
     const char* eop_wg = reinterpret_cast<const char*>(FWD ? prm.ident : prm.resid);
     const bool has_eop = eop_wg != nullptr;
     if (!LORES && has_eop) eop_wg += m0 * prm.Nout * 2;
@@ -340,11 +341,17 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] += rs[e];
                     }
-                    if (!HAND && prm.gapg != nullptr) {  // (stage-end blocks only: they run on hipcc's own waits, see launch_panel)
-                        const long m = m0 + (ok ? rbase + r4 : 0);
-                        const long img = LORES ? (long)fast_div((unsigned)m, prm.div_pq) : m / PQ;
+                    if (prm.gapg != nullptr) {
+                        // pooled-feature gradient of the row's image.  HAND: from the two rows panel_kernel staged in LDS (a
+                        // whole panel spans at most two images there: launch_panel) -- no vector-memory operation, the
+                        // hand-counted waits stay exact; otherwise straight from memory on hipcc's own waits
+                        const unsigned m = (unsigned)(m0 + (ok ? rbase + r4 : 0));
+                        const unsigned img = fast_div(m, prm.div_pq);
+                        uint4 gv;
+                        if constexpr (HAND) gv = *reinterpret_cast<const uint4*>(gapl + ((img - img0) * (unsigned)prm.Nout + (unsigned)ncol) * 2u);
+                        else gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) + (long)img * prm.Nout + ncol);
                         float gp[8];
-                        unpack16<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) + img * prm.Nout + ncol), gp);
+                        unpack16<T>(gv, gp);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
                     }
@@ -417,9 +424,24 @@ __global__ __launch_bounds__(256, HAND ? 2 : 1) void panel_kernel(const PanelPar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* scratch = smem + BM * ROWB + wave * SCR_BYTES;                          // private to this wave
     float* colsum = reinterpret_cast<float*>(smem + BM * ROWB + NW * SCR_BYTES);  // [Nout] (input gradient with sums)
+    char* gapl = smem + BM * ROWB + NW * SCR_BYTES + (FWD || prm.sums == nullptr ? 0 : prm.Nout * 4);  // [2][Nout] T (HAND with gapg)
     const long m0 = (long)blockIdx.x * BM;
     const int rows_left = (int)((long)prm.M - m0 < BM ? (long)prm.M - m0 : BM);  // rows of this panel inside the tensor
 
+    if constexpr (!FWD && HAND) {
+        if (prm.gapg != nullptr) {
+            // the pooled-feature gradients of the (at most two) images this panel touches: read by the epilogue from LDS
+            const unsigned i0 = fast_div((unsigned)m0, prm.div_pq);
+            const unsigned nimg = fast_div((unsigned)(prm.M - 1), prm.div_pq) + 1u;
+            const int cpr = prm.Nout >> 3;
+            for (int i = tid; i < 2 * cpr; i += NT) {
+                const unsigned img = i0 + (i >= cpr ? 1u : 0u);
+                const int ch = i >= cpr ? i - cpr : i;
+                *reinterpret_cast<uint4*>(gapl + i * 16) = *reinterpret_cast<const uint4*>(
+                    reinterpret_cast<const T*>(prm.gapg) + (long)(img < nimg ? img : nimg - 1) * prm.Nout + ch * 8);
+            }
+        }
+    }
     // ---------------- stage the operand panel: every pass requested up front, transformed in registers ----------------
     // (loads are unconditional from a clamped row -- a row past the tensor's end re-reads the last valid one and its
     //  results are never stored: a divergent branch around each load made hipcc drain the queue between passes)
@@ -471,7 +493,7 @@ __global__ __launch_bounds__(256, HAND ? 2 : 1) void panel_kernel(const PanelPar
     __syncthreads();  // the only workgroup barrier before the sums: from here on every wave runs alone
 
     // HAND (chosen by the launcher): every panel whole and every optional operand of the epilogue class present
-    panel_blocks<T, K, BM, EPI, HAND>(prm, panel, scratch, colsum, m0, rows_left, wave, lane);
+    panel_blocks<T, K, BM, EPI, HAND>(prm, panel, scratch, colsum, gapl, m0, rows_left, wave, lane);
 
     if constexpr (!FWD) {
         if (prm.sums != nullptr) {
@@ -657,12 +679,14 @@ long g_panel_hand = 1;  // msfwsi_set_tuning(17, .): 0 = every launch on hipcc's
 
 template <typename T, int K, int BM, int PRO, int EPI>
 int launch_panel(const PanelParams& prm, hipStream_t stream) {
-    const int LDS = BM * K * 2 + 4 * 32 * 80 + (EPI != 1 && prm.sums != nullptr ? prm.Nout * 4 : 0);
+    const int LDS = BM * K * 2 + 4 * 32 * 80 + (EPI != 1 && prm.sums != nullptr ? prm.Nout * 4 : 0) +
+                    (EPI != 1 && prm.gapg != nullptr ? prm.Nout * 4 : 0);
     // hand-counted loads (panel_blocks) need a fixed number of vector-memory operations per block: whole panels only, and
     // every optional operand of the epilogue class present (the engine's launches all are: M = N*H*W with N a multiple of
     // 128 tiles, identity + gate bytes / residual + gate bytes + sums)
     const bool hand = g_panel_hand && prm.M % BM == 0 && (EPI == 1 ? (prm.ident != nullptr && prm.gate_out != nullptr)
-                                                   : (prm.resid != nullptr && prm.mask_bits != nullptr && prm.gapg == nullptr));
+                                                   : (prm.resid != nullptr && prm.mask_bits != nullptr &&
+                                                      (prm.gapg == nullptr || prm.P * prm.Q >= BM)));  // (a panel within two images)
     void (*kern)(const PanelParams) = hand ? panel_kernel<T, K, BM, PRO, EPI, true> : panel_kernel<T, K, BM, PRO, EPI, false>;
     if (LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

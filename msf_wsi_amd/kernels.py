@@ -607,7 +607,7 @@ def panel_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, resid=None, r
         _p(gapg), float(gap_scale), _p(mask_bits), _p(sums), nsh, _stream()), extra_elems=extra, dtype=dt,
         epi=3 if resid_stride > 1 else 0,
         symbol_override=_panel_symbol(d, dt, d.K, 2 if bnbwd is not None else 0, 3 if resid_stride > 1 else 0,
-                                       resid is not None and mask_bits is not None and gapg is None))
+                                       resid is not None and mask_bits is not None and (gapg is None or d.H * d.W >= 128)))
     if rc == -2:
         return False
     _lib.check(rc, "panel_dgrad")

@@ -290,3 +290,52 @@ def test_panel_gram(hip_lib, dt, geom):
     assert rel(sa, a64.sum(0)) < 1e-6 and rel(sb, a64.sum(0)) < 1e-6
     assert not kn.panel_gram(rnd((64, 256), dt, g).cuda(), torch.ones(256).cuda(), torch.zeros(256).cuda(),
                              kn.zeros((256, 1, 1, 256), torch.float32, "cuda"), kn.zeros((256,), torch.float64, "cuda"))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(8, 16, 16, 128, 256), (4, 16, 16, 256, 512), (16, 12, 12, 64, 256)])
+@pytest.mark.parametrize("lowres", [False, True])
+def test_panel_dgrad_pooled_gradient_from_lds(hip_lib, dt, geom, lowres):
+    """whole panels with the pooled-feature gradient (the stage-boundary launches of the encoder backward): the
+    hand-counted instance reads gapg from the two image rows staged in LDS; same bits as the compiler-counted instance
+    that reads it from memory, and both against fp64"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Kc, Cin = geom
+    M = N * H * W
+    assert M % 128 == 0 and H * W >= 128
+    g = torch.Generator().manual_seed(16)
+    dy = rnd((M, Kc), dt, g, 0.1).cuda()
+    w = rnd((Kc, Cin), dt, g, 1.0 / math.sqrt(Kc)).cuda()
+    full = rnd((M, Cin), dt, g, 0.1).cuda()
+    lo = rnd((N * (H // 2) * (W // 2), Cin), dt, g, 0.1).cuda()
+    gapg = rnd((N, Cin), dt, g, 0.5).cuda()
+    bits = kn.gate_pack(torch.randint(0, 256, (M, Cin // 8), dtype=torch.uint8, generator=g), Cin, dt).cuda()
+    d = kn.conv_desc(dt, N, H, W, Cin, Kc, 1, 1, 1, 0)
+    wpk = kn.panel_pack_weights(w, torch.empty_like(w), Cin, Kc, 1, Cin)
+    kw = dict(resid=lo, resid_stride=2) if lowres else dict(resid=full)
+
+    def run():
+        dx = torch.empty(M, Cin, dtype=dt, device="cuda")
+        sums = kn.new_stats(Cin, 2, "cuda")
+        assert kn.panel_dgrad(d, dy, wpk, dx, gapg=gapg, gap_scale=1.0 / (H * W), mask_bits=bits, sums=sums, **kw)
+        torch.cuda.synchronize()
+        return dx, sums.sum(0)[0]
+
+    try:
+        assert hip_lib.msfwsi_set_tuning(17, 0) == 0
+        ref_dx, ref_s = run()
+        assert hip_lib.msfwsi_set_tuning(17, 1) == 0
+        dx, s = run()
+    finally:
+        hip_lib.msfwsi_set_tuning(17, 1)
+    assert torch.equal(dx, ref_dx)
+    assert (s - ref_s).abs().max().item() <= 1e-9 * max(1.0, ref_s.abs().max().item())
+    res = torch.zeros(N, H, W, Cin, dtype=torch.float64)
+    if lowres:
+        res[:, ::2, ::2, :] = lo.cpu().double().view(N, H // 2, W // 2, Cin)
+    else:
+        res = full.cpu().double().view(N, H, W, Cin)
+    ref = dy.cpu().double() @ w.cpu().double() + res.reshape(M, Cin) + (gapg.cpu().double() / (H * W)).repeat_interleave(H * W, dim=0)
+    ref = ref * unpack_bits(bits, M, Cin).double()
+    assert rel(dx, ref) < tol(dt)
