@@ -10,7 +10,9 @@
  *   - every pointer is a DEVICE pointer owned by the caller (torch's caching allocator); the library
  *     never allocates, frees or synchronises; `stream` is a hipStream_t passed as void*.
  *   - return value: 0 ok; <0 invalid argument (-1) / unsupported configuration (-2); >0 a hipError_t.
- *   - re-entrant and stateless: safe to call from the forward thread and autograd's backward thread.
+ *   - re-entrant: safe to call from the forward thread and autograd's backward thread.  The only state the library
+ *     keeps is the PROCESS-GLOBAL tuning switches of msfwsi_set_tuning (relaxed atomics; they select between kernels that
+ *     compute the same results and default to the measured-fastest choice).
  *   - activations are NHWC ("channels last"), viewed as [M = N*H*W][C]; dtype selects the storage type
  *     of activations AND weights (MSFWSI_DT_F32 exact-fp32 MFMA path, MSFWSI_DT_BF16 / MSFWSI_DT_F16 16-bit
  *     MFMA with fp32 accumulation); per-channel vectors, statistics and weight gradients are always fp32 / fp64.
@@ -469,8 +471,7 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * gradient, key 6 = 0 the 256x256 / 16-wave weight-gradient tile, key 9 = 0 the weights-stationary 3x3
  * kernel of the 64 -> 64 layers, key 10 = 0 their output-stationary weight-gradient kernel, key 11 = smallest
  * padded raster (positions) that kernel takes, key 12 = 0 the stationary stem kernels (forward and weight gradient), key 13 =
- * smallest padded raster the stem's weight-gradient kernel takes, key 14 = 1 the max-pool backward by 2x2 input
- * patches (default 0, measured slower), key 16 = 0 the column-walk max-pool forward / backward (default 1; 0 = one thread per
+ * smallest padded raster the stem's weight-gradient kernel takes, key 16 = 0 the column-walk max-pool forward / backward (default 1; 0 = one thread per
  * window / pixel) (A/B measurements, tests).
  * key 17 = 0 runs the panel kernels (csrc/panel.hip) on compiler-counted waits instead of the hand-counted ones (same
  * arithmetic, bit-identical results: the A/B reference of tools/check_hand_waits.py's static audit).
@@ -478,6 +479,8 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * kernel (0 = none; 1 = each gradient tile summed by one workgroup in pixel order instead of fp32 atomics in arrival
  * order -- the results then differ from the default's by rounding, 4e-7, and are the same on every run). */
 int msfwsi_set_tuning(int key, long value);
+/* the current value of a switch (fixtures save it before they flip one, and restore exactly that) */
+int msfwsi_get_tuning(int key, long* value);
 
 /* library identification: returns the gfx target string the code objects were built for */
 const char* msfwsi_target(void);

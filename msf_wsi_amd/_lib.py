@@ -103,6 +103,7 @@ SIGNATURES = {
     "msfwsi_panel_fwd_post": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "msfwsi_panel_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _i, _vp],
     "msfwsi_set_tuning": [_i, _l],
+    "msfwsi_get_tuning": [_i, _vp],
     "msfwsi_conv3x3_supported": [_desc],
     "msfwsi_conv3x3_stationary": [_desc],
     "msfwsi_conv_wgrad_stationary": [_desc],
@@ -158,7 +159,7 @@ def load() -> C.CDLL:
                      (4, "MSFWSI_SMALL_GRID_BLOCKS"), (5, "MSFWSI_S2_PARITY"), (6, "MSFWSI_WGRAD_BIG"),
                      (9, "MSFWSI_C3_STATIONARY"),
                      (10, "MSFWSI_WGRAD_OS"),
-                     (12, "MSFWSI_STEM_WS"), (14, "MSFWSI_POOL_BWD_PATCH"), (15, "MSFWSI_WGRAD_MAX_SPLITS")):  # A/B switches (see msfwsi_set_tuning)
+                     (12, "MSFWSI_STEM_WS"), (15, "MSFWSI_WGRAD_MAX_SPLITS")):  # A/B switches (see msfwsi_set_tuning)
         if env in os.environ:
             lib.msfwsi_set_tuning(key, int(os.environ[env]))
     _lib = lib

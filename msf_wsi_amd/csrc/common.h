@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -25,6 +27,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
     do {                       \
         if (!(cond)) return MSFWSI_EINVAL; \
     } while (0)
+
+// Process-global tuning switches (msfwsi_set_tuning / msfwsi_get_tuning): read by every launch, written from any host thread
+// (tests, A/B drivers) -- relaxed atomics, no ordering implied between a switch and launches already enqueued.
+struct msfwsi_tunable {
+    std::atomic<long> v;
+    constexpr msfwsi_tunable(long init) : v(init) {}
+    operator long() const { return v.load(std::memory_order_relaxed); }
+    msfwsi_tunable& operator=(long x) {
+        v.store(x, std::memory_order_relaxed);
+        return *this;
+    }
+};
 
 static inline int msfwsi_launch_status() {
     hipError_t e = hipGetLastError();

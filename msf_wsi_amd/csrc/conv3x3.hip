@@ -692,7 +692,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const C3WParams prm) {
     }
 }
 
-long g_c3_stationary = 1;  // msfwsi_set_tuning(9, .): 0 = the 64 -> 64 layers on the per-tile kernels
+msfwsi_tunable g_c3_stationary{1};  // msfwsi_set_tuning(9, .): 0 = the 64 -> 64 layers on the per-tile kernels
 
 template <typename T, bool DGRAD>
 int launch_c3w(C3WParams& prm, hipStream_t stream) {
@@ -762,7 +762,11 @@ extern "C" int msfwsi_conv3x3_supported(const msfwsi_conv_desc* d) {
 extern "C" int msfwsi_conv3x3_stationary(const msfwsi_conv_desc* d) {
     return d != nullptr && msfwsi_dtype_ok(d->dtype) && c3w_ok(d) ? 1 : 0;
 }
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(long v) { g_c3_stationary = v; }
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_c3_set_stationary(long v, int write) {
+    const long old = g_c3_stationary;
+    if (write) g_c3_stationary = v;
+    return old;
+}
 
 extern "C" int msfwsi_conv3x3_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y, double* stats,
                                   int nshard, const float* pro_scale, const float* pro_shift, void* stream) {

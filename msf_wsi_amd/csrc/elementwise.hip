@@ -501,115 +501,6 @@ __global__ void stem_pool_bwd_kernel(const T* __restrict__ dp, const unsigned ch
     if (sums != nullptr) col_commit<2, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
 }
 
-// The same by 2x2 INPUT PATCHES (rows 2i, 2i+1 x columns 2j, 2j+1): the four pixels of a patch are covered by the four
-// windows (i..i+1, j..j+1) only -- an even row / column belongs to one window, an odd one to two -- so a thread loads
-// the gradient and argmax chunks of 4 windows for 4 pixels (per-pixel form above: 9 window loads for the same 4
-// pixels, 1 / 2 / 2 / 4) and the kernel moves 224 instead of 344 bytes through the vector memory path per 64 bytes of
-// output.  OFF by default: it measured 1 % slower on the whole step (see g_pool_bwd_patch).  Window position codes
-// r*3+s of the four pixels:
-//   (2i,2j): (i,j)=4 | (2i,2j+1): (i,j)=5, (i,j+1)=3 | (2i+1,2j): (i,j)=7, (i+1,j)=1 | (2i+1,2j+1): 8, 6, 2, 0
-template <typename T>
-__global__ __launch_bounds__(256) void stem_pool_bwd_patch_kernel(const T* __restrict__ dp, const unsigned char* __restrict__ amax,
-                                           const T* __restrict__ c0, const float* __restrict__ scale,
-                                           const float* __restrict__ shift, T* __restrict__ g0, double* sums, int nshard,
-                                           const float* __restrict__ k1, const float* __restrict__ k2,
-                                           const float* __restrict__ k3, const T* __restrict__ dact, int N, int H, int W,
-                                           int C, int P, int Q, int cw, int nrl, int rows_per_block) {
-    constexpr int VEC = ElemTraits<T>::VEC;
-    extern __shared__ float smem_f[];
-    const int tid = threadIdx.x;
-    const int cc = tid % cw, rl = tid / cw;
-    const int chunk = blockIdx.x * cw + cc;
-    const bool active = rl < nrl && chunk * VEC < C;
-    const int ch = chunk * VEC;
-    const int Hh = (H + 1) >> 1, Wh = (W + 1) >> 1;
-    float acc[2][VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = 0.f;
-    if (active) {
-        float sc[VEC], sh[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            sc[e] = scale[ch + e];
-            sh[e] = shift[ch + e];
-        }
-        const long Mp = (long)N * Hh * Wh;
-        const long rbeg = (long)blockIdx.y * rows_per_block;
-        const long rend = rbeg + rows_per_block < Mp ? rbeg + rows_per_block : Mp;
-        for (long mp = rbeg + rl; mp < rend; mp += nrl) {
-            const unsigned mu = (unsigned)mp;  // N*Hh*Wh < 2^31 (checked by the launcher)
-            const unsigned t = mu / (unsigned)Wh;
-            const int j = (int)(mu - t * (unsigned)Wh);
-            const int n = (int)(t / (unsigned)Hh);
-            const int i = (int)(t - (unsigned)n * (unsigned)Hh);
-            // the four windows (i + a, j + b): gradient chunks kept PACKED (16 bytes each) and unpacked per use -- held as
-            // 4 x 8 floats the kernel needed ~170 VGPRs and spilled at the 128 a 256-thread streaming kernel gets
-            uint4 dpk[2][2];
-            unsigned long long ab[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    ab[a][b] = ~0ull;  // no position code matches 0xff
-                    dpk[a][b] = make_uint4(0, 0, 0, 0);
-                    if (i + a < P && j + b < Q) {
-                        const long o = (((long)n * P + i + a) * Q + j + b) * C + ch;
-                        dpk[a][b] = *reinterpret_cast<const uint4*>(dp + o);
-                        if constexpr (VEC == 8) ab[a][b] = *reinterpret_cast<const unsigned long long*>(amax + o);
-                        else ab[a][b] = *reinterpret_cast<const unsigned*>(amax + o);
-                    }
-                }
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int dw = 0; dw < 2; ++dw) {
-                    const int h = 2 * i + dh, w = 2 * j + dw;
-                    if (h >= H || w >= W) continue;
-                    float g[VEC];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) g[e] = 0.f;
-                    // window (i + a, j + b) sees this pixel at r = dh + 1 - 2a, s = dw + 1 - 2b (valid when in 0..2)
-#pragma unroll
-                    for (int a = 0; a <= dh; ++a)
-#pragma unroll
-                        for (int b = 0; b <= dw; ++b) {
-                            const unsigned code = (unsigned)((dh + 1 - 2 * a) * 3 + (dw + 1 - 2 * b));
-                            float d[VEC];
-                            unpack16<T>(dpk[a][b], d);
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e)
-                                if (((unsigned)(ab[a][b] >> (8 * e)) & 0xffu) == code) g[e] += d[e];
-                        }
-                    const long m = ((long)n * H + h) * W + w;
-                    float x[VEC];
-                    unpack16<T>(*reinterpret_cast<const uint4*>(c0 + m * C + ch), x);
-                    if (dact != nullptr) {
-                        float da[VEC];
-                        unpack16<T>(*reinterpret_cast<const uint4*>(dact + m * C + ch), da);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) g[e] += da[e];
-                    }
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        if (!(fmaf(x[e], sc[e], sh[e]) > 0.f)) g[e] = 0.f;
-                        g[e] = round_to<T>(g[e]);
-                        acc[0][e] += g[e];
-                        acc[1][e] = fmaf(g[e], x[e], acc[1][e]);
-                    }
-                    if (k1 != nullptr) {
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) g[e] = fmaf(k1[ch + e], g[e], fmaf(k2[ch + e], x[e], k3[ch + e]));
-                    }
-                    if (g0 != nullptr) *reinterpret_cast<uint4*>(g0 + m * C + ch) = pack16<T>(g);
-                    // one pixel after the other: scheduled together, the four pixels' loads and unpacked vectors need
-                    // ~180 VGPRs (two waves per SIMD, or spills at the 128 of four) -- other waves cover the latency
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        }
-    }
-    if (sums != nullptr) col_commit<2, VEC>(acc, smem_f, cw, nrl, cc, rl, active, ch, C, sums, nshard);
-}
-
 // ---------------------------------------------------------------------------------------------
 // The same by COLUMN WALK (round 4, the default for the training path: g0 + sums, no second gradient, no k1 mode).
 // The per-pixel kernel above loads the gradient + argmax chunks of every window that covers a pixel: 2.25 window loads
@@ -1436,10 +1327,12 @@ extern "C" int msfwsi_bn_act_sum(int dtype, const void* c, const float* scale, c
     return msfwsi_launch_status();
 }
 
-static long g_pool_bwd_patch = 0;
-static long g_pool_bwd_walk = 1;  // msfwsi_set_tuning(16, .): 0 = the per-window / per-pixel max-pool kernels (A/B); 1 = column walk
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_patch(long v) { g_pool_bwd_patch = v; }
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_walk(long v) { g_pool_bwd_walk = v; }
+static msfwsi_tunable g_pool_bwd_walk{1};  // msfwsi_set_tuning(16, .): 0 = the per-window / per-pixel max-pool kernels (A/B); 1 = column walk
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_pool_bwd_set_walk(long v, int write) {
+    const long old = g_pool_bwd_walk;
+    if (write) g_pool_bwd_walk = v;
+    return old;
+}
 
 extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scale, const float* shift, void* out,
                                     unsigned char* argmax, int N, int H, int W, int C, void* stream) {
@@ -1466,11 +1359,6 @@ extern "C" int msfwsi_stem_pool_fwd(int dtype, const void* c0, const float* scal
     return msfwsi_launch_status();
 }
 
-// msfwsi_set_tuning(14, .): 1 = the 2x2-patch kernel.  Measured on the bench workload (A/B on one box, two rounds):
-// 568-571 ms/step with it against 563.6 without -- fewer bytes through the vector memory path, but four pixels per
-// thread need ~180 VGPRs (hipcc schedules them together: two waves per SIMD, or 150-300 bytes of scratch when capped at
-// 128 / 96 registers), too few waves in flight for a streaming kernel; the per-pixel kernel (109 VGPRs) stays the default
-
 extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax, const void* c0,
                                     const float* scale, const float* shift, void* g0, double* sums, int nshard,
                                     const float* k1, const float* k2, const float* k3, const void* dact, int N, int H,
@@ -1495,13 +1383,6 @@ extern "C" int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned ch
         MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_walk_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, ST(stream),
                                (const T*)dp, argmax, (const T*)c0, scale, shift, (T*)g0, sums, nshard, N, H, W, C, P, Q,
                                cpp, qgroups, ntask));
-        return msfwsi_launch_status();
-    }
-    if (g_pool_bwd_patch) {  // by 2x2 input patches: 4 window loads per 4 pixels instead of 9
-        ColGrid gp = make_col_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2), C, vec, 4096);
-        MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(stem_pool_bwd_patch_kernel<T>, gp.grid, dim3(kThreads), lds, ST(stream),
-                               (const T*)dp, argmax, (const T*)c0, scale, shift, (T*)g0, sums, nshard, k1, k2, k3,
-                               (const T*)dact, N, H, W, C, P, Q, gp.cw, gp.nrl, gp.rows_per_block));
         return msfwsi_launch_status();
     }
     ColGrid g = make_col_grid((long)N * H * W, C, vec, 2048);

@@ -29,12 +29,6 @@
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
-#ifndef MSFWSI_SETPRIO
-#define MSFWSI_SETPRIO 0
-#endif
-#ifndef MSFWSI_STAGGER
-#define MSFWSI_STAGGER 0  // 1: the second half of a workgroup's waves (the SIMD partners of the first half) issue the DMA requests AFTER their MFMAs
-#endif
 #ifndef MSFWSI_ABLATE
 #define MSFWSI_ABLATE 0  // diagnostic builds (tools/build_variant.sh): 1 = pure-DMA kernel without its k loop (epilogue only),
 #endif                   // 2 = without the epilogue's global loads / stores (k loop + LDS transposition only), 3 = 3x3 launches
@@ -1025,16 +1019,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
                     wf[tn] = t;
                 }
             }
-#if MSFWSI_SETPRIO
-            __builtin_amdgcn_s_setprio(1);  // T5 of the HIP guide: keeps hipcc from spreading the MFMA cluster (A/B: no gain here)
-#endif
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) mma_step<T>(acc[tn][tm], wf[tn], xf[tm]);
-#if MSFWSI_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
     };
 
@@ -1062,14 +1050,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         // transposed reads draining the pipeline every slab (common.h, lds_dma16_buf): a request issued before the MFMAs
         // then only delayed them.  With the requests in inline asm two slabs really are in flight, and requests first is
         // the faster order again (whole step 547.5 -> 545.3 ms, A/B on one box, two rounds).
-#if MSFWSI_STAGGER
-        // waves w and w + NW/2 share a SIMD and would run in lockstep (same program, one barrier per slab): the first half
-        // requests before its MFMAs, the second half after -- one partner's request stalls beside the other's MFMAs
-        const bool late = wave >= (Cfg::NW / 2);
-        if (!late && kt + 2 < nk) fetch(st_f);
-        compute(st_c);
-        if (late && kt + 2 < nk) fetch(st_f);
-#elif MSFWSI_FETCH_FIRST
+#if MSFWSI_FETCH_FIRST
         if (kt + 2 < nk) fetch(st_f);
         compute(st_c);
 #else
@@ -1083,7 +1064,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
     igemm_epilogue<T, BM, BN, WM, WN, DGRAD, false, EPI>(acc, prm, smem, tile_m, m0, n0);
 }
 
-long g_fast_dma = 1;  // tunable through msfwsi_set_tuning(1, .): 0 = always the generic kernel
+msfwsi_tunable g_fast_dma{1};  // tunable through msfwsi_set_tuning(1, .): 0 = always the generic kernel
 
 template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, bool APRO>
 int launch_igemm(IgemmParams& prm, hipStream_t stream) {
@@ -1128,9 +1109,9 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
     return msfwsi_launch_status();
 }
 
-long g_s2_parity = 1;               // key 5: stride-2 3x3 input gradients by output-pixel parity (0 = one masked launch)
-long g_big_tile_min_blocks = 1024;  // tunable through msfwsi_set_tuning
-long g_small_grid_blocks = 100;     // key 4: 128x128 grids below this use 128x64 tiles (measured: helps <= 72 tiles, hurts at 144+)
+msfwsi_tunable g_s2_parity{1};               // key 5: stride-2 3x3 input gradients by output-pixel parity (0 = one masked launch)
+msfwsi_tunable g_big_tile_min_blocks{1024};  // tunable through msfwsi_set_tuning
+msfwsi_tunable g_small_grid_blocks{100};     // key 4: 128x128 grids below this use 128x64 tiles (measured: helps <= 72 tiles, hurts at 144+)
 
 template <typename T, bool DGRAD, bool APRO>
 int dispatch_tile(IgemmParams& prm, hipStream_t stream) {
@@ -1165,80 +1146,53 @@ int check_desc(const msfwsi_conv_desc* d) {
 
 }  // namespace
 
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_c3_set_stationary(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_os_min(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_patch(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_max_splits(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_pool_bwd_set_walk(long v);
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_panel_set_hand(long v);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_lin(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_big(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_c3_set_stationary(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_os(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_os_min(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_stem_set_ws(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_stem_set_os_min(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_max_splits(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_pool_bwd_set_walk(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_panel_set_hand(long v, int write);
+
+namespace {
+long own_tunable(msfwsi_tunable& g, long v, int write) {
+    const long old = g;
+    if (write) g = v;
+    return old;
+}
+// the switch behind `key`: its value before the call in *old, rewritten when `write`; false for an unknown key
+bool tuning_access(int key, long v, int write, long* old) {
+    switch (key) {
+        case 0: *old = own_tunable(g_big_tile_min_blocks, v, write); return true;
+        case 1: *old = own_tunable(g_fast_dma, v, write); return true;
+        case 2: *old = msfwsi_wgrad_set_lin(v, write); return true;
+        case 4: *old = own_tunable(g_small_grid_blocks, v, write); return true;
+        case 5: *old = own_tunable(g_s2_parity, v, write); return true;
+        case 6: *old = msfwsi_wgrad_set_big(v, write); return true;
+        case 9: *old = msfwsi_c3_set_stationary(v, write); return true;
+        case 10: *old = msfwsi_wgrad_set_os(v, write); return true;
+        case 11: *old = msfwsi_wgrad_set_os_min(v, write); return true;
+        case 12: *old = msfwsi_stem_set_ws(v, write); return true;
+        case 13: *old = msfwsi_stem_set_os_min(v, write); return true;
+        case 15: *old = msfwsi_wgrad_set_max_splits(v, write); return true;
+        case 16: *old = msfwsi_pool_bwd_set_walk(v, write); return true;
+        case 17: *old = msfwsi_panel_set_hand(v, write); return true;
+    }
+    return false;
+}
+}  // namespace
 
 extern "C" int msfwsi_set_tuning(int key, long value) {
-    if (key == 2) {
-        msfwsi_wgrad_set_lin(value);
-        return MSFWSI_OK;
-    }
-    if (key == 6) {
-        msfwsi_wgrad_set_big(value);
-        return MSFWSI_OK;
-    }
-    if (key == 9) {
-        msfwsi_c3_set_stationary(value);
-        return MSFWSI_OK;
-    }
-    if (key == 10) {
-        msfwsi_wgrad_set_os(value);
-        return MSFWSI_OK;
-    }
-    if (key == 11) {
-        msfwsi_wgrad_set_os_min(value);
-        return MSFWSI_OK;
-    }
-    if (key == 12) {
-        msfwsi_stem_set_ws(value);
-        return MSFWSI_OK;
-    }
-    if (key == 13) {
-        msfwsi_stem_set_os_min(value);
-        return MSFWSI_OK;
-    }
-    if (key == 14) {
-        msfwsi_pool_bwd_set_patch(value);
-        return MSFWSI_OK;
-    }
-    if (key == 15) {
-        msfwsi_wgrad_set_max_splits(value);
-        return MSFWSI_OK;
-    }
-    if (key == 16) {
-        msfwsi_pool_bwd_set_walk(value);
-        return MSFWSI_OK;
-    }
-    if (key == 17) {
-        msfwsi_panel_set_hand(value);
-        return MSFWSI_OK;
-    }
-    if (key == 4) {
-        g_small_grid_blocks = value;
-        return MSFWSI_OK;
-    }
-    if (key == 5) {
-        g_s2_parity = value;
-        return MSFWSI_OK;
-    }
-    if (key == 0) {
-        g_big_tile_min_blocks = value;
-        return MSFWSI_OK;
-    }
-    if (key == 1) {
-        g_fast_dma = value;
-        return MSFWSI_OK;
-    }
-    return MSFWSI_EINVAL;
+    long old;
+    return tuning_access(key, value, 1, &old) ? MSFWSI_OK : MSFWSI_EINVAL;
+}
+
+extern "C" int msfwsi_get_tuning(int key, long* value) {
+    MSFWSI_CHECK_ARG(value != nullptr);
+    return tuning_access(key, 0, 0, value) ? MSFWSI_OK : MSFWSI_EINVAL;
 }
 
 extern "C" int msfwsi_conv_fwd(const msfwsi_conv_desc* d, const void* x, const void* w, void* y,

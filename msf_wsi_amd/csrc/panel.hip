@@ -675,7 +675,7 @@ __global__ void panel_pack_kernel(const T* __restrict__ w, T* __restrict__ wpk, 
     wpk[i] = w[n * stride_n + k * stride_k];
 }
 
-long g_panel_hand = 1;  // msfwsi_set_tuning(17, .): 0 = every launch on hipcc's own waits (the A/B reference of the hand-counted ones)
+msfwsi_tunable g_panel_hand{1};  // msfwsi_set_tuning(17, .): 0 = every launch on hipcc's own waits (the A/B reference of the hand-counted ones)
 
 template <typename T, int K, int BM, int PRO, int EPI>
 int launch_panel(const PanelParams& prm, hipStream_t stream) {
@@ -720,7 +720,11 @@ bool is_1x1(const msfwsi_conv_desc* d) {
 
 }  // namespace
 
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_panel_set_hand(long v) { g_panel_hand = v; }
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_panel_set_hand(long v, int write) {
+    const long old = g_panel_hand;
+    if (write) g_panel_hand = v;
+    return old;
+}
 
 extern "C" int msfwsi_panel_supported(const msfwsi_conv_desc* d, int dgrad) {
     if (!is_1x1(d)) return 0;

@@ -513,8 +513,8 @@ int launch_stem_wgrad(StemWgParams& prm, hipStream_t stream) {
     return msfwsi_launch_status();
 }
 
-long g_stem_ws = 1;  // msfwsi_set_tuning(12, .): 0 = the stem on the gather kernel
-long g_stem_os_min_pos = 32L * 512 * 256;  // msfwsi_set_tuning(13, .): smallest padded raster the weight-gradient kernel takes
+msfwsi_tunable g_stem_ws{1};  // msfwsi_set_tuning(12, .): 0 = the stem on the gather kernel
+msfwsi_tunable g_stem_os_min_pos{32L * 512 * 256};  // msfwsi_set_tuning(13, .): smallest padded raster the weight-gradient kernel takes
 
 template <typename T>
 int launch_stem_ws(StemParams& prm, hipStream_t stream) {
@@ -542,7 +542,11 @@ int launch_stem_ws(StemParams& prm, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_ws(long v) { g_stem_ws = v; }
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_stem_set_ws(long v, int write) {
+    const long old = g_stem_ws;
+    if (write) g_stem_ws = v;
+    return old;
+}
 
 // weight gradient of the space-to-depth stem on the output-stationary kernel; MSFWSI_EUNSUPPORTED where it does not
 // apply (msfwsi_conv_wgrad then takes the gather kernel).  From ~32 chunks per workgroup (16 384 atomics each at the end).
@@ -565,7 +569,11 @@ extern "C" __attribute__((visibility("hidden"))) int msfwsi_stem_os_wgrad(const 
     if (d->dtype == MSFWSI_DT_BF16) return launch_stem_wgrad<__bf16>(prm, st);
     return launch_stem_wgrad<_Float16>(prm, st);
 }
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_stem_set_os_min(long v) { g_stem_os_min_pos = v; }
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_stem_set_os_min(long v, int write) {
+    const long old = g_stem_os_min_pos;
+    if (write) g_stem_os_min_pos = v;
+    return old;
+}
 
 // the space-to-depth stem on the weights-stationary kernel; MSFWSI_EUNSUPPORTED where it does not apply (the caller,
 // msfwsi_stem_conv_fwd, then takes the gather kernel)

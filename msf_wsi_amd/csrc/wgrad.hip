@@ -17,9 +17,6 @@
 #include "common.h"
 #include "../../include/msfwsi_hip.h"
 
-#ifndef MSFWSI_STAGGER
-#define MSFWSI_STAGGER 0
-#endif
 #ifndef MSFWSI_WGRAD_BIG_WAVES
 #define MSFWSI_WGRAD_BIG_WAVES 16  // waves of the 256 x 256 tile (8: 128 x 64 per wave, 16: 64 x 64)
 #endif
@@ -380,12 +377,7 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
             // DMA requests of slab kt+NST-1 (its stage was read in kt-1, every wave is past this iteration's barrier) and the
             // MFMAs of slab kt: requests first since the DMA is issued from inline asm (see igemm.hip's main loop and
             // common.h lds_dma16_buf; round 2's "MFMAs first" belonged to the drained pipeline)
-#if MSFWSI_STAGGER
-            const bool late = wave >= (Cfg::NW / 2);  // see igemm.hip: SIMD partners alternate request / MFMA phases
-            if (!late && kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
-            compute(st_c);
-            if (late && kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
-#elif MSFWSI_FETCH_FIRST
+#if MSFWSI_FETCH_FIRST
             if (kt + AHEAD < nk) fetch(mbeg + (kt + AHEAD) * BKM, st_f);
             compute(st_c);
 #else
@@ -653,8 +645,8 @@ __global__ __launch_bounds__(512) void wgrad_os_kernel(const WgWParams prm) {
     if (extra) flush(acc[4], 8, xcb, xib);
 }
 
-long g_wgrad_os = 1;  // msfwsi_set_tuning(10, .): 0 = the 64 -> 64 3x3 weight gradient on the gather kernel
-long g_wgrad_os_min_pos = 32L * 256 * 256;  // msfwsi_set_tuning(11, .): smallest padded raster the kernel takes
+msfwsi_tunable g_wgrad_os{1};  // msfwsi_set_tuning(10, .): 0 = the 64 -> 64 3x3 weight gradient on the gather kernel
+msfwsi_tunable g_wgrad_os_min_pos{32L * 256 * 256};  // msfwsi_set_tuning(11, .): smallest padded raster the kernel takes
 
 bool wgrad_os_ok(const msfwsi_conv_desc* d) {
     return g_wgrad_os && d->dtype != MSFWSI_DT_F32 && d->C == 64 && d->K == 64 && d->R == 3 && d->S == 3 &&
@@ -694,12 +686,12 @@ int launch_wgrad_os(const msfwsi_conv_desc* d, const void* x, const void* dy, fl
     return msfwsi_launch_status();
 }
 
-long g_wgrad_lin = 1;  // msfwsi_set_tuning(2, .): 0 = always the generic staging
+msfwsi_tunable g_wgrad_lin{1};  // msfwsi_set_tuning(2, .): 0 = always the generic staging
 // msfwsi_set_tuning(15, .): cap on the pixel splits of the gather weight-gradient kernel (0 = none).  With 1 every
 // gradient tile is summed by ONE workgroup in pixel order: the step is then reproducible bit for bit (the splits add
 // their partial sums with fp32 atomics in arrival order, 4e-7 jitter per tensor) -- what a chaotic 30-step test needs
-long g_wgrad_max_splits = 0;
-long g_wgrad_big = 1;  // msfwsi_set_tuning(6, .): 0 = never the 256 x 256 tile
+msfwsi_tunable g_wgrad_max_splits{0};
+msfwsi_tunable g_wgrad_big{1};  // msfwsi_set_tuning(6, .): 0 = never the 256 x 256 tile
 
 // workgroups of `kern` that fit the device at once (all splits carry equal work, so a grid that overshoots this by
 // one workgroup costs a whole second round: measured 0.75 vs 0.56 ms for 1025 vs 1020 workgroups)
@@ -782,11 +774,31 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_lin(long v) { g_wgrad_lin = v; }
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_max_splits(long v) { g_wgrad_max_splits = v; }
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_big(long v) { g_wgrad_big = v; }
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os(long v) { g_wgrad_os = v; }
-extern "C" __attribute__((visibility("hidden"))) void msfwsi_wgrad_set_os_min(long v) { g_wgrad_os_min_pos = v; }
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_lin(long v, int write) {
+    const long old = g_wgrad_lin;
+    if (write) g_wgrad_lin = v;
+    return old;
+}
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_max_splits(long v, int write) {
+    const long old = g_wgrad_max_splits;
+    if (write) g_wgrad_max_splits = v;
+    return old;
+}
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_big(long v, int write) {
+    const long old = g_wgrad_big;
+    if (write) g_wgrad_big = v;
+    return old;
+}
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_os(long v, int write) {
+    const long old = g_wgrad_os;
+    if (write) g_wgrad_os = v;
+    return old;
+}
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_os_min(long v, int write) {
+    const long old = g_wgrad_os_min_pos;
+    if (write) g_wgrad_os_min_pos = v;
+    return old;
+}
 
 // 1 if msfwsi_conv_wgrad serves this geometry with the output-stationary kernel (whose BatchNorm+ReLU prologue is free:
 // callers then pass pro_scale / pro_shift instead of materialising the activation)

@@ -335,7 +335,6 @@ class Engine:
         self.store_head_wgrad = os.environ.get("MSFWSI_STORE_HEAD_WGRAD", "1") != "0"
         # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
         # stem_pool_bwd + bn_bwd_apply (the pool-backward window logic is VALU-bound, not byte-bound): off
-        self.stem_two_pass = os.environ.get("MSFWSI_STEM_TWO_PASS", "0") != "0"
         self.fold_ds = os.environ.get("MSFWSI_FOLD_DS", "1") != "0"  # stride-1 downsample branch folded like bn3
         self.fold_ds_fwd = os.environ.get("MSFWSI_FOLD_DS_FWD", "1") != "0"  # ... and its forward: one two-source GEMM
         self.fold_ds_strided = os.environ.get("MSFWSI_FOLD_DS_STRIDED", "1") != "0"  # ... also for the stride-2 branches
@@ -377,17 +376,6 @@ class Engine:
         # (different encoder, different parameters: no ordering between them and the target passes).  Needs the
         # memory calibration of an earlier step of the same shape (`_calib`).  MSFWSI_CTX_STREAM=0 turns it off.
         self.ctx_stream = os.environ.get("MSFWSI_CTX_STREAM", "1") != "0"
-        # STAGGER of the two target streams.  Two passes that start together run the same layer at the same time: both
-        # HBM-bound in layer1-2, both MFMA-bound in layer3-4 -- the streams share a bottleneck instead of complementing
-        # each other.  With the stagger view 1 starts when view 0 has finished stage `stagger_fwd` of its forward (its
-        # backward: when view 0's backward has come down through stage `stagger_bwd`), so one stream's MFMA-bound deep
-        # layers run beside the other's HBM-bound shallow ones.  -1 = start together.  MSFWSI_STAGGER="f,b".
-        # OFF by default: measured (A/B on one box, two rounds, profiles/r04_ab_stagger.txt) 518.3 / 517.0 ms with "1,2",
-        # 514.0 / 515.0 with "0,3", 521.8 / 523.8 with "2,1", 513.6 / 512.3 with "-1,2" against 516.2 / 513.2 without: what
-        # the complementary middle gains, the head and tail where one stream runs alone lose again.
-        st = os.environ.get("MSFWSI_STAGGER", "-1,-1").split(",")
-        self.stagger_fwd, self.stagger_bwd = int(st[0]), int(st[1] if len(st) > 1 else st[0])
-        self._stage_mark: Optional[tuple] = None
         self._calib: Dict[tuple, Tuple[float, float]] = {}
         self._side: Dict[str, torch.cuda.Stream] = {}
         self._bn_order: Optional[Tuple[str, dict]] = None
@@ -1062,9 +1050,6 @@ class Engine:
             f = torch.empty(N, y.shape[-1], dtype=dtype, device=x.device)
             kn.gap_fwd(y, f, N, h * w, y.shape[-1])
             feats.append(f)
-            mark = self._stage_mark
-            if mark is not None and mark[0] == "fwd" and mark[1] == si:  # see Engine.stagger
-                mark[2].record(torch.cuda.current_stream(x.device))
         if not save:
             return EncPass(enc, N, H, W, None, None, None, None, [], feats, x_src=x, saved=False)
         return EncPass(enc, N, H, W, xin, stem, pooled, amax, blocks, feats)
@@ -1202,10 +1187,6 @@ class Engine:
             dy, pre = self._block_bwd(rec, dy, gapg, grads, dtype, pre=pre, gate=gate)
             rec.units = []  # release activations
             rec.ds = None
-            mark = self._stage_mark
-            if (mark is not None and mark[0] == "bwd" and mark[1] == rec.stage
-                    and (i == 0 or ps.blocks[i - 1].stage != rec.stage)):  # the first block of that stage is done
-                mark[2].record(torch.cuda.current_stream(dy.device))
         self._stem_bwd(ps, dy, grads, dtype, dstem)
 
     def _stem_bwd(self, ps: EncPass, dy: torch.Tensor, grads: GradStore, dtype: torch.dtype,
@@ -1214,25 +1195,18 @@ class Engine:
         of the max-pool output [N,P,Q,64]"""
         st, u = ps.stem.st, ps.stem
         H0, W0 = u.desc.P, u.desc.Q
-        # two passes over (dy, argmax, c): sums first, then dc0 = k1*g + k2*c0 + k3 with g re-derived on the fly (the
-        # gated gradient g itself is never written: -2 passes over the largest tensor of the network)
         sums = kn.new_stats(64, 2, u.c.device)
         g0 = torch.empty_like(u.c)
-        if self.stem_two_pass and dstem is None:
-            kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, None, sums, ps.N, H0, W0, 64)
-            k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
-            kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, None, ps.N, H0, W0, 64, k=(k[0], k[1], k[2]))
-        else:
-            kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, sums, ps.N, H0, W0, 64, dact=dstem)
-            k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
-            if u.s2d and self.stem_fuse_bnbwd:
-                # dc0 = k1*g + k2*c0 + k3 formed inside the weight-gradient kernel's staging: the 6.6 GB gradient is
-                # neither rewritten nor re-read (-13 GB per target pass)
-                dw2 = kn.zeros((u.desc.K, 4, 4, 16), torch.float32, g0.device)
-                if kn.stem_wgrad_bnbwd(u.desc, u.x, g0, u.c, (k[0], k[1], k[2]), dw2):
-                    kn.stem_s2d_wfold(dw2, grads.get(u.op.weight))
-                    return
-            kn.bn_bwd_apply(g0, u.c, k[0], k[1], k[2], g0)
+        kn.stem_pool_bwd(dy, ps.amax, u.c, st.scale, st.shift, g0, sums, ps.N, H0, W0, 64, dact=dstem)
+        k = self._bn_bwd_coeffs(sums, 2, 1, u.bn, st, grads)
+        if u.s2d and self.stem_fuse_bnbwd:
+            # dc0 = k1*g + k2*c0 + k3 formed inside the weight-gradient kernel's staging: the 6.6 GB gradient is
+            # neither rewritten nor re-read (-13 GB per target pass)
+            dw2 = kn.zeros((u.desc.K, 4, 4, 16), torch.float32, g0.device)
+            if kn.stem_wgrad_bnbwd(u.desc, u.x, g0, u.c, (k[0], k[1], k[2]), dw2):
+                kn.stem_s2d_wfold(dw2, grads.get(u.op.weight))
+                return
+        kn.bn_bwd_apply(g0, u.c, k[0], k[1], k[2], g0)
         self._unit_wgrad(u, g0, grads, dtype)
 
     def _foldable(self, rec: BlockRec) -> bool:
@@ -1788,14 +1762,7 @@ class Engine:
                         self._bn_order = ("follow", ev_c)
                         rec.enc["c1"] = self.encoder_forward(model.context_encoder, x2[0], dtype, save="c1" not in nosave)
                 self._bn_order = ("lead", ev_t)
-                go = torch.cuda.Event() if 0 <= self.stagger_fwd < 3 else None
-                self._stage_mark = ("fwd", self.stagger_fwd, go) if go is not None else None
-                try:
-                    rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
-                finally:
-                    self._stage_mark = None
-                if go is not None:
-                    side.wait_event(go)  # view 1 starts when view 0 has left the HBM-bound stages (Engine.stagger)
+                rec.enc["t0"] = self.encoder_forward(model.target_encoder, x1[1], dtype, save="t0" not in nosave)
                 with torch.cuda.stream(side):
                     self._bn_order = ("follow", ev_t)
                     rec.enc["t1"] = self.encoder_forward(model.target_encoder, x2[1], dtype, save="t1" not in nosave)
@@ -1903,29 +1870,16 @@ class Engine:
         tri = dual and rec.tri
         third = self._side_stream(dev, "ctx") if tri else None
 
-        go_b = torch.cuda.Event() if (dual and 0 < self.stagger_bwd <= 3) else None
-
         def run(name, df):
             st = third if (tri and name.startswith("c")) else (side if dual and name.endswith("1") else None)
             if st is not None:
                 for d in df:
                     if d is not None:
                         d.record_stream(st)
-                if st is side and go_b is not None and go_b_set[0]:
-                    side.wait_event(go_b)  # view 1's backward starts when view 0's has come down to the shallow stages
                 with torch.cuda.stream(st):
                     self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
             else:
-                mark = go_b is not None and name == "t0" and rec.enc[name].saved
-                self._stage_mark = ("bwd", self.stagger_bwd, go_b) if mark else None
-                try:
-                    self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
-                finally:
-                    self._stage_mark = None
-                if mark:
-                    go_b_set[0] = True
-
-        go_b_set = [False]
+                self.encoder_backward(self._materialise(rec.enc.pop(name), dtype), df, grads, dtype)
 
         if dual:
             side.wait_stream(main)  # the heads' backward produced the feature gradients

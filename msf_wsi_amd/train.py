@@ -96,10 +96,6 @@ class FlatAdamScaler:
         """Adam's step count (host read-back: synchronises; used by checkpointing and tests only)"""
         return int(self.step_dev.item())
 
-    # index of an optimizer group whose Adam pass may run on a side stream UNDER THE NEXT STEP's encoder passes: nothing
-    # reads its weights before the heads (PretrainStep: the 1.58 B-parameter `inter_` group = 80 % of Adam's 47 GB)
-    late_group: Optional[int] = None
-
     def optimizer_step(self):
         found = None
         ls = None
@@ -109,72 +105,16 @@ class FlatAdamScaler:
                 kn.nonfinite_check(g, self.found_inf)
             found, ls = self.found_inf, self.scale
         kn.adam_step_advance(self.step_dev, found)
-        late = self.late_group if (self.late_group is not None and self._late_ok()) else None
         for gi in range(len(self.flats.w)):
-            if gi == late:
-                continue
             kn.adam(self.flats.w[gi], self.flats.g[gi], self.flats.m[gi], self.flats.v[gi], self.lrs[gi],
                     self.betas[0], self.betas[1], self.eps[gi], self.step_dev, loss_scale=ls, found=found,
                     p_lowp=self.flats.w16[gi])
-        if late is not None:
-            # the late group's Adam pass (+ the clear of its gradient buffer for the next step) on the optimizer stream:
-            # it has everything it reads (gradients, found-inf flag, step count, loss scale) once this point of the main
-            # stream is reached; the next step's first reader / writer of that group waits for `late_done`
-            # (wait_late: the heads of the forward; checkpoint / state readers)
-            main = torch.cuda.current_stream(self.device)
-            st = self._opt_stream()
-            late_ls = None
-            if ls is not None:  # its own copy of the loss scale: scaler_update below rewrites the original on the main stream
-                if self._late_ls is None:
-                    self._late_ls = torch.empty_like(self.scale)
-                    self._late_ls.record_stream(st)
-                self._late_ls.copy_(self.scale)
-                late_ls = self._late_ls
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                kn.adam(self.flats.w[late], self.flats.g[late], self.flats.m[late], self.flats.v[late], self.lrs[late],
-                        self.betas[0], self.betas[1], self.eps[late], self.step_dev, loss_scale=late_ls, found=found,
-                        p_lowp=self.flats.w16[late])
-                self.flats.zero_group(late)
-                self._late_event = torch.cuda.Event()
-                self._late_event.record(st)
-            self._late_cleared = True
         if self.use_scaler:
             kn.scaler_update(self.scale, self.growth_tracker, self.found_inf, self.growth_factor,
                              self.backoff_factor, self.growth_interval)
         # padded / cast copies (and the stem's filter-row runs) keyed on torch's version counter do not see
         # raw-pointer updates
         self.engine.invalidate_weights()
-
-    _late_event = None
-    _late_cleared = False
-    _late_ls = None
-    _opt_stream_obj = None
-
-    def _late_ok(self) -> bool:
-        """OFF by default: measured +-0 on BASELINE config 2 (509.7 / 509.7 ms with it, 511.2 / 508.9 without, A/B on one box,
-        profiles/r04_ab_adam_overlap.txt) -- the pass is HBM-bound and so is the stem of the next step it would hide
-        under.  MSFWSI_ADAM_OVERLAP=1 turns it on."""
-        import os
-
-        return os.environ.get("MSFWSI_ADAM_OVERLAP", "0") != "0"
-
-    def _opt_stream(self):
-        if self._opt_stream_obj is None:
-            self._opt_stream_obj = st = torch.cuda.Stream(device=self.device)
-            # buffers the optimizer stream touches: should their owner be dropped while a late pass is still running, the
-            # caching allocator must not hand the blocks to the main stream before that pass has finished
-            late = self.late_group
-            for t in (self.flats.w[late], self.flats.g[late], self.flats.m[late], self.flats.v[late], self.flats.w16[late],
-                      self.found_inf, self.step_dev, self.scale):
-                if t is not None:
-                    t.record_stream(st)
-        return self._opt_stream_obj
-
-    def wait_late(self):
-        """the calling stream waits for the late group's Adam pass of the previous step (no-op when there is none)"""
-        if self._late_event is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._late_event)
 
     # ---------------------------------------------------------------------------------------
     # checkpoint interop (reference dict layout)
@@ -276,13 +216,6 @@ class PretrainStep(FlatAdamScaler):
             grad_group = dist.new_group(backend=dist.get_backend())
         self.reducer = GradReducer(self.flats, grad_group)
         self._init_optimizer_state(use_scaler, init_scale)
-        # Adam of the `inter_` group (80 % of the optimizer's HBM traffic) runs on its own stream under the NEXT step's
-        # encoder passes: the heads are the first to read those weights (FlatAdamScaler.optimizer_step)
-        self.late_group = 2
-        self.engine.before_heads = self.wait_late
-        # whoever reads the parameters through the module API (state_dict: checkpoints, evaluation copies) on the current
-        # stream waits for that pass too; raw reads of flats.w need a device synchronisation or wait_late()
-        model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.wait_late())
         # epoch meter of ssl_train.py:421,467-468,483-486: [sum loss*bs, sum bs], kept on the device
         self.epoch_meter = torch.zeros(2, dtype=torch.float64, device=dev)
 
@@ -354,9 +287,7 @@ class PretrainStep(FlatAdamScaler):
         """one optimisation step; returns the (device-resident, fp64) loss of this minibatch"""
         bs = batch[0][0].shape[0]
         self.engine.reset_counters()
-        # (the late group's buffer was cleared by the optimizer stream right after its Adam pass of the previous step)
-        self.flats.zero_grads(skip_groups=(self.late_group,) if self._late_cleared else ())
-        self._late_cleared = False
+        self.flats.zero_grads()
         kn.ARENA.begin_step(self.device)  # one clear for all of this step's small zero-initialised accumulators
         try:
             outs, rec, dps = self.forward_loss(batch, want_grad=True)
@@ -384,7 +315,6 @@ class PretrainStep(FlatAdamScaler):
 
     def checkpoint(self, epoch: int) -> dict:
         """the dict the reference passes to save_checkpoint (ssl_train.py:375-386); DDP's "module." prefix kept"""
-        self.wait_late()
         sd = {"module." + k: v.detach().clone() for k, v in self.model.state_dict().items()}
         return {"epoch": epoch + 1, "arch": self.arch, "state_dict": sd, "optimizer": self.optimizer_state_dict(),
                 "scaler": self.scaler_state_dict()}
@@ -394,7 +324,6 @@ class PretrainStep(FlatAdamScaler):
 
     def resume(self, ckpt: dict) -> int:
         """ssl_train.py:313-335 incl. the hard-coded eps=0.1 after loading"""
-        self.wait_late()
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt["state_dict"].items()}
         self.model.load_state_dict(sd)  # copies into the flat-buffer views in place
         self.load_optimizer_state_dict(ckpt["optimizer"])

@@ -147,8 +147,7 @@ def reproducible_sums(hip_lib):
     on the next.  With the cap every value of the step repeats bit for bit, so these tests have one outcome per build.
     The kernel-level tests (test_kernels_gpu, test_production_gpu, test_train_gpu, ...) keep the default split-K path, and
     test_lowp_parity_gpu.py::test_default_path_* gate the DEFAULT configuration three runs in a row."""
-    hip_lib.msfwsi_set_tuning(15, 1)
-    try:
+    from helpers import tuned
+
+    with tuned(hip_lib, {15: 1}):
         yield
-    finally:
-        hip_lib.msfwsi_set_tuning(15, 0)

@@ -307,3 +307,24 @@ def lowp_gate(rels, names, ref_spread, floor, what, max_violations=0.05):
     if over.any():
         assert float(rels[over].max()) <= max(floor, 2.0 * float(ref.max())), (what, names[int(rels.argmax())])
     return rels
+
+
+import contextlib
+import ctypes
+
+
+@contextlib.contextmanager
+def tuned(lib, settings):
+    """msfwsi_set_tuning(key, value) for every (key, value) of `settings`, and on exit EXACTLY the values the switches had
+    before (msfwsi_get_tuning): a fixture cannot leave the process-global switches in another state than it found them"""
+    saved = {}
+    try:
+        for key, value in settings.items():
+            old = ctypes.c_long()
+            assert lib.msfwsi_get_tuning(int(key), ctypes.byref(old)) == 0, f"unknown tuning key {key}"
+            saved[key] = old.value
+            assert lib.msfwsi_set_tuning(int(key), int(value)) == 0
+        yield
+    finally:
+        for key, value in saved.items():
+            assert lib.msfwsi_set_tuning(int(key), int(value)) == 0

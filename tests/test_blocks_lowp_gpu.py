@@ -39,15 +39,10 @@ IDS = ["bf16", "fp16"]
 @pytest.fixture
 def stationary_forced(hip_lib):
     """the shape-specialised persistent kernels take the small test shapes too (size gates lifted)"""
-    for key in (9, 10, 12):
-        hip_lib.msfwsi_set_tuning(key, 1)
-    hip_lib.msfwsi_set_tuning(11, 0)
-    hip_lib.msfwsi_set_tuning(13, 0)
-    try:
+    from helpers import tuned
+
+    with tuned(hip_lib, {9: 1, 10: 1, 12: 1, 11: 0, 13: 0}):
         yield
-    finally:
-        hip_lib.msfwsi_set_tuning(11, 32 * 256 * 256)
-        hip_lib.msfwsi_set_tuning(13, 32 * 512 * 256)
 
 
 def _encoder(arch, gain=0.1):

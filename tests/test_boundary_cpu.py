@@ -114,3 +114,17 @@ def test_pretrained_offline_dir(tmp_path, monkeypatch):
     got = resnet.resnet18(pretrained=True)
     for (k, a), (_, b) in zip(ref.state_dict().items(), got.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_panel_hand_counted_waits_audit():
+    """static audit of the panel kernels' hand-counted `s_waitcnt vmcnt(N)` (tools/check_hand_waits.py): in hipcc's
+    assembly of csrc/panel.hip every asm load is followed by at least N younger vector-memory operations before the wait that
+    covers its first reader, and hipcc has put no wait, load or scratch access of its own into those loops"""
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "check_hand_waits.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 findings" in r.stdout

@@ -503,16 +503,13 @@ def test_residual_block_end(hip_lib, dt):
 @pytest.fixture
 def pool_bwd_kernel(request, hip_lib):
     """which max-pool backward kernel msfwsi_stem_pool_bwd dispatches to: "walk" = the column walk (default,
-    msfwsi_set_tuning(16, 1)), "pixel" = one thread per pixel (16 -> 0), "patch" = 2x2 input patches (16 -> 0, 14 -> 1;
-    off by default, kept as an A/B reference: one geometry only)"""
-    hip_lib.msfwsi_set_tuning(16, 1 if request.param == "walk" else 0)
-    hip_lib.msfwsi_set_tuning(14, 1 if request.param == "patch" else 0)
+    msfwsi_set_tuning(16, 1)), "pixel" = one thread per pixel (16 -> 0)"""
+    assert hip_lib.msfwsi_set_tuning(16, 1 if request.param == "walk" else 0) == 0
     yield request.param
-    hip_lib.msfwsi_set_tuning(16, 1)
-    hip_lib.msfwsi_set_tuning(14, 0)
+    assert hip_lib.msfwsi_set_tuning(16, 1) == 0
 
 
-POOL_CASES = [(k, hw) for k in ("walk", "pixel") for hw in ((16, 16), (15, 13), (14, 17), (34, 70))] + [("patch", (15, 13))]
+POOL_CASES = [(k, hw) for k in ("walk", "pixel") for hw in ((16, 16), (15, 13), (14, 17), (34, 70))]
 
 
 @pytest.mark.parametrize("pool_bwd_kernel,hw", POOL_CASES, indirect=["pool_bwd_kernel"],
