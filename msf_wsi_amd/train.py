@@ -16,6 +16,7 @@ the reference's quirk of forcing eps=0.1 afterwards (:325-326).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -96,25 +97,78 @@ class FlatAdamScaler:
         """Adam's step count (host read-back: synchronises; used by checkpointing and tests only)"""
         return int(self.step_dev.item())
 
+    # optimizer groups whose fp32 master weights no kernel of a step reads (only Adam and state_dict do): after a SHARDED
+    # step their 16-bit compute copy alone is all-gathered; the masters of the other ranks' shards are fetched on demand
+    # (sync_master_weights: checkpoints, state_dict).  PretrainStep: the `inter_` heads, 95 % of the parameters.
+    lazy_master_groups: Tuple[int, ...] = ()
+    _master_stale = False
+    _last_scattered: Optional[dict] = None
+
     def optimizer_step(self):
+        """GradScaler's inf check + unscale, Adam, scaler update (ssl_train.py:473-474).  With a sharding reducer
+        (dist.GradReducer(shard=True)): the check and Adam run on this rank's shard of every bucket, then the updated
+        weights are all-gathered -- the fp32 masters where kernels read them, the 16-bit copy alone for lazy_master_groups."""
+        reducer = getattr(self, "reducer", None)
+        sharded = reducer is not None and reducer.sharding
+        owned = scattered = None
+        if sharded:
+            owned, scattered = reducer.take_shards()
+        ngroups = len(self.flats.w)
+
+        def ranges(gi):  # element ranges of group gi this rank steps
+            return owned.get(gi, []) if sharded else [(0, self.flats.w[gi].numel())]
+
         found = None
         ls = None
         if self.use_scaler:
             self.found_inf.zero_()
-            for g in self.flats.g:
-                kn.nonfinite_check(g, self.found_inf)
+            for gi in range(ngroups):
+                for lo, hi in ranges(gi):
+                    kn.nonfinite_check(self.flats.g[gi][lo:hi], self.found_inf)
+            if sharded:  # every rank must take the same skip / step decision
+                import torch.distributed as dist
+
+                dist.all_reduce(self.found_inf, op=dist.ReduceOp.MAX, group=reducer.group)
             found, ls = self.found_inf, self.scale
         kn.adam_step_advance(self.step_dev, found)
-        for gi in range(len(self.flats.w)):
-            kn.adam(self.flats.w[gi], self.flats.g[gi], self.flats.m[gi], self.flats.v[gi], self.lrs[gi],
-                    self.betas[0], self.betas[1], self.eps[gi], self.step_dev, loss_scale=ls, found=found,
-                    p_lowp=self.flats.w16[gi])
+        for gi in range(ngroups):
+            w16 = self.flats.w16[gi]
+            for lo, hi in ranges(gi):
+                if hi > lo:
+                    kn.adam(self.flats.w[gi][lo:hi], self.flats.g[gi][lo:hi], self.flats.m[gi][lo:hi], self.flats.v[gi][lo:hi],
+                            self.lrs[gi], self.betas[0], self.betas[1], self.eps[gi], self.step_dev, loss_scale=ls,
+                            found=found, p_lowp=w16[lo:hi] if w16 is not None else None)
+        if sharded:
+            works = []
+            for gi in range(ngroups):
+                sc = scattered.get(gi, [])
+                w16 = self.flats.w16[gi]
+                lazy = gi in self.lazy_master_groups and w16 is not None
+                if w16 is not None:
+                    works += reducer.gather_weights(gi, sc, w16)
+                if not lazy:
+                    works += reducer.gather_weights(gi, sc, self.flats.w[gi])
+            for wk in works:
+                wk.wait()
+            self._last_scattered = scattered
+            self._master_stale = any(gi in self.lazy_master_groups and self.flats.w16[gi] is not None for gi in range(ngroups))
         if self.use_scaler:
             kn.scaler_update(self.scale, self.growth_tracker, self.found_inf, self.growth_factor,
                              self.backoff_factor, self.growth_interval)
         # padded / cast copies (and the stem's filter-row runs) keyed on torch's version counter do not see
         # raw-pointer updates
         self.engine.invalidate_weights()
+
+    def sync_master_weights(self):
+        """after sharded steps: fetch the other ranks' shards of the fp32 master weights of lazy_master_groups (their Adam
+        moments stay sharded: optimizer_state_dict gathers them).  COLLECTIVE: every rank must call it (checkpoint, resume and
+        the state_dict hook do)."""
+        if not self._master_stale:
+            return
+        for gi in self.lazy_master_groups:
+            for wk in self.reducer.gather_weights(gi, self._last_scattered.get(gi, []), self.flats.w[gi]):
+                wk.wait()
+        self._master_stale = False
 
     # ---------------------------------------------------------------------------------------
     # checkpoint interop (reference dict layout)
@@ -124,6 +178,13 @@ class FlatAdamScaler:
         return torch.optim.Adam(groups, lr=self.init_lr)
 
     def optimizer_state_dict(self) -> dict:
+        reducer = getattr(self, "reducer", None)
+        if reducer is not None and reducer.sharding and self._last_scattered is not None:
+            # sharded steps leave each rank with the moments of its own shards: gather them (collective, like checkpoint())
+            for gi in range(len(self.flats.w)):
+                for buf in (self.flats.m[gi], self.flats.v[gi]):
+                    for wk in reducer.gather_weights(gi, self._last_scattered.get(gi, []), buf):
+                        wk.wait()
         opt = self._torch_adam()
         t = self.t
         if t > 0:
@@ -172,7 +233,11 @@ class PretrainStep(FlatAdamScaler):
     def __init__(self, model: nn.Module, lr: float = 1e-3, global_batch: int = 32, ms_lr: Sequence[float] = (1, 1, 1),
                  fuser_weights: Sequence[float] = FUSER_WEIGHTS, dtype: torch.dtype = torch.bfloat16,
                  use_scaler: Optional[bool] = None, init_scale: float = 65536.0, process_group=None,
-                 sync_bn: bool = True, arch: str = "resnet18", loss: str = "cosine", temperature: float = 0.2):
+                 sync_bn: bool = True, arch: str = "resnet18", loss: str = "cosine", temperature: float = 0.2,
+                 shard_optimizer: Optional[bool] = None):
+        """shard_optimizer (None: on with more than one rank unless MSFWSI_SHARD_OPT=0): gradients are reduce-scattered, each
+        rank runs Adam on 1/world of every bucket and the updated weights are all-gathered (fp32 masters of the encoders,
+        the 16-bit copy alone for the `inter_` heads) -- checkpoint() / resume() are then COLLECTIVE calls."""
         _lib.load()
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -214,8 +279,19 @@ class PretrainStep(FlatAdamScaler):
                 raise _lib.MsfwsiHipError("MSFWSI_FORCE_SYNC needs an initialised process group")
 
             grad_group = dist.new_group(backend=dist.get_backend())
-        self.reducer = GradReducer(self.flats, grad_group)
+        if shard_optimizer is None:
+            shard_optimizer = os.environ.get("MSFWSI_SHARD_OPT", "1") != "0"
+        self.reducer = GradReducer(self.flats, grad_group, shard=bool(shard_optimizer))
+        if dtype != torch.float32:
+            self.lazy_master_groups = (2,)  # the `inter_` heads: kernels read their 16-bit copy only
         self._init_optimizer_state(use_scaler, init_scale)
+
+        def _state_dict_guard(module, prefix, keep_vars):
+            if self._master_stale:
+                raise RuntimeError("state_dict() after sharded optimizer steps: the fp32 master weights of the `inter_` heads "
+                                   "are current only on their owning ranks -- call PretrainStep.sync_master_weights() (or "
+                                   "checkpoint()) on EVERY rank first")
+        model.register_state_dict_pre_hook(_state_dict_guard)
         # epoch meter of ssl_train.py:421,467-468,483-486: [sum loss*bs, sum bs], kept on the device
         self.epoch_meter = torch.zeros(2, dtype=torch.float64, device=dev)
 
@@ -315,6 +391,7 @@ class PretrainStep(FlatAdamScaler):
 
     def checkpoint(self, epoch: int) -> dict:
         """the dict the reference passes to save_checkpoint (ssl_train.py:375-386); DDP's "module." prefix kept"""
+        self.sync_master_weights()  # (sharded optimizer: a collective -- every rank calls checkpoint(), rank 0 saves)
         sd = {"module." + k: v.detach().clone() for k, v in self.model.state_dict().items()}
         return {"epoch": epoch + 1, "arch": self.arch, "state_dict": sd, "optimizer": self.optimizer_state_dict(),
                 "scaler": self.scaler_state_dict()}
@@ -324,6 +401,7 @@ class PretrainStep(FlatAdamScaler):
 
     def resume(self, ckpt: dict) -> int:
         """ssl_train.py:313-335 incl. the hard-coded eps=0.1 after loading"""
+        self._master_stale = False  # every master is about to be overwritten
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt["state_dict"].items()}
         self.model.load_state_dict(sd)  # copies into the flat-buffer views in place
         self.load_optimizer_state_dict(ckpt["optimizer"])

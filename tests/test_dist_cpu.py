@@ -295,3 +295,91 @@ def test_collective_recompute_plan_is_rank_invariant():
     assert ret[0] == ret[1], (ret[0], ret[1])
     assert [g[0] for g in ret[0]] == [("t1",)] * 4 and ret[0][0][1].startswith("recompute:t1")
     assert [g[2] for g in ret[0]] == [1, 1, 1, 2]  # one plan collective per shape, on both ranks alike
+
+
+def test_shard_bucket_partitions_every_bucket():
+    """the sharded optimizer's split of a gradient bucket (dist.shard_bucket): the ranks' shards and the common tail tile
+    [lo, hi) exactly once, shards start on 16-byte groups of fp32 (the Adam kernel's float4 steps), equal shard lengths
+    (reduce-scatter needs them), tail shorter than world * (align + 1)"""
+    from msf_wsi_amd.dist import shard_bucket
+
+    for world in (1, 2, 3, 4, 8):
+        for lo, n in ((0, 1), (64, 7), (128, 64), (0, 4097), (256, 18432 * 18432 // 64 + 5), (64, 1000003)):
+            hi = lo + n
+            cover = []
+            pers = set()
+            for r in range(world):
+                per, own, tail = shard_bucket(lo, hi, world, r)
+                pers.add(per)
+                assert per % 4 == 0 and own[1] - own[0] == per and (own[0] - lo) % 4 == 0
+                assert tail[1] == hi and tail[0] == lo + per * world and (tail[0] - lo) % 4 == 0
+                assert tail[1] - tail[0] < world * 5
+                if per:
+                    cover.append(own)
+            assert len(pers) == 1
+            cover.sort()
+            pos = lo
+            for a, b in cover:
+                assert a == pos
+                pos = b
+            assert pos == tail[0]
+
+
+def _shard_worker(rank, world, port, ret):
+    """the reducer's sharded exchange on CPU tensors over gloo: every rank ends with the MEAN gradient on the ranges it owns,
+    a stand-in update w -= g on those ranges followed by gather_weights leaves every rank with the weights of the unsharded
+    step, bit for bit"""
+    from msf_wsi_amd.dist import FlatGroups, GradReducer
+
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(5)
+        model = build_product("resnet18")
+        flats = FlatGroups(model, with_bf16=False, device="cpu")
+        w0 = [w.clone() for w in flats.w]
+        gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+        local = [[torch.randn(g.numel(), generator=gens[r]) for g in flats.g] for r in range(world)]  # every rank's gradients
+        mean = [sum(local[r][gi] for r in range(world)) / world for gi in range(len(flats.g))]
+        for gi, g in enumerate(flats.g):
+            g.copy_(local[rank][gi])
+        red = GradReducer(flats, None, shard=True)
+        assert red.sharding
+        # the trainer's order: the fuser heads' per-scale buckets, then what is left of the group, then the other groups
+        for part in ("inter_projector.3.", "inter_predictor.3.", "inter_projector.0."):
+            red.launch("inter", part=part)
+        red.launch("inter")
+        red.launch("target")
+        red.launch("context")
+        red.wait()
+        owned, scattered = red.take_shards()
+        covered = 0
+        for gi in range(len(flats.g)):
+            for lo, hi in owned.get(gi, []):
+                assert torch.equal(flats.g[gi][lo:hi], mean[gi][lo:hi]) or torch.allclose(flats.g[gi][lo:hi], mean[gi][lo:hi], rtol=0, atol=1e-6)
+                flats.w[gi][lo:hi] -= flats.g[gi][lo:hi]
+                covered += hi - lo
+        for gi in range(len(flats.g)):
+            for wk in red.gather_weights(gi, scattered.get(gi, []), flats.w[gi]):
+                wk.wait()
+        ret[f"w{rank}"] = [w.clone() for w in flats.w]
+        ret[f"covered{rank}"] = covered
+        if rank == 0:
+            ret["ref"] = [w0[gi] - mean[gi] for gi in range(len(w0))]
+            ret["total"] = sum(g.numel() for g in flats.g)
+            ret["msgs"] = red.launches_last_step
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_reducer_equals_allreduce_step():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    world = 2
+    mp.spawn(_shard_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for gi, ref in enumerate(ret["ref"]):
+        for r in range(world):
+            assert torch.allclose(ret[f"w{r}"][gi], ref, rtol=0, atol=1e-6), (gi, r)
+        assert torch.equal(ret["w0"][gi], ret["w1"][gi])  # identical weights on every rank
+    # each rank stepped about half of the parameters (its shards + the short tails of 6 buckets)
+    assert ret["total"] // 2 <= ret["covered0"] <= ret["total"] // 2 + 6 * world * 5
