@@ -150,6 +150,7 @@ class FlatAdamScaler:
                     works += reducer.gather_weights(gi, sc, self.flats.w[gi])
             for wk in works:
                 wk.wait()
+            self._gather_small_masters(reducer, owned, scattered)
             self._last_scattered = scattered
             self._master_stale = any(gi in self.lazy_master_groups and self.flats.w16[gi] is not None for gi in range(ngroups))
         if self.use_scaler:
@@ -158,6 +159,41 @@ class FlatAdamScaler:
         # padded / cast copies (and the stem's filter-row runs) keyed on torch's version counter do not see
         # raw-pointer updates
         self.engine.invalidate_weights()
+
+    _small_cache = None
+
+    def _gather_small_masters(self, reducer, owned, scattered):
+        """lazy_master_groups keep the other ranks' fp32 masters stale -- but the 1-D parameters of those groups (BatchNorm
+        weight / bias, Linear bias) have no 16-bit copy: kernels read their fp32 values directly.  They are a few thousand
+        elements: every rank contributes the ones it stepped (its shards; bucket tails, which every rank steps, count on rank
+        0), zeros elsewhere, and ONE all-reduce(SUM) completes the vector everywhere."""
+        import torch.distributed as dist
+
+        from .dist import rank as _rank
+
+        lazy = [gi for gi in self.lazy_master_groups if self.flats.w16[gi] is not None]
+        if not lazy:
+            return
+        if self._small_cache is None:
+            r = _rank(reducer.group)
+            cache = []
+            for gi in lazy:
+                spans = [(off, off + p.numel()) for p, off in zip(self.flats.params[gi], self.flats.offsets[gi]) if p.dim() < 2]
+                if not spans:
+                    continue
+                dev = self.flats.w[gi].device
+                idx = torch.cat([torch.arange(a, b, device=dev) for a, b in spans])
+                mine = torch.zeros_like(idx, dtype=torch.bool)
+                shards = [(lo + r * per, lo + (r + 1) * per) for lo, per in scattered.get(gi, [])]
+                for lo, hi in owned.get(gi, []):
+                    if (lo, hi) in shards or r == 0:  # a tail (stepped identically by every rank) counts once
+                        mine |= (idx >= lo) & (idx < hi)
+                cache.append((gi, idx, mine.to(torch.float32)))
+            self._small_cache = cache
+        for gi, idx, mine in self._small_cache:
+            vals = self.flats.w[gi][idx] * mine
+            dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=reducer.group)
+            self.flats.w[gi][idx] = vals
 
     def sync_master_weights(self):
         """after sharded steps: fetch the other ranks' shards of the fp32 master weights of lazy_master_groups (their Adam
