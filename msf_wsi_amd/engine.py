@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import kernels as kn
-from .dist import sync_sums
+from .dist import probe_collectives, sync_sums
 
 
 # ------------------------------------------------------------------------------------------------
@@ -320,6 +320,7 @@ class Engine:
         # activation-stationary ("panel") kernels for the short-k 1x1 convs of a Bottleneck (csrc/panel.hip): conv3's fused
         # tail reads conv2's RAW output (bn2 + ReLU applied while the panel is staged), conv1's input gradient forms bn1's
         # backward dc1 = k1*g + k2*c1 + k3 in its staging and writes it back once for the weight gradient
+        self.multirank_streams = os.environ.get("MSFWSI_MULTIRANK_STREAMS", "1") != "0"
         self.panel_fwd = os.environ.get("MSFWSI_PANEL_FWD", "1") != "0"
         self.panel_dgrad = os.environ.get("MSFWSI_PANEL_DGRAD", "1") != "0"
         self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
@@ -378,6 +379,7 @@ class Engine:
         self.ctx_stream = os.environ.get("MSFWSI_CTX_STREAM", "1") != "0"
         self._calib: Dict[tuple, Tuple[float, float]] = {}
         self._side: Dict[str, torch.cuda.Stream] = {}
+        self._stream_groups: Dict[int, object] = {}  # side stream handle -> its own communicator (see _comm)
         self._bn_order: Optional[Tuple[str, dict]] = None
         # Cross-replica runs: the two views of an encoder in LOCKSTEP on two host threads, one SyncBatchNorm message per
         # BatchNorm and direction for both views (_ViewPair).  On whenever statistics are exchanged (more than one rank,
@@ -422,6 +424,26 @@ class Engine:
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.group)
         return 1
+
+    def _comm(self):
+        """the process group the CURRENT stream's BatchNorm exchanges travel on.  Collectives of one communicator execute in
+        the order they were enqueued: with all three streams on one communicator the second view's first exchange would
+        queue behind ALL exchanges of the first view's pass -- the streams would run one after the other.  Each side stream
+        gets its own communicator (created collectively, in a fixed order, before the first multi-stream step)."""
+        if not self._stream_groups:
+            return self.group
+        return self._stream_groups.get(torch.cuda.current_stream().cuda_stream, self.group)
+
+    def _make_stream_groups(self, dev):
+        """COLLECTIVE (every rank, same order): communicators for the side streams of the multi-stream schedule"""
+        if self._stream_groups or not (dist.is_available() and dist.is_initialized()):
+            return
+        backend = dist.get_backend(self.group)
+        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else None
+        for which in ("side", "ctx"):
+            g = dist.new_group(ranks=ranks, backend=backend)
+            self._stream_groups[self._side_stream(dev, which).cuda_stream] = g
+            probe_collectives(g, dev)  # the communicator's buffers exist before the memory plan measures what is free
 
     def _side_stream(self, dev, which: str = "side") -> "torch.cuda.Stream":
         key = f"{dev}/{which}"
@@ -482,7 +504,7 @@ class Engine:
         return isinstance(bn, nn.SyncBatchNorm)
 
     def _pair_collective(self, both: torch.Tensor):
-        sync_sums(both.view(-1), self.group, force=self.force_sync)
+        sync_sums(both.view(-1), self._comm(), force=self.force_sync)
         self.collectives += 1
 
     def _lockstep(self) -> bool:
@@ -561,7 +583,7 @@ class Engine:
             else:
                 packed = self._msg_buf("fwd", 2 * Cn, dev)
                 kn.shard_sum(stats, packed)
-                sync_sums(packed, self.group, force=self.force_sync)  # RCCL sum of [sum, sumsq]; equal shards per rank
+                sync_sums(packed, self._comm(), force=self.force_sync)  # RCCL sum of [sum, sumsq]; equal shards per rank
                 self.collectives += 1
             stats = packed.view(1, 2, Cn)
             total *= self._world()
@@ -611,7 +633,7 @@ class Engine:
             if pv is not None:  # lockstep: one message for both views (enqueued after both local finalizes)
                 pv[0].exchange(pv[1], lambda: self._pair_collective(both))
             else:
-                sync_sums(packed, self.group, force=self.force_sync)
+                sync_sums(packed, self._comm(), force=self.force_sync)
                 self.collectives += 1
             kn.bn_bwd_finalize(packed.view(1, nslots, Cn), nslots, which, st.count,
                                bn.weight if bn.affine else None, st.mean, st.invstd, None, None, k[0], k[1], k[2])
@@ -1116,7 +1138,13 @@ class Engine:
         finally:
             del self._world
         plan = ("recompute:" + ",".join(sorted(nosave)) if nosave else "keep-all") + (",drop-c3" if drop else "")
-        return plan + (",views-lockstep" + ("" if pair else "(forward only)") if world > 1 else "")
+        if world > 1:
+            # two sets of backward transients fit beside the RCCL reserve: the multi-stream schedule (side streams on their
+            # own communicators); otherwise the two views of an encoder in lockstep on one stream
+            if pair and not nosave and self.multirank_streams and self.allow_multistream:
+                return plan + ",dual-stream" + ("+context-stream" if self.ctx_stream else "")
+            return plan + ",views-lockstep" + ("" if pair else "(forward only)")
+        return plan
 
     def _plan_local(self, per_image_bytes: float, B: int, K: int, device, c3_fraction: float, ctx_passes: int = 1):
         """this rank's own (features-only passes, drop conv3 outputs, two views' backward side by side) choice;
@@ -1674,11 +1702,17 @@ class Engine:
         # reference call order (backbone.py:140-145): separate BatchNorm batches per call
         self._drop_c3 = False  # the first (small) context pass keeps everything and calibrates the planner
         shape_key = (tuple(x1[0].shape[1:]), tuple(x1[1].shape[1:]), sum(1 for _ in model.parameters()), str(dtype))
+        multi = self._world() > 1 or (self.force_sync and dist.is_available() and dist.is_initialized())
         if self.dual_stream is not None:
             dual = self.dual_stream
-        else:  # automatic: one rank, backward wanted, and the previous step of this shape found the memory for it
-            dual = (need_backward and self.allow_multistream and self._world() == 1 and not self.force_sync
+        else:
+            # automatic: backward wanted, and the previous step of this shape found the memory for it.  With several ranks
+            # the finding is part of the COLLECTIVE plan (every rank takes the same branch) and the side streams exchange
+            # their BatchNorm statistics on communicators of their own (MSFWSI_MULTIRANK_STREAMS=0: lockstep views instead)
+            dual = (need_backward and self.allow_multistream and (not multi or self.multirank_streams)
                     and self._dual_ok.get((B, K) + shape_key, False))
+        if dual and multi:
+            self._make_stream_groups(dev)
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev) if dual else None
         ev_c, ev_t = {}, {}

@@ -29,9 +29,12 @@ def _worker(rank, world, port, ret):
     from msf_wsi_amd.train import PretrainStep
 
     if world == 2:
-        os.environ["MSFWSI_DUAL_STREAM"] = "1"  # the optional two-stream schedule under a real multi-rank exchange
-    # (world 4: the default multi-rank schedule -- the two views of an encoder in LOCKSTEP, one SyncBatchNorm message per
-    #  BatchNorm and direction for both views)
+        os.environ["MSFWSI_DUAL_STREAM"] = "1"  # the multi-stream schedule under a real multi-rank exchange, from step one
+    else:
+        # world 4: the other multi-rank schedule -- the two views of an encoder in LOCKSTEP on one stream, one SyncBatchNorm
+        # message per BatchNorm and direction for both views (what a rank falls back to when two sets of backward transients
+        # do not fit beside the RCCL reserve; MSFWSI_MULTIRANK_STREAMS=0 selects it outright)
+        os.environ["MSFWSI_MULTIRANK_STREAMS"] = "0"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
