@@ -552,7 +552,11 @@ def main():
                        # SyncBatchNorm exchanges (+ the plan) of the last step and the gradient exchange's messages
                        "collectives_per_step": run_collectives,
                        "gradient_messages_per_step": ts.reducer.launches_last_step,
-                       "gradient_bytes_per_step": ts.reducer.bytes_last_step},
+                       "gradient_bytes_per_step": ts.reducer.bytes_last_step,
+                       # sharded: every bucket reduce-scattered, Adam on 1/world of it, updated weights all-gathered (fp32
+                       # masters of the encoders, the 16-bit copy alone for the fuser heads)
+                       "optimizer": ("sharded (reduce-scatter, Adam on 1/%d, all-gather)" % max(1, world)
+                                     if ts.reducer.sharding else "replicated (all-reduce)" if ts.reducer.active else "single rank")},
         }
         if timer is not None and args.layer_report:
             rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1][1])

@@ -320,3 +320,60 @@ def test_block_fault_injection(hip_lib, stationary_forced, monkeypatch, factor):
     # (the block's OUTPUT cannot show it: bn3 behind the linear conv3 divides a uniform scale of conv3's operand out
     #  again -- it is the gradients flowing back through the mis-scaled activation that are off by the factor)
     assert any(k.startswith("layer2.0:") for k in bad), (factor, {k: v for k, v in worst.items() if k.startswith("layer2.0")})
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_block_gates_agree_with_free_fp64_gates(hip_lib, stationary_forced, dtype):
+    """The backward comparisons above run the fp64 block WITH THE PRODUCT'S ReLU gates; this test closes the other half:
+    with FREE gates (plain fp64 ReLU on the same 16-bit block input) the fraction of gates -- inner activations and block
+    output -- that fall on the other side in the product is at most 2^-7 (bf16) / 2^-10 (fp16): a kernel that derived or
+    stored its gates wrongly (msfwsi_conv_fwd_post's gate_out, the panel kernels' blocked gate bytes, the mask the input
+    gradients re-derive from a raw conv output) would differ in percent of them.  And the gate BYTES the forward wrote equal
+    the sign of the stored block output bit for bit."""
+    from msf_wsi_amd import kernels as kn
+    from msf_wsi_amd.engine import Engine
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden("r50enc_b16_s64_div")
+    x = orc.diverse_images(man["B"], man["size"], man["data_seed"])
+    enc = _encoder("resnet50").cuda().train()
+    eng = Engine()
+    eng.update_running = False
+    ps = eng.encoder_forward(enc, x.cuda(), dtype)
+    torch.cuda.synchronize()
+    blocks = [b for stage in enc.stages() for b in stage]
+    bound = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    worst, with_bits = 0.0, 0
+    for blk, rec in zip(blocks, ps.blocks):
+        x64 = _nchw64(rec.y_in)
+        out = x64
+        main = blk.main_branch()
+        for i, (conv, bn) in enumerate(main):
+            w = conv.weight.detach().double().cpu()
+            out = F.batch_norm(F.conv2d(out, w, None, stride=conv.stride, padding=conv.padding), None, None,
+                               bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu(), training=True, eps=bn.eps)
+            if i + 1 < len(main):
+                free = out > 0
+                mine = _gate_of(rec.units[i].c, rec.units[i].st) > 0
+                frac = (free != mine).double().mean().item()
+                worst = max(worst, frac)
+                assert frac <= bound, (f"gate of unit {i}", frac, bound)
+                out = F.relu(out)
+        ident = x64
+        if blk.downsample is not None:
+            dc, db = blk.downsample[0], blk.downsample[1]
+            ident = F.batch_norm(F.conv2d(x64, dc.weight.detach().double().cpu(), None, stride=dc.stride), None, None,
+                                 db.weight.detach().double().cpu(), db.bias.detach().double().cpu(), training=True, eps=db.eps)
+        free_out = (out + ident) > 0
+        mine_out = _nchw64(rec.y_out) > 0
+        frac = (free_out != mine_out).double().mean().item()
+        worst = max(worst, frac)
+        assert frac <= bound, ("block output gate", frac, bound)
+        if rec.gate_bits is not None:  # the bytes the fused tails wrote: (stored y > 0), bit for bit
+            with_bits += 1
+            M, Cn = rec.y_out.numel() // rec.y_out.shape[-1], rec.y_out.shape[-1]
+            b = kn.gate_unpack(rec.gate_bits, M, Cn, dtype).to(torch.int32)
+            got = ((b.unsqueeze(-1) >> torch.arange(8, device=b.device)) & 1).bool().view(M, Cn)
+            assert torch.equal(got, rec.y_out.view(M, Cn) > 0)
+    assert with_bits >= 12, with_bits  # every Bottleneck tail on the fused path carries gate bytes
+    print(f"[free gates {dtype}] worst fraction of differing gates {worst:.2e} (bound {bound:.2e})")
