@@ -159,6 +159,28 @@ int msfwsi_panel_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c,
 int msfwsi_panel_gram(int dtype, const void* c, const float* scale, const float* shift, double* A64, double* sums, long M,
                       int C, void* stream);
 
+/* ---- image-stationary 3x3 convolution of the deep layers (csrc/img3x3.hip) ----------------------------------------
+ * conv2 of the Bottlenecks of layer2 / layer3 (src/models/resnet.py:25-28,128: 3x3, stride 1, pad 1, C == K) at 28x28x128
+ * and 14x14x256, 16-bit storage: a workgroup keeps a band of 196 output pixels with its halo in LDS (read from HBM once;
+ * a filter tap is a constant added to the fragment address) and streams the filter in MFMA fragment order -- no barrier
+ * and no LDS-DMA in the k loop.  msfwsi_img3x3_supported says whether a geometry qualifies; otherwise the entry points
+ * return MSFWSI_EUNSUPPORTED and callers use msfwsi_conv_fwd / msfwsi_conv_dgrad. */
+int msfwsi_img3x3_supported(const msfwsi_conv_desc* d);
+/* wpk <- the filter w [K][3][3][C] in fragment order: [n/32][tap*(Ck/16) + c/16][64 lanes][8]; dgrad = 0: output channel n
+ * = K index, operand channel c = C index; dgrad = 1: n = C index, c = K index, taps flipped (the transposed convolution). */
+int msfwsi_img3x3_pack_weights(int dtype, const void* w, void* wpk, int K, int C, int dgrad, void* stream);
+/* y = conv3x3(act(x), W) with act = relu(pro_scale*x + pro_shift) when pro_* != NULL (x = the producer's raw conv output,
+ * resnet.py:125-128 fused; the zero padding stays zero), else x.  stats as in msfwsi_conv_fwd. */
+int msfwsi_img3x3_fwd(const msfwsi_conv_desc* d, const void* x, const float* pro_scale, const float* pro_shift,
+                      const void* wpk, void* y, double* stats, int nshard, void* stream);
+/* dx = gate(conv3x3_transpose(dc, W)), sums as in msfwsi_conv_dgrad with mask_c; dc = k1*dy + k2*c + k3 when c != NULL (the
+ * BatchNorm backward of the layer whose raw output is c, formed while the band is staged; dc_out (nullable) receives it
+ * for the weight gradient; it may alias dy only at 14x14, where a workgroup owns a whole image: bands of a 28x28 image read
+ * their halo rows from each other's gradient), else dy. */
+int msfwsi_img3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c, const float* k1, const float* k2,
+                        const float* k3, void* dc_out, const void* wpk, void* dx, const void* mask_c,
+                        const float* mask_scale, const float* mask_shift, double* sums, int nshard, void* stream);
+
 /* Specialised 3x3 / stride 1 / pad 1 path: the input patch of 256 raster pixels (+ halo) is staged once per
  * channel slab in LDS and reused by all nine taps (see csrc/conv3x3.hip).  Same results as msfwsi_conv_fwd /
  * msfwsi_conv_dgrad without prologue/bias/gapg; `supported` tells whether a geometry qualifies.

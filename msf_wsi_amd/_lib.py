@@ -97,6 +97,10 @@ SIGNATURES = {
     "msfwsi_color_stage": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "msfwsi_blur_sharpen": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "msfwsi_inverse_perm": [_vp, _vp, _l, _i, _vp],
+    "msfwsi_img3x3_supported": [_desc],
+    "msfwsi_img3x3_pack_weights": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "msfwsi_img3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_img3x3_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_panel_gram": [_i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
     "msfwsi_panel_supported": [_desc, _i],
     "msfwsi_panel_pack_weights": [_i, _vp, _vp, _i, _i, _l, _l, _vp],

@@ -1,0 +1,361 @@
+// Image-stationary 3x3 / stride 1 / pad 1 convolution for the deep layers of the encoders on gfx950 (16-bit storage):
+// conv2 of the Bottlenecks of layer2 (28x28, 128 -> 128) and layer3 (14x14, 256 -> 256), forward and input gradient
+// (reference src/models/resnet.py:25-28,128; backward through scaler.scale(loss).backward(), tools/ssl_train.py:472).
+//
+// Why a third 3x3 kernel.  The gather kernel (igemm.hip) re-fetches every activation row NINE times from L2 into LDS -- one
+// `buffer_load ... lds` piece per (tap, 64-byte slab), a workgroup barrier per slab -- and runs these layers at 0.9-1.0
+// PFLOP/s, 40 % MFMA utilisation: its waves stall in the issue of the DMA pieces and at 72-144 barriers per tile.  Here
+//   * a workgroup owns a BAND of an image: BH full rows (the whole 14x14 image; 7 rows of a 28x28 one) = 196 output pixels
+//     = seven 32-row MFMA tiles.  The band with its halo ((BH+2) x (W+2) positions, zero outside the image) is read from
+//     HBM ONCE, optionally transformed on the way (the producer's BatchNorm+ReLU; or the BatchNorm backward dc = k1 g + k2
+//     c + k3, written back for the weight gradient), and parked in LDS: a filter tap is then nothing but a constant added
+//     to the fragment's LDS address;
+//   * after one barrier every wave runs alone: wave w owns output channels 32w .. 32w+31 of all 196 pixels (7 accumulator
+//     tiles); its weight fragments stream from L2 in MFMA order (msfwsi_img3x3_pack_weights: 1 KiB per fragment, 9 * C/16
+//     of them, consumed strictly in sequence) through a four-deep register ring of hand-counted asm loads (handload.h);
+//     7 MFMAs per fragment, one ds_read_b128 per MFMA, no barrier, no DMA, no address arithmetic beyond one XOR per read.
+// Weight traffic: every workgroup streams the whole filter (1.2 MB at 256 channels) from L2 -- 4.8 GB per N = 4096 launch
+// at ~15 TB/s, below the MFMA time; activations: one pass.
+#include "common.h"
+#include "handload.h"
+#include "../../include/msfwsi_hip.h"
+
+namespace {
+
+struct Img3Params {
+    const void* src;    // [N][H][W][C]: PRO 0 the operand, PRO 1 the producer's raw conv output, PRO 2 the gated gradient g
+    const void* src_c;  // PRO 2: the raw conv output whose BatchNorm is differentiated
+    const float* p0;    // PRO 1: scale  PRO 2: k1
+    const float* p1;    // PRO 1: shift  PRO 2: k2
+    const float* p2;    //               PRO 2: k3
+    void* aout;         // PRO 2, nullable: dc written back [N][H][W][C]
+    const void* wpk;    // [KO/32][9 * C/16][64][8]
+    void* out;          // [N][H][W][KO]
+    double* stats;      // forward: [nshard][2][KO] += {sum y, sum y^2} of the stored outputs; gradient: {sum g, sum g*c}
+    int nshard;
+    const void* mask_c;       // gradient: [N][H][W][KO] raw conv output whose BatchNorm+ReLU gates it, nullable
+    const float* mask_scale;
+    const float* mask_shift;
+    int N, H;
+};
+
+__device__ __forceinline__ int img_swz(int row) { return row & 15; }  // rows are >= 256 bytes: see panel.hip panel_swz
+
+template <typename T, int C, int KO, int BH, int IW, int PRO, bool DGRAD>
+__global__ __launch_bounds__(KO * 2, 2) void img3x3_kernel(const Img3Params prm) {
+    constexpr int NW = KO / 32, NT = 64 * NW;
+    constexpr int PW = IW + 2, PP = (BH + 2) * PW;  // padded positions of the band
+    constexpr int CPR = C / 8, ROWB = C * 2;
+    constexpr int NCH = (PP * CPR + NT - 1) / NT;    // 16-byte chunks staged per thread
+    constexpr int MB = BH * IW;                      // output pixels of the band
+    constexpr int TM = (MB + 31) / 32;
+    constexpr int KC = C / 16;                       // k steps per tap
+    constexpr int R = 4;                             // weight-fragment ring
+    constexpr int SCR_PITCH = 80, SCR_BYTES = 32 * SCR_PITCH;
+    static_assert(C % 128 == 0 && KO % 32 == 0 && NT % CPR == 0 && KC % R == 0, "image kernel geometry");
+    typedef typename MmaFrag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* img = smem;  // [PP][ROWB], chunk index XOR-swizzled by the position
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    char* scratch = smem + PP * ROWB + wave * SCR_BYTES;
+
+    const int nband = prm.H / BH;
+    const int image = blockIdx.x / nband, band = blockIdx.x - image * nband;
+    const int row0 = band * BH;                                   // first image row of the band
+    const long pix0 = ((long)image * prm.H + row0) * IW;          // first output pixel (bands are contiguous in memory)
+
+    // ---------------- stage the band + halo: every chunk requested up front (clamped addresses, no branches) ----------------
+    {
+        const int cc = tid % CPR;
+        const char* src_img = reinterpret_cast<const char*>(prm.src) + (long)image * prm.H * IW * ROWB;
+        const char* srcc_img = PRO == 2 ? reinterpret_cast<const char*>(prm.src_c) + (long)image * prm.H * IW * ROWB : nullptr;
+        uint4 v[NCH], vc[PRO == 2 ? NCH : 1];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int pos = (tid + i * NT) / CPR;
+            const int ph = pos / PW, pw = pos - ph * PW;
+            const int hh = row0 + ph - 1, ww = pw - 1;
+            const bool ok = pos < PP && hh >= 0 && hh < prm.H && ww >= 0 && ww < IW;
+            const unsigned off = (unsigned)((ok ? hh * IW + ww : row0 * IW) * ROWB + cc * 16);
+            v[i] = *reinterpret_cast<const uint4*>(src_img + off);
+            if constexpr (PRO == 2) vc[i] = *reinterpret_cast<const uint4*>(srcc_img + off);
+        }
+        float c0[PRO ? 8 : 1], c1[PRO ? 8 : 1], c2[PRO == 2 ? 8 : 1];
+        if constexpr (PRO != 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                c0[e] = prm.p0[cc * 8 + e];
+                c1[e] = prm.p1[cc * 8 + e];
+                if constexpr (PRO == 2) c2[e] = prm.p2[cc * 8 + e];
+            }
+        }
+        char* aout_img = PRO == 2 && prm.aout != nullptr ? reinterpret_cast<char*>(prm.aout) + (long)image * prm.H * IW * ROWB : nullptr;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int pos = (tid + i * NT) / CPR;
+            const int ph = pos / PW, pw = pos - ph * PW;
+            const int hh = row0 + ph - 1, ww = pw - 1;
+            const bool ok = pos < PP && hh >= 0 && hh < prm.H && ww >= 0 && ww < IW;
+            uint4 t = v[i];
+            if constexpr (PRO == 1) {
+                float f[8];
+                unpack16<T>(t, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], c0[e], c1[e]), 0.f);
+                t = pack16<T>(f);
+            } else if constexpr (PRO == 2) {
+                float g[8], c[8];
+                unpack16<T>(t, g);
+                unpack16<T>(vc[i], c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = fmaf(c0[e], g[e], fmaf(c1[e], c[e], c2[e]));  // = msfwsi_bn_bwd_apply
+                t = pack16<T>(g);
+                // every pixel is written by the ONE band that owns its row (halo rows belong to the neighbours)
+                if (aout_img != nullptr && ok && ph >= 1 && ph <= BH)
+                    *reinterpret_cast<uint4*>(aout_img + (unsigned)((hh * IW + ww) * ROWB + cc * 16)) = t;
+            }
+            if (!ok) t = make_uint4(0, 0, 0, 0);  // zero padding AFTER the transform (relu(shift) is not zero)
+            if (pos < PP) *reinterpret_cast<uint4*>(img + pos * ROWB + ((cc ^ img_swz(pos)) << 4)) = t;
+        }
+    }
+    // the first R weight fragments of this wave's channel block, then the only barrier
+    const char* wb = reinterpret_cast<const char*>(prm.wpk) + (long)wave * (9 * KC) * 1024;
+    u32x4 wf[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) pl_load16<true>(wf[i], wb, (unsigned)(i * 1024 + lane * 16));
+    __syncthreads();
+
+    // ---------------- the k loop: 9 taps x KC steps, 7 MFMAs per weight fragment ----------------
+    int pos0[TM];  // padded position of the window origin of this lane's pixel in row tile tm (0 for the padding rows)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int p = tm * 32 + l31;
+        const int h = p / IW, w = p - h * IW;
+        pos0[tm] = p < MB ? h * PW + w : 0;
+    }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+
+    int step = 0;  // fragments consumed so far (the ring slot is step % R: static inside the unrolled tap body)
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int r = tap / 3, s_ = tap - r * 3;
+        const int shift = r * PW + s_;
+        int rowb[TM], sw[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row = pos0[tm] + shift;
+            rowb[tm] = row * ROWB;
+            sw[tm] = img_swz(row) ^ lh;  // chunk (2 kc + lh) ^ swz = (2 kc) ^ (lh ^ swz)
+        }
+        frag_t xc[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) xc[tm] = *reinterpret_cast<const frag_t*>(img + rowb[tm] + ((0 ^ sw[tm]) << 4));
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            pl_wait<true, R - 1>(wf[kc % R]);
+            const frag_t wfr = __builtin_bit_cast(frag_t, wf[kc % R]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                mma32<T>(acc[tm], wfr, xc[tm]);
+                if (kc + 1 < KC) xc[tm] = *reinterpret_cast<const frag_t*>(img + rowb[tm] + (((2 * (kc + 1)) ^ sw[tm]) << 4));
+            }
+            // the fragment R steps ahead takes the slot just consumed (past the end: the last fragment again, never used)
+            const int nxt = step + kc + R < 9 * KC ? step + kc + R : 9 * KC - 1;
+            pl_load16<true>(wf[kc % R], wb, (unsigned)(nxt * 1024 + lane * 16));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kc + 1 < KC) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        step += KC;
+    }
+    // the ring's trailing re-requests are still in flight: the wait NAMES their registers, so that hipcc cannot hand them to
+    // the epilogue's address arithmetic before the loads have landed (it did: tools/check_hand_waits.py)
+    static_assert(R == 4, "the final wait lists the ring slots");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) : : "memory");
+
+    // ---------------- epilogue: 16-byte row chunks through the wave's scratch; statistics / gate + sums ----------------
+    const int q = lane & 3, r4 = lane >> 2;
+    const int ncol = wave * 32 + q * 8;
+    T* __restrict__ out = reinterpret_cast<T*>(prm.out) + pix0 * KO;
+    const T* __restrict__ mask_c = DGRAD ? reinterpret_cast<const T*>(prm.mask_c) : nullptr;
+    if (mask_c != nullptr) mask_c += pix0 * KO;
+    uint4 mk[DGRAD ? TM * 2 : 1];
+    float msc[8], msh[8];
+    if constexpr (DGRAD) {
+        if (mask_c != nullptr) {
+#pragma unroll
+            for (int t = 0; t < TM * 2; ++t) {
+                const int p = (t >> 1) * 32 + (t & 1) * 16 + r4;
+                mk[t] = *reinterpret_cast<const uint4*>(mask_c + (long)(p < MB ? p : 0) * KO + ncol);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                msc[e] = prm.mask_scale[ncol + e];
+                msh[e] = prm.mask_shift[ncol + e];
+            }
+        }
+    }
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint2*>(scratch + l31 * SCR_PITCH + (8 * g + 4 * lh) * 2) =
+                pack4<T>(acc[tm][4 * g], acc[tm][4 * g + 1], acc[tm][4 * g + 2], acc[tm][4 * g + 3]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = tm * 32 + i * 16 + r4;
+            uint4 cv = *reinterpret_cast<const uint4*>(scratch + (i * 16 + r4) * SCR_PITCH + q * 16);
+            if (p < MB) {
+                float f[8];
+                unpack16<T>(cv, f);
+                if constexpr (DGRAD) {
+                    if (mask_c != nullptr) {
+                        float c[8];
+                        unpack16<T>(mk[tm * 2 + i], c);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (!(fmaf(c[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
+                            s0[e] += f[e];
+                            s1[e] = fmaf(f[e], c[e], s1[e]);
+                        }
+                        cv = pack16<T>(f);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s0[e] += f[e];
+                        s1[e] = fmaf(f[e], f[e], s1[e]);
+                    }
+                }
+                *reinterpret_cast<uint4*>(out + (long)p * KO + ncol) = cv;
+            }
+        }
+    }
+    if (prm.stats != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) {
+                s0[e] += __shfl_xor(s0[e], off, 64);
+                s1[e] += __shfl_xor(s1[e], off, 64);
+            }
+        }
+        if (lane < 4) {
+            double* dst = prm.stats + (long)(blockIdx.x % prm.nshard) * 2 * KO + ncol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(dst + e, (double)s0[e]);
+                atomicAdd(dst + KO + e, (double)s1[e]);
+            }
+        }
+    }
+}
+
+// wpk[n/32][step][lane][j], step = tap * (Ck/16) + c/16:  forward  W'(n, tap, c) = w[n][tap][c]         (w = [K][3][3][C])
+//                                                          gradient W'(n, tap, c) = w[c][8 - tap][n]     (taps flipped)
+template <typename U>
+__global__ void img3x3_pack_kernel(const U* __restrict__ w, U* __restrict__ wpk, int K, int C, int dgrad) {
+    const int nout = dgrad ? C : K, ck = dgrad ? K : C;
+    const long total = (long)nout * 9 * ck;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long frag = i >> 9;
+    const int steps = 9 * (ck >> 4);
+    const int step = (int)(frag % steps), nb = (int)(frag / steps);
+    const int tap = step / (ck >> 4), c = (step - tap * (ck >> 4)) * 16 + 8 * (lane >> 5) + j;
+    const int n = nb * 32 + (lane & 31);
+    wpk[i] = dgrad ? w[((long)c * 9 + (8 - tap)) * C + n] : w[((long)n * 9 + tap) * C + c];
+}
+
+template <typename T, int C, int BH, int IW, int PRO, bool DGRAD>
+int launch_img(const Img3Params& prm, hipStream_t stream) {
+    constexpr int KO = C;
+    constexpr int LDS = (BH + 2) * (IW + 2) * C * 2 + (KO / 32) * 32 * 80;
+    void (*kern)(const Img3Params) = img3x3_kernel<T, C, KO, BH, IW, PRO, DGRAD>;
+    if (LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long nwg = (long)prm.N * (prm.H / BH);
+    if (nwg <= 0 || nwg > 0x7fffffffL) return MSFWSI_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(KO * 2), LDS, stream, prm);
+    return msfwsi_launch_status();
+}
+
+template <typename T, int PRO, bool DGRAD>
+int dispatch_img(const msfwsi_conv_desc* d, const Img3Params& prm, hipStream_t st) {
+    if (d->H == 14 && d->C == 256) return launch_img<T, 256, 14, 14, PRO, DGRAD>(prm, st);
+    if (d->H == 28 && d->C == 128) return launch_img<T, 128, 7, 28, PRO, DGRAD>(prm, st);
+    return MSFWSI_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int msfwsi_img3x3_supported(const msfwsi_conv_desc* d) {
+    if (d == nullptr || (d->dtype != MSFWSI_DT_BF16 && d->dtype != MSFWSI_DT_F16)) return 0;
+    if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->C != d->K || d->H != d->W || d->P != d->H || d->Q != d->W) return 0;
+    return ((d->H == 14 && d->C == 256) || (d->H == 28 && d->C == 128)) && (long)d->N * d->H * d->W <= 0x7fffffffL ? 1 : 0;
+}
+
+extern "C" int msfwsi_img3x3_pack_weights(int dtype, const void* w, void* wpk, int K, int C, int dgrad, void* stream) {
+    MSFWSI_CHECK_ARG(w != nullptr && wpk != nullptr && K > 0 && C > 0);
+    if ((dtype != MSFWSI_DT_BF16 && dtype != MSFWSI_DT_F16) || K % 32 != 0 || C % 32 != 0) return MSFWSI_EUNSUPPORTED;
+    const long n = (long)K * 9 * C;
+    hipLaunchKernelGGL(img3x3_pack_kernel<unsigned short>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(w),
+                       reinterpret_cast<unsigned short*>(wpk), K, C, dgrad ? 1 : 0);
+    return msfwsi_launch_status();
+}
+
+extern "C" int msfwsi_img3x3_fwd(const msfwsi_conv_desc* d, const void* x, const float* pro_scale, const float* pro_shift,
+                                 const void* wpk, void* y, double* stats, int nshard, void* stream) {
+    if (!msfwsi_img3x3_supported(d)) return d == nullptr ? MSFWSI_EINVAL : MSFWSI_EUNSUPPORTED;
+    MSFWSI_CHECK_ARG(x != nullptr && wpk != nullptr && y != nullptr && (stats == nullptr || nshard >= 1));
+    MSFWSI_CHECK_ARG((pro_scale == nullptr) == (pro_shift == nullptr));
+    Img3Params prm{};
+    prm.src = x; prm.p0 = pro_scale; prm.p1 = pro_shift; prm.wpk = wpk; prm.out = y;
+    prm.stats = stats; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = d->N; prm.H = d->H;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool pro = pro_scale != nullptr;
+    if (d->dtype == MSFWSI_DT_BF16) return pro ? dispatch_img<__bf16, 1, false>(d, prm, st) : dispatch_img<__bf16, 0, false>(d, prm, st);
+    return pro ? dispatch_img<_Float16, 1, false>(d, prm, st) : dispatch_img<_Float16, 0, false>(d, prm, st);
+}
+
+extern "C" int msfwsi_img3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c, const float* k1, const float* k2,
+                                   const float* k3, void* dc_out, const void* wpk, void* dx, const void* mask_c,
+                                   const float* mask_scale, const float* mask_shift, double* sums, int nshard, void* stream) {
+    if (!msfwsi_img3x3_supported(d)) return d == nullptr ? MSFWSI_EINVAL : MSFWSI_EUNSUPPORTED;
+    MSFWSI_CHECK_ARG(dy != nullptr && wpk != nullptr && dx != nullptr);
+    const bool pro = c != nullptr;
+    MSFWSI_CHECK_ARG(pro == (k1 != nullptr) && pro == (k2 != nullptr) && pro == (k3 != nullptr) && (pro || dc_out == nullptr));
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
+    // a band reads its halo rows from the gradient of the NEIGHBOURING bands: written back in place, a neighbour's rows could
+    // already hold dc instead of g.  In place only where a workgroup owns the whole image (14 x 14).
+    MSFWSI_CHECK_ARG(dc_out == nullptr || dc_out != dy || d->H == 14);
+    Img3Params prm{};
+    prm.src = dy; prm.src_c = c; prm.p0 = k1; prm.p1 = k2; prm.p2 = k3; prm.aout = dc_out;
+    prm.wpk = wpk; prm.out = dx;
+    prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
+    prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = d->N; prm.H = d->H;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MSFWSI_DT_BF16) return pro ? dispatch_img<__bf16, 2, true>(d, prm, st) : dispatch_img<__bf16, 0, true>(d, prm, st);
+    return pro ? dispatch_img<_Float16, 2, true>(d, prm, st) : dispatch_img<_Float16, 0, true>(d, prm, st);
+}

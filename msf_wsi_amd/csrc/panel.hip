@@ -26,6 +26,7 @@
 //     barrier in the loop: one wave's epilogue traffic runs beside its neighbours' MFMAs and loads.
 // 16-bit storage types only (fp32 launches keep the gather kernel).
 #include "common.h"
+#include "handload.h"
 #include "../../include/msfwsi_hip.h"
 
 #ifndef MSFWSI_PANEL_ABLATE
@@ -81,56 +82,6 @@ __device__ __forceinline__ int panel_swz(int row) {
     // row: rows are K*2 bytes apart (a multiple of 256 for K >= 128; 128 bytes for K = 64, where bit 0 of the row picks
     // the half of the bank row)
     return K >= 128 ? (row & 15) : ((row >> 1) & 7);
-}
-
-template <typename T>
-__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d);
-template <>
-__device__ __forceinline__ uint2 pack4<__bf16>(float a, float b, float c, float d) {
-    return make_uint2(pack2_bf16(a, b), pack2_bf16(c, d));
-}
-template <>
-__device__ __forceinline__ uint2 pack4<_Float16>(float a, float b, float c, float d) {
-    return make_uint2(pack2_f16(a, b), pack2_f16(c, d));
-}
-
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-__device__ __forceinline__ uint4 as_uint4(const u32x4& v) { return make_uint4(v.x, v.y, v.z, v.w); }
-
-// Global loads of the block loop, in two forms.  HAND = true (whole panels: every workgroup but possibly the last): inline
-// asm, invisible to hipcc's wait-count pass, completion tracked by hand-counted `s_waitcnt vmcnt(N)` statements that name the
-// destination "+v" (so that no consumer is scheduled above the wait; form (ii) of the HIP guide's inline-asm section).
-// Why: the loop is software-pipelined ACROSS iterations (operands of block j+1 are requested during block j), and for
-// loads whose results cross the loop's back edge hipcc falls back to `vmcnt(<small>)` at the first use -- every block
-// began by draining the queue, i.e. by waiting for the identity loads issued a moment earlier (1.0 -> 1.25 ms per launch).
-// HAND = false (the ragged last panel): plain loads, hipcc's own waits.
-template <bool HAND>
-__device__ __forceinline__ void pl_load16(u32x4& dst, const void* sbase, unsigned voff) {
-    if constexpr (HAND) {
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-    } else {
-        dst = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(sbase) + voff);
-    }
-}
-template <bool HAND>
-__device__ __forceinline__ void pl_load4(unsigned& dst, const void* sbase, unsigned voff) {
-    if constexpr (HAND) {
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-    } else {
-        dst = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(sbase) + voff);
-    }
-}
-// at most N vector-memory operations younger than the one that fills `r` may still be outstanding
-template <bool HAND, int N>
-__device__ __forceinline__ void pl_wait(u32x4& r) {
-    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
-    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
-}
-template <bool HAND, int N>
-__device__ __forceinline__ void pl_wait(u32x4& r, unsigned& r2) {
-    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
-    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r), "+v"(r2) : "n"(N) : "memory");
 }
 
 // The block loop of one wave.  Vector-memory operations per block, in program order (HAND mode: all unconditional):
@@ -400,7 +351,19 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
             }
         }
     }
-    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's re-requested operands: nobody reads them
+    // the last block's re-requested operands: nobody reads them, but they are still in flight -- every destination register is
+    // named by a draining wait before hipcc may re-use it (tools/check_hand_waits.py checks the code after the loop too)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) pl_drain<HAND>(wf[ks]);
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        pl_drain<HAND>(er[t]);
+        if constexpr (!FWD) pl_drain<HAND>(ebw[t]);
+    }
+    if constexpr (FWD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pl_drain<HAND>(pq[i]);
+    }
 }
 
 // PRO: 0 none, 1 relu(scale*c + shift), 2 k1*g + k2*c + k3.   EPI: 1 forward post, 0 input gradient, 3 input gradient with

@@ -1255,6 +1255,96 @@ def conv3x3_dgrad(d: ConvDesc, dy, w, dx, resid=None, mask=None, sums=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# image-stationary 3x3 of the deep layers (csrc/img3x3.hip)
+# ------------------------------------------------------------------------------------------------
+def img3x3_supported(d: ConvDesc) -> bool:
+    """conv2 of layer2 / layer3 (src/models/resnet.py:128 at 28x28x128 / 14x14x256, 16-bit storage)"""
+    return bool(_lib.load().msfwsi_img3x3_supported(C.byref(d)))
+
+
+def img3x3_pack_weights(w, wpk, dgrad: bool):
+    """wpk <- w [K][3][3][C] in the fragment order the kernel streams (dgrad: transposed, taps flipped)"""
+    K, Cc = w.shape[0], w.shape[-1]
+    _req(w, "w", w.dtype, K * 9 * Cc)
+    _req(wpk, "wpk", w.dtype, K * 9 * Cc)
+    _lib.check(_lib.load().msfwsi_img3x3_pack_weights(dt_of(w), _p(w), _p(wpk), K, Cc, int(dgrad), _stream()),
+               "img3x3_pack_weights")
+    return wpk
+
+
+def _img3_symbol(d: ConvDesc, dt, pro: int, dgrad: bool) -> str:
+    t = "DF16_" if dt == torch.float16 else "DF16b"
+    bh = 14 if d.H == 14 else 7
+    return f"img3x3_kernelI{t}Li{d.C}ELi{d.K}ELi{bh}ELi{d.W}ELi{pro}ELb{int(dgrad)}EE"
+
+
+def img3x3_fwd(d: ConvDesc, x, wpk, y, stats=None, pro=None) -> bool:
+    """False (nothing launched) where the geometry is not served; pro = (scale, shift): x is the producer's raw output"""
+    lib = _lib.load()
+    dt = x.dtype
+    ps = psh = None
+    if pro is not None:
+        ps, psh = pro
+        _req(ps, "pro_scale", torch.float32, d.C)
+        _req(psh, "pro_shift", torch.float32, d.C)
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(wpk, "wpk", dt, d.K * 9 * d.C)
+    _req(y, "y", dt, d.N * d.P * d.Q * d.K)
+    nsh = 1
+    if stats is not None:
+        _req(stats, "stats", torch.float64)
+        nsh = stats.shape[0]
+        if stats.numel() != nsh * 2 * d.K:
+            raise ValueError("stats must be [nshard,2,K]")
+    rc = _timed("conv_fwd", d, x.element_size(), lambda: lib.msfwsi_img3x3_fwd(
+        C.byref(d), _p(x), _p(ps), _p(psh), _p(wpk), _p(y), _p(stats), nsh, _stream()), halo=True, dtype=x.dtype,
+        symbol_override=_img3_symbol(d, dt, 1 if pro is not None else 0, False))
+    if rc == -2:
+        return False
+    _lib.check(rc, "img3x3_fwd")
+    return True
+
+
+def img3x3_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, mask=None, sums=None) -> bool:
+    """bnbwd = (c, k1, k2, k3): the gradient operand is k1*dy + k2*c + k3 (BatchNorm backward fused into the staging),
+    written to dc_out when given; mask / sums as conv3x3_dgrad.  False where the geometry is not served."""
+    lib = _lib.load()
+    dt = dy.dtype
+    n_out = d.N * d.P * d.Q * d.K
+    _req(dy, "dy", dt, n_out)
+    _req(wpk, "wpk", dt, d.K * 9 * d.C)
+    _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
+    cc = k1 = k2 = k3 = None
+    if bnbwd is not None:
+        cc, k1, k2, k3 = bnbwd
+        _req(cc, "c", dt, n_out)
+        for nm, t in (("k1", k1), ("k2", k2), ("k3", k3)):
+            _req(t, nm, torch.float32, d.K)
+    _opt(dc_out, "dc_out", dt, n_out)
+    mc = msc = msh = None
+    nsh = 1
+    if mask is not None:
+        mc, msc, msh = mask
+        _req(mc, "mask_c", dt, d.N * d.H * d.W * d.C)
+        _req(msc, "mask_scale", torch.float32, d.C)
+        _req(msh, "mask_shift", torch.float32, d.C)
+        _req(sums, "sums", torch.float64)
+        nsh = sums.numel() // (2 * d.C)
+        if nsh * 2 * d.C != sums.numel():
+            raise ValueError("sums must be [nshard,2,C]")
+    elif sums is not None:
+        raise ValueError("sums without mask")
+    rc = _timed("conv_dgrad", d, dy.element_size(), lambda: lib.msfwsi_img3x3_dgrad(
+        C.byref(d), _p(dy), _p(cc), _p(k1), _p(k2), _p(k3), _p(dc_out), _p(wpk), _p(dx), _p(mc), _p(msc), _p(msh), _p(sums),
+        nsh, _stream()), extra_elems=(dx.numel() if mask is not None else 0), halo=True, dtype=dy.dtype,
+        symbol_override=_img3_symbol(d, dt, 2 if bnbwd is not None else 0, True))
+    if rc == -2:
+        return False
+    _lib.check(rc, "img3x3_dgrad")
+    return True
+
+
+# ------------------------------------------------------------------------------------------------
 # validation metrics (csrc/metrics.hip)
 # ------------------------------------------------------------------------------------------------
 def seg_stats(logits, pred, target, num_classes: int, pred_shift: int, target_shift: int, ignore_index):

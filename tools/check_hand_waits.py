@@ -1,4 +1,5 @@
-"""Static audit of the hand-counted vector-memory waits of the panel kernels (csrc/panel.hip, HAND = true instances).
+"""Static audit of the hand-counted vector-memory waits of the activation-stationary kernels (csrc/panel.hip HAND = true
+instances, csrc/img3x3.hip).
 
 The block loop issues its global loads from inline asm (invisible to hipcc's wait-count pass) and waits for them with
 hand-written `s_waitcnt vmcnt(N)` statements.  `vmcnt(N)` returns once all but the N youngest vector-memory operations of the
@@ -9,7 +10,7 @@ This script disassembles nothing: it reads hipcc's `-S` output, walks the innerm
     least N younger vector-memory operations had been issued (else: a consumer, or a compiler copy / spill, reads the
     register before the data has landed);
   * hipcc has put no vector-memory wait of its own, no scratch access and no load of its own into the loop.
-usage: python tools/check_hand_waits.py [panel.s]      (no argument: compiles msf_wsi_amd/csrc/panel.hip to /tmp first)
+usage: python tools/check_hand_waits.py [file.s ...]   (no argument: compiles csrc/panel.hip and csrc/img3x3.hip to /tmp first)
 exit status 1 on any finding."""
 import os
 import re
@@ -60,7 +61,7 @@ def loop_body(body):
             break
     if header is None:
         return None
-    before, after, cur, seen_header = [], [], None, False
+    before, after, tail, cur, seen_header = [], [], [], None, False
     for ln in body:
         m = re.match(r"^\.L(BB\d+_\d+):(.*)", ln)
         if m:
@@ -69,30 +70,49 @@ def loop_body(body):
             elif f"Header={header} " in m.group(2) + " ":
                 cur = after if seen_header else before
             else:
-                cur = None
+                cur = tail if seen_header else None  # code after the loop (in text order)
             continue
+        if re.match(r"^; %bb\.", ln) and cur is after and seen_header and after and re.search(r"s_cbranch_\w+\s+\.L" + header, after[-1]):
+            cur = tail  # the fall-through block behind the back-edge branch
         if cur is not None:
             cur.append(ln)
-    return after + before
+    return after + before, tail
 
 
 def audit(name, body):
-    loop = loop_body(body)
-    if loop is None:
+    got = loop_body(body)
+    if got is None:
         return [f"{name}: no loop found"]
-    ins, in_asm = [], False
-    for ln in loop:
-        t = ln.strip()
-        if t.startswith(";;#ASMSTART"):
-            in_asm = True
-            continue
-        if t.startswith(";;#ASMEND"):
-            in_asm = False
-            continue
-        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
-            continue
-        ins.append((t.split(";")[0].strip(), in_asm))
+
+    def instructions(lines):
+        out, in_asm = [], False
+        for ln in lines:
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+                continue
+            out.append((t.split(";")[0].strip(), in_asm))
+        return out
+
+    ins, tail = instructions(got[0]), instructions(got[1])
     problems = []
+    # after the loop: until an asm wait for everything, hipcc must not touch a register an asm load may still write
+    inflight = set()
+    for t, a in ins:
+        if a and t.startswith("global_load"):
+            inflight |= regs_of(t.split(",")[0])
+    for t, a in tail:
+        if a and re.match(r"s_waitcnt vmcnt\(0\)", t):
+            break
+        if not a and regs_of(t) & inflight and not t.startswith("s_"):
+            problems.append(f"{name}: after the loop `{t}` touches a register an asm load may still be writing "
+                            f"(no draining wait names it)")
+            break
     for t, a in ins:
         if not a and re.match(r"s_waitcnt.*vmcnt", t):
             problems.append(f"{name}: compiler wait inside the loop: {t}")
@@ -117,6 +137,10 @@ def audit(name, body):
             ops = t2.split(None, 1)
             srcs = regs_of(ops[1].split(",", 1)[1]) if len(ops) > 1 and "," in ops[1] and not t2.startswith(("global_store", "ds_write")) \
                 else regs_of(ops[1]) if len(ops) > 1 and t2.startswith(("global_store", "ds_write", "s_waitcnt")) else set()
+            dsts = regs_of(ops[1].split(",", 1)[0]) if len(ops) > 1 and not t2.startswith(("global_store", "ds_write", "s_")) else set()
+            if not a2 and dsts & dst and not covered:
+                problems.append(f"{name}: `{t2}` overwrites {t.split(',')[0].split()[-1]} while its asm load may still be in flight")
+                break
             if not m and srcs & dst and not covered:
                 problems.append(f"{name}: `{t2}` reads {t.split(',')[0].split()[-1]} before a covering wait "
                                 f"({younger} younger operations issued)")
@@ -131,20 +155,26 @@ def audit(name, body):
 
 
 def main():
+    # (source, kernel-name test): every instance whose block / k loop issues its loads from inline asm
+    targets = [("panel.hip", lambda n: "panel_kernel" in n and n.endswith("Lb1EEEvNS_11PanelParamsE")),
+               ("img3x3.hip", lambda n: "img3x3_kernel" in n)]
     if len(sys.argv) > 1:
-        path = sys.argv[1]
+        files = [(a, None) for a in sys.argv[1:]]
     else:
-        path = "/tmp/msfwsi_panel_audit.s"
-        src = os.path.join(ROOT, "msf_wsi_amd", "csrc", "panel.hip")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics",
-                        "-Wno-inline-asm", "-S", "--cuda-device-only", src, "-o", path], check=True,
-                       stderr=subprocess.DEVNULL)
-    lines = open(path).read().splitlines()
+        files = []
+        for src, _ in targets:
+            path = f"/tmp/msfwsi_audit_{src}.s"
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics",
+                            "-Wno-inline-asm", "-S", "--cuda-device-only", os.path.join(ROOT, "msf_wsi_amd", "csrc", src),
+                            "-o", path], check=True, stderr=subprocess.DEVNULL)
+            files.append((path, src))
     found, n = [], 0
-    for name, body in kernels(lines):
-        if "panel_kernel" in name and name.endswith("Lb1EEEvNS_11PanelParamsE"):
-            n += 1
-            found += audit(name, body)
+    for path, _ in files:
+        lines = open(path).read().splitlines()
+        for name, body in kernels(lines):
+            if any(test(name) for _, test in targets):
+                n += 1
+                found += audit(name, body)
     print(f"{n} hand-counted instances audited, {len(found)} findings")
     for f in found:
         print("  " + f)

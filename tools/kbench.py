@@ -259,7 +259,47 @@ def case_deep():
         del x, y, dy, dx, dw
 
 
-CASES = {"panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+def case_img3():
+    """conv2 of layer2 / layer3: the image-stationary kernel (csrc/img3x3.hip) beside the gather kernel the engine runs"""
+    for H, Cn in ((14, 256), (28, 128)):
+        N = NIMG
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cn, Cn, 3, 3, 1, 1)
+        assert kn.img3x3_supported(d)
+        x = rnd(M, Cn)
+        w = rnd(Cn, 9 * Cn, scale=0.05).view(Cn, 3, 3, Cn)
+        wf = kn.img3x3_pack_weights(w, torch.empty_like(w), False)
+        wb = kn.img3x3_pack_weights(w, torch.empty_like(w), True)
+        y = torch.empty(M, Cn, dtype=DT, device="cuda")
+        a = torch.empty(M, Cn, dtype=DT, device="cuda")
+        dy = rnd(M, Cn, scale=0.05)
+        dx = torch.empty(M, Cn, dtype=DT, device="cuda")
+        dc = torch.empty(M, Cn, dtype=DT, device="cuda")
+        sc, sh = torch.rand(Cn, device="cuda") + 0.5, torch.randn(Cn, device="cuda") * 0.3
+        k1, k2, k3 = torch.rand(Cn, device="cuda"), torch.randn(Cn, device="cuda") * 0.1, torch.randn(Cn, device="cuda") * 0.01
+        fl = 2.0 * M * Cn * Cn * 9
+        nb = 2 * M * Cn * 2
+        tag = f"img3 {H}x{H} C{Cn}"
+        report(f"{tag} fwd gather (+stats)", timeit(lambda: kn.conv_fwd(d, x, w, y, stats=kn.new_stats(Cn, 2, "cuda"))), nb, fl)
+        report(f"{tag} fwd image (+stats)", timeit(lambda: kn.img3x3_fwd(d, x, wf, y, stats=kn.new_stats(Cn, 2, "cuda"))), nb, fl)
+        report(f"{tag} bn_act + fwd gather", timeit(lambda: (kn.bn_act(x, sc, sh, a, relu=True),
+                                                          kn.conv_fwd(d, a, w, y, stats=kn.new_stats(Cn, 2, "cuda")))), nb * 2, fl)
+        report(f"{tag} fwd image, BN+ReLU in the staging",
+               timeit(lambda: kn.img3x3_fwd(d, x, wf, y, stats=kn.new_stats(Cn, 2, "cuda"), pro=(sc, sh))), nb, fl)
+        report(f"{tag} dgrad gather + gate", timeit(lambda: kn.conv_dgrad(d, dy, w, dx, mask=(x, sc, sh), sums=kn.new_stats(Cn, 2, "cuda"))),
+               nb + M * Cn * 2, fl)
+        report(f"{tag} dgrad image + gate", timeit(lambda: kn.img3x3_dgrad(d, dy, wb, dx, mask=(x, sc, sh), sums=kn.new_stats(Cn, 2, "cuda"))),
+               nb + M * Cn * 2, fl)
+        report(f"{tag} bn_bwd_apply + dgrad gather + gate",
+               timeit(lambda: (kn.bn_bwd_apply(dy, y, k1, k2, k3, dc),
+                               kn.conv_dgrad(d, dc, w, dx, mask=(x, sc, sh), sums=kn.new_stats(Cn, 2, "cuda")))), nb * 2 + 2 * M * Cn * 2, fl)
+        report(f"{tag} dgrad image + gate, BN backward in the staging (dc written)",
+               timeit(lambda: kn.img3x3_dgrad(d, dy, wb, dx, bnbwd=(y, k1, k2, k3), dc_out=dc, mask=(x, sc, sh),
+                                              sums=kn.new_stats(Cn, 2, "cuda"))), nb * 2 + M * Cn * 2, fl)
+        del x, y, a, dy, dx, dc
+
+
+CASES = {"img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():
