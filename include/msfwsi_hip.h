@@ -176,10 +176,14 @@ int msfwsi_img3x3_fwd(const msfwsi_conv_desc* d, const void* x, const float* pro
 /* dx = gate(conv3x3_transpose(dc, W)), sums as in msfwsi_conv_dgrad with mask_c; dc = k1*dy + k2*c + k3 when c != NULL (the
  * BatchNorm backward of the layer whose raw output is c, formed while the band is staged; dc_out (nullable) receives it
  * for the weight gradient; it may alias dy only at 14x14, where a workgroup owns a whole image: bands of a 28x28 image read
- * their halo rows from each other's gradient), else dy. */
+ * their halo rows from each other's gradient), else dy.  act_out (nullable, needs mask_c): receives the gating activation
+ * relu(mask_scale*mask_c + mask_shift) -- what msfwsi_bn_act would write -- which is this conv's forward operand and so the
+ * operand of its weight gradient (src/models/resnet.py:125-128 backwards: three stand-alone passes of a Bottleneck's backward
+ * become by-products of this launch). */
 int msfwsi_img3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c, const float* k1, const float* k2,
                         const float* k3, void* dc_out, const void* wpk, void* dx, const void* mask_c,
-                        const float* mask_scale, const float* mask_shift, double* sums, int nshard, void* stream);
+                        const float* mask_scale, const float* mask_shift, void* act_out, double* sums, int nshard,
+                        void* stream);
 
 /* Specialised 3x3 / stride 1 / pad 1 path: the input patch of 256 raster pixels (+ halo) is staged once per
  * channel slab in LDS and reused by all nine taps (see csrc/conv3x3.hip).  Same results as msfwsi_conv_fwd /

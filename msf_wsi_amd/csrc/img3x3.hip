@@ -20,6 +20,16 @@
 #include "handload.h"
 #include "../../include/msfwsi_hip.h"
 
+#ifndef MSFWSI_IMG_TN
+#define MSFWSI_IMG_TN 1  // 32-channel blocks per wave: 1 = eight / four waves of 32 channels, two per SIMD; 2 = four / two
+#endif                   // waves of 64 (half the LDS reads per MFMA, one wave per SIMD: slower but for the 14x14 forward)
+#ifndef MSFWSI_IMG_STAGGER
+#define MSFWSI_IMG_STAGGER 40  // x 64 clocks between the eight start phases of the first round (0: off); -6 % on the 14x14 forward, neutral elsewhere (profiles/r05_img3_stagger.txt)
+#endif
+#ifndef MSFWSI_IMG_ABLATE
+#define MSFWSI_IMG_ABLATE 0  // diagnostic builds (tools/build_variant.sh), WRONG RESULTS: 1 no staging loads, 2 one tap instead
+#endif                       // of nine, 4 no output stores / mask loads, 8 no weight re-loads, 16 no LDS reads in the k loop
+
 namespace {
 
 struct Img3Params {
@@ -36,23 +46,26 @@ struct Img3Params {
     const void* mask_c;       // gradient: [N][H][W][KO] raw conv output whose BatchNorm+ReLU gates it, nullable
     const float* mask_scale;
     const float* mask_shift;
+    void* act_out;            // gradient, nullable (needs mask_c): relu(mask_scale * mask_c + mask_shift) [N][H][W][KO], = msfwsi_bn_act
     int N, H;
 };
 
 __device__ __forceinline__ int img_swz(int row) { return row & 15; }  // rows are >= 256 bytes: see panel.hip panel_swz
 
-template <typename T, int C, int KO, int BH, int IW, int PRO, bool DGRAD>
-__global__ __launch_bounds__(KO * 2, 2) void img3x3_kernel(const Img3Params prm) {
-    constexpr int NW = KO / 32, NT = 64 * NW;
+template <typename T, int C, int KO, int BH, int IW, int PRO, bool DGRAD, int TN>
+__global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3Params prm) {
+    constexpr int NW = KO / (32 * TN), NT = 64 * NW;
     constexpr int PW = IW + 2, PP = (BH + 2) * PW;  // padded positions of the band
     constexpr int CPR = C / 8, ROWB = C * 2;
-    constexpr int NCH = (PP * CPR + NT - 1) / NT;    // 16-byte chunks staged per thread
+    constexpr int NCHT = (PP * CPR + NT - 1) / NT;   // 16-byte chunks staged per thread,
+    constexpr int NPASS = (NCHT + 15) / 16;          // at most 16 in flight at a time
+    constexpr int NCH = (NCHT + NPASS - 1) / NPASS;
     constexpr int MB = BH * IW;                      // output pixels of the band
     constexpr int TM = (MB + 31) / 32;
     constexpr int KC = C / 16;                       // k steps per tap
     constexpr int R = 4;                             // weight-fragment ring
     constexpr int SCR_PITCH = 80, SCR_BYTES = 32 * SCR_PITCH;
-    static_assert(C % 128 == 0 && KO % 32 == 0 && NT % CPR == 0 && KC % R == 0, "image kernel geometry");
+    static_assert(C % 128 == 0 && KO % (32 * TN) == 0 && NT % CPR == 0 && KC % R == 0 && (TN == 1 || TN == 2), "image kernel geometry");
     typedef typename MmaFrag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,22 +81,19 @@ __global__ __launch_bounds__(KO * 2, 2) void img3x3_kernel(const Img3Params prm)
     const int row0 = band * BH;                                   // first image row of the band
     const long pix0 = ((long)image * prm.H + row0) * IW;          // first output pixel (bands are contiguous in memory)
 
+#if MSFWSI_IMG_STAGGER
+    // Workgroups of equal length that start together stay together: all 256 CUs stage at once (an HBM burst nobody computes
+    // under), then all compute (HBM idle).  The first round starts in eight phases, MSFWSI_IMG_STAGGER * 64 clocks apart.
+    if (blockIdx.x < 256u * (PP * ROWB <= 72 * 1024 ? 2 : 1)) {
+        const int g = (blockIdx.x >> 3) & 7;
+        for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(MSFWSI_IMG_STAGGER);
+    }
+#endif
     // ---------------- stage the band + halo: every chunk requested up front (clamped addresses, no branches) ----------------
     {
         const int cc = tid % CPR;
         const char* src_img = reinterpret_cast<const char*>(prm.src) + (long)image * prm.H * IW * ROWB;
         const char* srcc_img = PRO == 2 ? reinterpret_cast<const char*>(prm.src_c) + (long)image * prm.H * IW * ROWB : nullptr;
-        uint4 v[NCH], vc[PRO == 2 ? NCH : 1];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int pos = (tid + i * NT) / CPR;
-            const int ph = pos / PW, pw = pos - ph * PW;
-            const int hh = row0 + ph - 1, ww = pw - 1;
-            const bool ok = pos < PP && hh >= 0 && hh < prm.H && ww >= 0 && ww < IW;
-            const unsigned off = (unsigned)((ok ? hh * IW + ww : row0 * IW) * ROWB + cc * 16);
-            v[i] = *reinterpret_cast<const uint4*>(src_img + off);
-            if constexpr (PRO == 2) vc[i] = *reinterpret_cast<const uint4*>(srcc_img + off);
-        }
         float c0[PRO ? 8 : 1], c1[PRO ? 8 : 1], c2[PRO == 2 ? 8 : 1];
         if constexpr (PRO != 0) {
 #pragma unroll
@@ -94,9 +104,24 @@ __global__ __launch_bounds__(KO * 2, 2) void img3x3_kernel(const Img3Params prm)
             }
         }
         char* aout_img = PRO == 2 && prm.aout != nullptr ? reinterpret_cast<char*>(prm.aout) + (long)image * prm.H * IW * ROWB : nullptr;
+#pragma unroll  // (straight-line: behind a run-time loop hipcc's wait-count pass turns conservative and drains the weight ring
+                // with a vmcnt(0) of its own at the top of every filter tap)
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int tbase = tid + pass * NCH * NT;
+        uint4 v[NCH], vc[PRO == 2 ? NCH : 1];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int pos = (tid + i * NT) / CPR;
+            const int pos = (tbase + i * NT) / CPR;
+            const int ph = pos / PW, pw = pos - ph * PW;
+            const int hh = row0 + ph - 1, ww = pw - 1;
+            const bool ok = pos < PP && hh >= 0 && hh < prm.H && ww >= 0 && ww < IW;
+            const unsigned off = (unsigned)((ok ? hh * IW + ww : row0 * IW) * ROWB + cc * 16);
+            v[i] = (MSFWSI_IMG_ABLATE & 1) ? make_uint4(off, 0, 0, 0) : *reinterpret_cast<const uint4*>(src_img + off);
+            if constexpr (PRO == 2) vc[i] = (MSFWSI_IMG_ABLATE & 1) ? make_uint4(off, 0, 0, 0) : *reinterpret_cast<const uint4*>(srcc_img + off);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int pos = (tbase + i * NT) / CPR;
             const int ph = pos / PW, pw = pos - ph * PW;
             const int hh = row0 + ph - 1, ww = pw - 1;
             const bool ok = pos < PP && hh >= 0 && hh < prm.H && ww >= 0 && ww < IW;
@@ -121,15 +146,23 @@ __global__ __launch_bounds__(KO * 2, 2) void img3x3_kernel(const Img3Params prm)
             if (!ok) t = make_uint4(0, 0, 0, 0);  // zero padding AFTER the transform (relu(shift) is not zero)
             if (pos < PP) *reinterpret_cast<uint4*>(img + pos * ROWB + ((cc ^ img_swz(pos)) << 4)) = t;
         }
+      }
     }
-    // the first R weight fragments of this wave's channel block, then the only barrier
-    const char* wb = reinterpret_cast<const char*>(prm.wpk) + (long)wave * (9 * KC) * 1024;
-    u32x4 wf[R];
+    // A wait hipcc can see: its wait-count pass otherwise carries "a staging load may still be writing v54 / v64" into the
+    // k loop (the staging loads sit in exec-masked branches) and guards the first re-use of those registers with a
+    // vmcnt(0) of its own at the top of EVERY filter tap -- which drains the weight ring nine times per workgroup.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
+    // the first R steps' weight fragments of this wave's channel blocks (TN per step), then the only barrier
+    const char* wb = reinterpret_cast<const char*>(prm.wpk) + (long)wave * TN * (9 * KC) * 1024;
+    constexpr unsigned NBLK = 9 * KC * 1024;  // bytes between the fragment streams of two channel blocks
+    u32x4 wf[R][TN];
 #pragma unroll
-    for (int i = 0; i < R; ++i) pl_load16<true>(wf[i], wb, (unsigned)(i * 1024 + lane * 16));
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) pl_load16<true>(wf[i][n], wb, (unsigned)(n * NBLK + i * 1024 + lane * 16));
     __syncthreads();
 
-    // ---------------- the k loop: 9 taps x KC steps, 7 MFMAs per weight fragment ----------------
+    // ---------------- the k loop: 9 taps x KC steps, 7 * TN MFMAs per step ----------------
     int pos0[TM];  // padded position of the window origin of this lane's pixel in row tile tm (0 for the padding rows)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
@@ -137,15 +170,17 @@ __global__ __launch_bounds__(KO * 2, 2) void img3x3_kernel(const Img3Params prm)
         const int h = p / IW, w = p - h * IW;
         pos0[tm] = p < MB ? h * PW + w : 0;
     }
-    f32x16 acc[TM];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[tm][n][j] = 0.f;
 
-    int step = 0;  // fragments consumed so far (the ring slot is step % R: static inside the unrolled tap body)
+    int step = 0;  // steps consumed so far (the ring slot is step % R: static inside the unrolled tap body)
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < ((MSFWSI_IMG_ABLATE & 2) ? 1 : 9); ++tap) {
         const int r = tap / 3, s_ = tap - r * 3;
         const int shift = r * PW + s_;
         int rowb[TM], sw[TM];
@@ -155,111 +190,141 @@ __global__ __launch_bounds__(KO * 2, 2) void img3x3_kernel(const Img3Params prm)
             rowb[tm] = row * ROWB;
             sw[tm] = img_swz(row) ^ lh;  // chunk (2 kc + lh) ^ swz = (2 kc) ^ (lh ^ swz)
         }
-        frag_t xc[TM];
+        frag_t xc[TM], xn[TN == 2 ? TM : 1];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) xc[tm] = *reinterpret_cast<const frag_t*>(img + rowb[tm] + ((0 ^ sw[tm]) << 4));
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            pl_wait<true, R - 1>(wf[kc % R]);
-            const frag_t wfr = __builtin_bit_cast(frag_t, wf[kc % R]);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                mma32<T>(acc[tm], wfr, xc[tm]);
-                if (kc + 1 < KC) xc[tm] = *reinterpret_cast<const frag_t*>(img + rowb[tm] + (((2 * (kc + 1)) ^ sw[tm]) << 4));
+            // the ring holds R steps of TN fragments, oldest first: all but the (R - 1) * TN youngest have landed
+            frag_t wfr[TN];
+            if constexpr (TN == 1) {
+                pl_wait<true, R - 1>(wf[kc % R][0]);
+            } else {
+                pl_wait<true, (R - 1) * TN>(wf[kc % R][0]);
+                pl_wait<true, (R - 1) * TN>(wf[kc % R][1]);
             }
-            // the fragment R steps ahead takes the slot just consumed (past the end: the last fragment again, never used)
-            const int nxt = step + kc + R < 9 * KC ? step + kc + R : 9 * KC - 1;
-            pl_load16<true>(wf[kc % R], wb, (unsigned)(nxt * 1024 + lane * 16));
+#pragma unroll
+            for (int n = 0; n < TN; ++n) wfr[n] = __builtin_bit_cast(frag_t, wf[kc % R][n]);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (kc + 1 < KC) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int n = 0; n < TN; ++n) mma32<T>(acc[tm][n], wfr[n], xc[tm]);
+                if (kc + 1 < KC && !(MSFWSI_IMG_ABLATE & 16)) {
+                    const frag_t nx = *reinterpret_cast<const frag_t*>(img + rowb[tm] + (((2 * (kc + 1)) ^ sw[tm]) << 4));
+                    if constexpr (TN == 2) xn[tm] = nx; else xc[tm] = nx;
+                }
+            }
+            if constexpr (TN == 2) {
+                if (kc + 1 < KC) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) xc[tm] = xn[tm];
+                }
+            }
+            // the step R ahead takes the slots just consumed (past the end: the last step again, never used)
+            const int nxt = step + kc + R < 9 * KC ? step + kc + R : 9 * KC - 1;
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                if (!(MSFWSI_IMG_ABLATE & 8)) pl_load16<true>(wf[kc % R][n], wb, (unsigned)(n * NBLK + nxt * 1024 + lane * 16));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+                if (kc + 1 < KC && !(MSFWSI_IMG_ABLATE & 16)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         step += KC;
     }
-    // the ring's trailing re-requests are still in flight: the wait NAMES their registers, so that hipcc cannot hand them to
+    // the ring's trailing re-requests are still in flight: the waits NAME their registers, so that hipcc cannot hand them to
     // the epilogue's address arithmetic before the loads have landed (it did: tools/check_hand_waits.py)
-    static_assert(R == 4, "the final wait lists the ring slots");
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]) : : "memory");
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) pl_drain<true>(wf[i][n]);
 
     // ---------------- epilogue: 16-byte row chunks through the wave's scratch; statistics / gate + sums ----------------
     const int q = lane & 3, r4 = lane >> 2;
-    const int ncol = wave * 32 + q * 8;
     T* __restrict__ out = reinterpret_cast<T*>(prm.out) + pix0 * KO;
     const T* __restrict__ mask_c = DGRAD ? reinterpret_cast<const T*>(prm.mask_c) : nullptr;
     if (mask_c != nullptr) mask_c += pix0 * KO;
-    uint4 mk[DGRAD ? TM * 2 : 1];
-    float msc[8], msh[8];
-    if constexpr (DGRAD) {
-        if (mask_c != nullptr) {
+    T* __restrict__ act = DGRAD && prm.act_out != nullptr ? reinterpret_cast<T*>(prm.act_out) + pix0 * KO : nullptr;
 #pragma unroll
-            for (int t = 0; t < TM * 2; ++t) {
-                const int p = (t >> 1) * 32 + (t & 1) * 16 + r4;
-                mk[t] = *reinterpret_cast<const uint4*>(mask_c + (long)(p < MB ? p : 0) * KO + ncol);
-            }
+    for (int n = 0; n < TN; ++n) {
+        const int ncol = (wave * TN + n) * 32 + q * 8;
+        uint4 mk[DGRAD ? TM * 2 : 1];
+        float msc[8], msh[8];
+        if constexpr (DGRAD) {
+            if (mask_c != nullptr) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                msc[e] = prm.mask_scale[ncol + e];
-                msh[e] = prm.mask_shift[ncol + e];
+                for (int t = 0; t < TM * 2; ++t) {
+                    const int p = (t >> 1) * 32 + (t & 1) * 16 + r4;
+                    mk[t] = (MSFWSI_IMG_ABLATE & 4) ? make_uint4(p, 1, 2, 3) : *reinterpret_cast<const uint4*>(mask_c + (long)(p < MB ? p : 0) * KO + ncol);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    msc[e] = prm.mask_scale[ncol + e];
+                    msh[e] = prm.mask_shift[ncol + e];
+                }
             }
         }
-    }
-    float s0[8], s1[8];
+        float s0[8], s1[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+        for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<uint2*>(scratch + l31 * SCR_PITCH + (8 * g + 4 * lh) * 2) =
-                pack4<T>(acc[tm][4 * g], acc[tm][4 * g + 1], acc[tm][4 * g + 2], acc[tm][4 * g + 3]);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2*>(scratch + l31 * SCR_PITCH + (8 * g + 4 * lh) * 2) =
+                    pack4<T>(acc[tm][n][4 * g], acc[tm][n][4 * g + 1], acc[tm][n][4 * g + 2], acc[tm][n][4 * g + 3]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = tm * 32 + i * 16 + r4;
-            uint4 cv = *reinterpret_cast<const uint4*>(scratch + (i * 16 + r4) * SCR_PITCH + q * 16);
-            if (p < MB) {
-                float f[8];
-                unpack16<T>(cv, f);
-                if constexpr (DGRAD) {
-                    if (mask_c != nullptr) {
-                        float c[8];
-                        unpack16<T>(mk[tm * 2 + i], c);
+            for (int i = 0; i < 2; ++i) {
+                const int p = tm * 32 + i * 16 + r4;
+                uint4 cv = *reinterpret_cast<const uint4*>(scratch + (i * 16 + r4) * SCR_PITCH + q * 16);
+                if (p < MB) {
+                    float f[8];
+                    unpack16<T>(cv, f);
+                    if constexpr (DGRAD) {
+                        if (mask_c != nullptr) {
+                            float c[8], a[8];
+                            unpack16<T>(mk[tm * 2 + i], c);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                a[e] = fmaxf(fmaf(c[e], msc[e], msh[e]), 0.f);
+                                if (!(a[e] > 0.f)) f[e] = 0.f;
+                                s0[e] += f[e];
+                                s1[e] = fmaf(f[e], c[e], s1[e]);
+                            }
+                            cv = pack16<T>(f);
+                            // the gating activation itself, for the weight gradient of this conv (its operand): the
+                            // stand-alone msfwsi_bn_act pass would re-read c for it
+                            if (act != nullptr) *reinterpret_cast<uint4*>(act + (long)p * KO + ncol) = pack16<T>(a);
+                        }
+                    } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            if (!(fmaf(c[e], msc[e], msh[e]) > 0.f)) f[e] = 0.f;
                             s0[e] += f[e];
-                            s1[e] = fmaf(f[e], c[e], s1[e]);
+                            s1[e] = fmaf(f[e], f[e], s1[e]);
                         }
-                        cv = pack16<T>(f);
                     }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        s0[e] += f[e];
-                        s1[e] = fmaf(f[e], f[e], s1[e]);
-                    }
+                    if (!(MSFWSI_IMG_ABLATE & 4) || cv.x == 0x12345u) *reinterpret_cast<uint4*>(out + (long)p * KO + ncol) = cv;
                 }
-                *reinterpret_cast<uint4*>(out + (long)p * KO + ncol) = cv;
             }
         }
-    }
-    if (prm.stats != nullptr) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) {
-                s0[e] += __shfl_xor(s0[e], off, 64);
-                s1[e] += __shfl_xor(s1[e], off, 64);
-            }
-        }
-        if (lane < 4) {
-            double* dst = prm.stats + (long)(blockIdx.x % prm.nshard) * 2 * KO + ncol;
+        if (prm.stats != nullptr) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                atomicAdd(dst + e, (double)s0[e]);
-                atomicAdd(dst + KO + e, (double)s1[e]);
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) {
+                    s0[e] += __shfl_xor(s0[e], off, 64);
+                    s1[e] += __shfl_xor(s1[e], off, 64);
+                }
+            }
+            if (lane < 4) {
+                double* dst = prm.stats + (long)(blockIdx.x % prm.nshard) * 2 * KO + ncol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    atomicAdd(dst + e, (double)s0[e]);
+                    atomicAdd(dst + KO + e, (double)s1[e]);
+                }
             }
         }
     }
@@ -285,15 +350,16 @@ __global__ void img3x3_pack_kernel(const U* __restrict__ w, U* __restrict__ wpk,
 template <typename T, int C, int BH, int IW, int PRO, bool DGRAD>
 int launch_img(const Img3Params& prm, hipStream_t stream) {
     constexpr int KO = C;
-    constexpr int LDS = (BH + 2) * (IW + 2) * C * 2 + (KO / 32) * 32 * 80;
-    void (*kern)(const Img3Params) = img3x3_kernel<T, C, KO, BH, IW, PRO, DGRAD>;
+    constexpr int TN = MSFWSI_IMG_TN;
+    constexpr int LDS = (BH + 2) * (IW + 2) * C * 2 + (KO / (32 * TN)) * 32 * 80;
+    void (*kern)(const Img3Params) = img3x3_kernel<T, C, KO, BH, IW, PRO, DGRAD, TN>;
     if (LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
     }
     const long nwg = (long)prm.N * (prm.H / BH);
     if (nwg <= 0 || nwg > 0x7fffffffL) return MSFWSI_EINVAL;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(KO * 2), LDS, stream, prm);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(KO * 2 / TN), LDS, stream, prm);
     return msfwsi_launch_status();
 }
 
@@ -339,20 +405,22 @@ extern "C" int msfwsi_img3x3_fwd(const msfwsi_conv_desc* d, const void* x, const
 
 extern "C" int msfwsi_img3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c, const float* k1, const float* k2,
                                    const float* k3, void* dc_out, const void* wpk, void* dx, const void* mask_c,
-                                   const float* mask_scale, const float* mask_shift, double* sums, int nshard, void* stream) {
+                                   const float* mask_scale, const float* mask_shift, void* act_out, double* sums, int nshard,
+                                   void* stream) {
     if (!msfwsi_img3x3_supported(d)) return d == nullptr ? MSFWSI_EINVAL : MSFWSI_EUNSUPPORTED;
     MSFWSI_CHECK_ARG(dy != nullptr && wpk != nullptr && dx != nullptr);
     const bool pro = c != nullptr;
     MSFWSI_CHECK_ARG(pro == (k1 != nullptr) && pro == (k2 != nullptr) && pro == (k3 != nullptr) && (pro || dc_out == nullptr));
     MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
     MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
+    MSFWSI_CHECK_ARG(act_out == nullptr || (mask_c != nullptr && act_out != mask_c && act_out != dx));
     // a band reads its halo rows from the gradient of the NEIGHBOURING bands: written back in place, a neighbour's rows could
     // already hold dc instead of g.  In place only where a workgroup owns the whole image (14 x 14).
     MSFWSI_CHECK_ARG(dc_out == nullptr || dc_out != dy || d->H == 14);
     Img3Params prm{};
     prm.src = dy; prm.src_c = c; prm.p0 = k1; prm.p1 = k2; prm.p2 = k3; prm.aout = dc_out;
     prm.wpk = wpk; prm.out = dx;
-    prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
+    prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift; prm.act_out = act_out;
     prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
     prm.N = d->N; prm.H = d->H;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

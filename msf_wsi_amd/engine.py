@@ -323,6 +323,9 @@ class Engine:
         self.multirank_streams = os.environ.get("MSFWSI_MULTIRANK_STREAMS", "1") != "0"
         self.panel_fwd = os.environ.get("MSFWSI_PANEL_FWD", "1") != "0"
         self.panel_dgrad = os.environ.get("MSFWSI_PANEL_DGRAD", "1") != "0"
+        # conv2 of layer2 / layer3 on the image-stationary kernels (csrc/img3x3.hip): bn1 + ReLU in the forward staging, bn2's
+        # backward in the gradient staging, a1 for the weight gradient as a by-product of the gradient's gate
+        self.img3x3 = os.environ.get("MSFWSI_IMG3X3", "1") != "0"
         self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
         self.panel_fwd_min_k = int(os.environ.get("MSFWSI_PANEL_FWD_MIN_K", "128"))  # 56x56 / 64 channels: the gather kernel is at the HBM roof
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
@@ -473,6 +476,9 @@ class Engine:
                             if m.stride == (1, 1) and m.bias is None:
                                 self._panel_weights(m, w, dtype, dgrad=False)
                                 self._panel_weights(m, w, dtype, dgrad=True)
+                        if isinstance(m, nn.Conv2d):
+                            self._img3_weights(m, w, dtype, dgrad=False)
+                            self._img3_weights(m, w, dtype, dgrad=True)
 
     def _msg_buf(self, kind: str, n: int, dev) -> torch.Tensor:
         """pre-allocated fp64 message buffer of the cross-replica BatchNorm exchange, one per (direction, length).
@@ -713,6 +719,15 @@ class Engine:
         bias = getattr(op, "bias", None)
         xin, pro = x, (x_pro.scale, x_pro.shift) if x_pro is not None else None
         fuse_pro = (pro is not None and self.fuse_pro3x3 and bias is None and not pad_c and kn.conv3x3_stationary(d))
+        wimg = self._img3_weights(op, w, dtype, dgrad=False) if not pad_c and kn.img3x3_supported(d) else None
+        if wimg is not None:
+            # image-stationary kernel: the band is staged once, BatchNorm + ReLU of the producer applied on the way
+            if not kn.img3x3_fwd(d, x, wimg, c, stats=stats, pro=pro):
+                raise _lib.MsfwsiHipError("img3x3_fwd refused a geometry msfwsi_img3x3_supported accepted")
+            u = Unit(op, bn, relu, d, x, x_pro, c)
+            if bn is not None:
+                u.st = self._bn_finalize(stats, N * d.P * d.Q, bn)
+            return u
         if fuse_pro:
             pass  # the weights-stationary 3x3 kernel applies BatchNorm + ReLU on the way into LDS: nothing to materialise
         elif pro is not None and self.materialize_3x3 and (R * S > 1 or (self.materialize_1x1 and N * H * W >= self.mat_min_rows)):
@@ -826,6 +841,17 @@ class Engine:
         if dgrad:  # the forward tensor read as the [k = K][n = C] operand
             return self.weights.derived("panel_dgrad", w, lambda t: kn.panel_pack_weights(t, torch.empty_like(t), Cn, K, 1, Cn))
         return self.weights.derived("panel_fwd", w, lambda t: kn.panel_pack_weights(t, torch.empty_like(t), K, Cn, Cn, 1))
+
+    def _img3_weights(self, op: nn.Module, w: torch.Tensor, dtype, dgrad: bool) -> Optional[torch.Tensor]:
+        """a 3x3 / stride 1 conv weight [K][3][3][C] of the widths the image-stationary kernels serve, in the fragment order
+        they stream (msfwsi_img3x3_pack_weights; the gradient's copy transposed with flipped taps); shared by the passes of
+        a step like _panel_weights.  None for every other layer."""
+        if (not self.img3x3 or dtype == torch.float32 or not isinstance(op, nn.Conv2d) or op.kernel_size != (3, 3)
+                or op.stride != (1, 1) or op.padding != (1, 1) or op.groups != 1 or op.bias is not None
+                or op.in_channels != op.out_channels or op.in_channels not in (128, 256)):
+            return None
+        return self.weights.derived("img3_dgrad" if dgrad else "img3_fwd", w,
+                                    lambda t: kn.img3x3_pack_weights(t, torch.empty_like(t), dgrad))
 
     def _f32_of(self, w16: torch.Tensor) -> torch.Tensor:
         """fp32 copy of a 16-bit weight tensor, shared by the passes of one step (dropped by invalidate_weights)"""
@@ -1385,8 +1411,12 @@ class Engine:
                 resid = self._unit_dgrad(rec.ds, g, dtype)
             prev = rec.units[1]
             kp = self._bn_bwd_coeffs(s2, 2, 1, prev.bn, prev.st, grads)
-            kn.bn_bwd_apply(da, prev.c, kp[0], kp[1], kp[2], da)
-            return self._block_bwd_tail(rec, da, 1, resid, grads, dtype, gate=gate, resid_stride=rstride)
+            top_bn = None
+            if self._img3_dgrad_weights(prev, rec.units[0], dtype) is not None:
+                top_bn = (prev.c, kp)  # bn2's backward is formed inside conv2's input-gradient launch (image-stationary kernel)
+            else:
+                kn.bn_bwd_apply(da, prev.c, kp[0], kp[1], kp[2], da)
+            return self._block_bwd_tail(rec, da, 1, resid, grads, dtype, gate=gate, resid_stride=rstride, top_bn=top_bn)
         if pre is not None:
             raise RuntimeError("a pre-gated gradient reached a block that is not on the folded path")
         last = rec.units[-1]
@@ -1435,19 +1465,49 @@ class Engine:
             return False
         return kn.panel_supported(first.desc, True)
 
+    def _img3_dgrad_weights(self, u: Unit, prev: Unit, dtype) -> Optional[torch.Tensor]:
+        """the packed filter if u's input gradient runs on the image-stationary kernel: a served 3x3 geometry whose operand
+        is prev's raw output under prev's BatchNorm + ReLU (conv2 of a Bottleneck of layer2 / layer3), else None"""
+        if u.x_pro is None or u.x is not prev.c or prev.st is None or u.s2d or not kn.img3x3_supported(u.desc):
+            return None
+        return self._img3_weights(u.op, self.weights.get(u.op.weight, dtype), dtype, dgrad=True)
+
     def _block_bwd_tail(self, rec: BlockRec, cur, top: int, resid, grads: GradStore, dtype, last_xmat=None,
-                        gate=None, resid_stride: int = 1):
+                        gate=None, resid_stride: int = 1, top_bn=None):
         """units[top] .. units[0]: weight gradient, input gradient with the producer's ReLU gate + BatchNorm sums
-        fused into its epilogue, BatchNorm backward; the first unit adds the identity-path gradient `resid`"""
+        fused into its epilogue, BatchNorm backward; the first unit adds the identity-path gradient `resid`.
+        top_bn = (c, (k1, k2, k3)): `cur` is still the gradient w.r.t. units[top]'s BatchNorm OUTPUT and the caller has
+        checked (_img3_dgrad_weights) that units[top]'s input-gradient launch forms the BatchNorm backward itself."""
         dev = cur.device
         fused = None
         for i in range(top, 0, -1):
             u, prev = rec.units[i], rec.units[i - 1]
-            self._unit_wgrad(u, cur, grads, dtype, x_mat=last_xmat)
-            last_xmat = None
             s2 = kn.new_stats(prev.c.shape[-1], 2, dev)
-            # ReLU gate of prev and its BatchNorm-backward sums are fused into the dgrad epilogue
-            da = self._unit_dgrad(u, cur, dtype, mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2)
+            wimg = self._img3_dgrad_weights(u, prev, dtype)
+            bn_here = top_bn if i == top else None
+            if wimg is not None:
+                # ONE launch: dc = bn backward of `cur` while the band is staged (written for the weight gradient: in place
+                # where a workgroup owns the whole image), da = gate(conv^T(dc)) + bn1's sums, and a1 = relu(bn1(c1)) --
+                # the weight gradient's operand -- stored from the gate's own arithmetic
+                d = u.desc
+                da = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dev)
+                a1 = torch.empty_like(prev.c)
+                dc, bnb = cur, None
+                if bn_here is not None:
+                    dc = cur if d.H == 14 else torch.empty_like(cur)
+                    bnb = (bn_here[0], bn_here[1][0], bn_here[1][1], bn_here[1][2])
+                if not kn.img3x3_dgrad(d, cur, wimg, da, bnbwd=bnb, dc_out=dc if bnb is not None else None,
+                                       mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2, act_out=a1):
+                    raise _lib.MsfwsiHipError("img3x3_dgrad refused a geometry msfwsi_img3x3_supported accepted")
+                self._unit_wgrad(u, dc, grads, dtype, x_mat=a1)
+                del a1, dc
+            else:
+                if bn_here is not None:
+                    raise RuntimeError("top_bn without the image-stationary kernel: the caller applies the BatchNorm backward")
+                self._unit_wgrad(u, cur, grads, dtype, x_mat=last_xmat)
+                # ReLU gate of prev and its BatchNorm-backward sums are fused into the dgrad epilogue
+                da = self._unit_dgrad(u, cur, dtype, mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2)
+            last_xmat = None
             kp = self._bn_bwd_coeffs(s2, 2, 1, prev.bn, prev.st, grads)
             if i == 1 and self._panel_dgrad_ok(rec.units[0], resid, gate):
                 fused = (da, prev.c, kp)  # bn1's backward is formed inside conv1's input-gradient launch below

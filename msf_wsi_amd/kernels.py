@@ -1305,9 +1305,10 @@ def img3x3_fwd(d: ConvDesc, x, wpk, y, stats=None, pro=None) -> bool:
     return True
 
 
-def img3x3_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, mask=None, sums=None) -> bool:
+def img3x3_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, mask=None, sums=None, act_out=None) -> bool:
     """bnbwd = (c, k1, k2, k3): the gradient operand is k1*dy + k2*c + k3 (BatchNorm backward fused into the staging),
-    written to dc_out when given; mask / sums as conv3x3_dgrad.  False where the geometry is not served."""
+    written to dc_out when given; mask / sums as conv3x3_dgrad; act_out receives relu(mask_scale*mask_c + mask_shift) (=
+    bn_act of the gating layer).  False where the geometry is not served."""
     lib = _lib.load()
     dt = dy.dtype
     n_out = d.N * d.P * d.Q * d.K
@@ -1321,6 +1322,7 @@ def img3x3_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, mask=None, s
         for nm, t in (("k1", k1), ("k2", k2), ("k3", k3)):
             _req(t, nm, torch.float32, d.K)
     _opt(dc_out, "dc_out", dt, n_out)
+    _opt(act_out, "act_out", dt, d.N * d.H * d.W * d.C)
     mc = msc = msh = None
     nsh = 1
     if mask is not None:
@@ -1335,8 +1337,10 @@ def img3x3_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, mask=None, s
     elif sums is not None:
         raise ValueError("sums without mask")
     rc = _timed("conv_dgrad", d, dy.element_size(), lambda: lib.msfwsi_img3x3_dgrad(
-        C.byref(d), _p(dy), _p(cc), _p(k1), _p(k2), _p(k3), _p(dc_out), _p(wpk), _p(dx), _p(mc), _p(msc), _p(msh), _p(sums),
-        nsh, _stream()), extra_elems=(dx.numel() if mask is not None else 0), halo=True, dtype=dy.dtype,
+        C.byref(d), _p(dy), _p(cc), _p(k1), _p(k2), _p(k3), _p(dc_out), _p(wpk), _p(dx), _p(mc), _p(msc), _p(msh), _p(act_out),
+        _p(sums), nsh, _stream()),
+        extra_elems=dx.numel() * ((mask is not None) + (act_out is not None) + (bnbwd is not None) + (dc_out is not None)),
+        halo=True, dtype=dy.dtype,
         symbol_override=_img3_symbol(d, dt, 2 if bnbwd is not None else 0, True))
     if rc == -2:
         return False

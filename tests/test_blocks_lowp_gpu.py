@@ -135,13 +135,14 @@ def _check(name, got, want, tol, worst):
     return r <= tol
 
 
-def run_blocks(arch, dtype, mutate=None):
-    """every residual block of `arch` on the product's own 16-bit block inputs; returns {tensor: rel-L2}, failures"""
+def run_blocks(arch, dtype, mutate=None, batch=None, size=None, only=None):
+    """every residual block of `arch` (only: those whose name passes) on the product's own 16-bit block inputs; returns
+    {tensor: rel-L2}, failures"""
     from msf_wsi_amd.engine import Engine, GradStore
     from oracle import msfwsi_oracle as orc
 
     vec, man = load_golden("r50enc_b16_s64_div")
-    x = orc.diverse_images(man["B"], man["size"], man["data_seed"])
+    x = orc.diverse_images(batch or man["B"], size or man["size"], man["data_seed"])
     enc = _encoder(arch).cuda().train()
     eng = Engine()
     eng.update_running = False
@@ -155,6 +156,8 @@ def run_blocks(arch, dtype, mutate=None):
     g = torch.Generator().manual_seed(11)
     worst, bad = {}, []
     for name, blk, rec in zip(names, blocks, ps.blocks):
+        if only is not None and not only(name):
+            continue
         dy = (torch.randn(rec.y_out.shape, generator=g) * 0.1).to(dtype).cuda()
         y_ref, dx_ref, g_ref = _block_oracle(blk, rec, _nchw64(rec.y_in), _nchw64(dy))
         if not _check(f"{name}: out", _nchw64(rec.y_out), y_ref, OUT_TOL[dtype], worst):
@@ -187,6 +190,42 @@ def test_every_block_within_a_few_ulp(hip_lib, stationary_forced, arch, dtype):
     worst, bad = run_blocks(arch, dtype)
     _report(f"blocks {arch} {dtype}", worst)
     assert not bad, [(k, f"{worst[k]:.2e}") for k in bad]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("arch", ["resnet50", "resnet18"])
+def test_deep_blocks_on_the_image_stationary_kernels(hip_lib, monkeypatch, arch, dtype):
+    """224 x 224 tiles put layer2 at 28x28x128 and layer3 at 14x14x256: conv2 of their stride-1 blocks runs on
+    csrc/img3x3.hip -- bn1 + ReLU inside the forward staging, bn2's backward inside the gradient staging (in place at 14x14,
+    into a second buffer at 28x28), a1 for the weight gradient written by the gradient's gate.  Same fp64 block oracle and
+    bounds as the 64 x 64 run; the launches are counted so that a silent fallback to the gather kernel fails the test."""
+    from msf_wsi_amd import kernels as kn
+
+    calls = {"fwd": 0, "dgrad": 0, "fused_bn": 0}
+    fwd, dgrad = kn.img3x3_fwd, kn.img3x3_dgrad
+
+    def count_fwd(*a, **k):
+        calls["fwd"] += 1
+        return fwd(*a, **k)
+
+    def count_dgrad(*a, **k):
+        calls["dgrad"] += 1
+        calls["fused_bn"] += k.get("bnbwd") is not None
+        assert k.get("act_out") is not None
+        return dgrad(*a, **k)
+
+    monkeypatch.setattr(kn, "img3x3_fwd", count_fwd)
+    monkeypatch.setattr(kn, "img3x3_dgrad", count_dgrad)
+    deep = lambda name: name.startswith(("layer2.", "layer3.")) and not name.endswith(".0")
+    worst, bad = run_blocks(arch, dtype, batch=3, size=224, only=deep)
+    _report(f"deep blocks {arch} {dtype}", worst)
+    assert not bad, [(k, f"{worst[k]:.2e}") for k in bad]
+    nblk = {"resnet50": 3 + 5, "resnet18": 1 + 1}[arch]
+    assert len([k for k in worst if k.endswith(": out")]) == nblk
+    if arch == "resnet50":   # conv2 of every Bottleneck of the two stages but the strided first ones; bn2 folded into each
+        assert calls == {"fwd": nblk, "dgrad": nblk, "fused_bn": nblk}
+    else:                    # BasicBlocks: both 3x3 convs forward (the strided blocks' conv2 too), conv2's gradient
+        assert calls["fwd"] == 2 * nblk + 2 and calls["dgrad"] == nblk and calls["fused_bn"] == 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)

@@ -97,7 +97,8 @@ def test_img3x3_dgrad(hip_lib, dt, geom, gate, bnbwd):
         ref = ref * ((c1.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0)
         sums = kn.new_stats(Cn)
         c1d = nhwc(c1).cuda()
-        kw.update(mask=(c1d, sc.cuda(), sh.cuda()), sums=sums)
+        act = torch.empty(N, H, H, Cn, dtype=dt, device="cuda")
+        kw.update(mask=(c1d, sc.cuda(), sh.cuda()), sums=sums, act_out=act)
     dx = torch.empty(N, H, H, Cn, dtype=dt, device="cuda")
     assert kn.img3x3_dgrad(d, dyd, wpk, dx, **kw)
     torch.cuda.synchronize()
@@ -114,6 +115,11 @@ def test_img3x3_dgrad(hip_lib, dt, geom, gate, bnbwd):
         gd = dx.double().cpu().reshape(-1, Cn)
         assert torch.allclose(s[0], gd.sum(0), rtol=1e-5, atol=1e-4)
         assert torch.allclose(s[1], (gd * c1d.double().cpu().reshape(-1, Cn)).sum(0), rtol=1e-5, atol=1e-4)
+        # the by-product activation is bit for bit what the stand-alone pass writes
+        want = torch.empty_like(act)
+        kn.bn_act(c1d, sc.cuda(), sh.cuda(), want, relu=True)
+        torch.cuda.synchronize()
+        assert torch.equal(act, want)
     # the gather kernel on the same (materialised) gradient operand
     dx2 = torch.empty_like(dx)
     kw2 = dict(mask=kw["mask"], sums=kn.new_stats(Cn)) if gate else {}
