@@ -50,7 +50,10 @@ struct Img3Params {
     int N, H;
 };
 
-__device__ __forceinline__ int img_swz(int row) { return row & 15; }  // rows are >= 256 bytes: see panel.hip panel_swz
+// chunk XOR of a staged pixel row (see panel.hip panel_swz): rows of >= 256 bytes rotate through 16 chunk positions; at 64
+// channels two 128-byte rows share a 256-byte bank line and rotate together through the 8 chunks of a row
+template <int C>
+__device__ __forceinline__ int img_swz(int row) { return C >= 128 ? (row & 15) : ((row >> 1) & 7); }
 
 template <typename T, int C, int KO, int BH, int IW, int PRO, bool DGRAD, int TN>
 __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3Params prm) {
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
     constexpr int KC = C / 16;                       // k steps per tap
     constexpr int R = 4;                             // weight-fragment ring
     constexpr int SCR_PITCH = 80, SCR_BYTES = 32 * SCR_PITCH;
-    static_assert(C % 128 == 0 && KO % (32 * TN) == 0 && NT % CPR == 0 && KC % R == 0 && (TN == 1 || TN == 2), "image kernel geometry");
+    static_assert(C % 64 == 0 && KO % (32 * TN) == 0 && NT % CPR == 0 && KC % R == 0 && (TN == 1 || TN == 2), "image kernel geometry");
     typedef typename MmaFrag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,15 +79,19 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
     const int l31 = lane & 31, lh = lane >> 5;
     char* scratch = smem + PP * ROWB + wave * SCR_BYTES;
 
+    // Bands in memory order per XCD: workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x takes the x-th eighth of
+    // the bands, in order -- neighbouring bands (which share two halo rows) meet in ONE L2 at about the same time.
+    unsigned bid = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
     const int nband = prm.H / BH;
-    const int image = blockIdx.x / nband, band = blockIdx.x - image * nband;
+    const int image = bid / nband, band = bid - image * nband;
     const int row0 = band * BH;                                   // first image row of the band
     const long pix0 = ((long)image * prm.H + row0) * IW;          // first output pixel (bands are contiguous in memory)
 
 #if MSFWSI_IMG_STAGGER
     // Workgroups of equal length that start together stay together: all 256 CUs stage at once (an HBM burst nobody computes
     // under), then all compute (HBM idle).  The first round starts in eight phases, MSFWSI_IMG_STAGGER * 64 clocks apart.
-    if (blockIdx.x < 256u * (PP * ROWB <= 72 * 1024 ? 2 : 1)) {
+    if (blockIdx.x < 256u * (unsigned)((160 * 1024) / (PP * ROWB + NW * SCR_BYTES))) {
         const int g = (blockIdx.x >> 3) & 7;
         for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(MSFWSI_IMG_STAGGER);
     }
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
                     *reinterpret_cast<uint4*>(aout_img + (unsigned)((hh * IW + ww) * ROWB + cc * 16)) = t;
             }
             if (!ok) t = make_uint4(0, 0, 0, 0);  // zero padding AFTER the transform (relu(shift) is not zero)
-            if (pos < PP) *reinterpret_cast<uint4*>(img + pos * ROWB + ((cc ^ img_swz(pos)) << 4)) = t;
+            if (pos < PP) *reinterpret_cast<uint4*>(img + pos * ROWB + ((cc ^ img_swz<C>(pos)) << 4)) = t;
         }
       }
     }
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
         for (int tm = 0; tm < TM; ++tm) {
             const int row = pos0[tm] + shift;
             rowb[tm] = row * ROWB;
-            sw[tm] = img_swz(row) ^ lh;  // chunk (2 kc + lh) ^ swz = (2 kc) ^ (lh ^ swz)
+            sw[tm] = img_swz<C>(row) ^ lh;  // chunk (2 kc + lh) ^ swz = (2 kc) ^ (lh ^ swz)
         }
         frag_t xc[TM], xn[TN == 2 ? TM : 1];
 #pragma unroll
@@ -367,6 +374,7 @@ template <typename T, int PRO, bool DGRAD>
 int dispatch_img(const msfwsi_conv_desc* d, const Img3Params& prm, hipStream_t st) {
     if (d->H == 14 && d->C == 256) return launch_img<T, 256, 14, 14, PRO, DGRAD>(prm, st);
     if (d->H == 28 && d->C == 128) return launch_img<T, 128, 7, 28, PRO, DGRAD>(prm, st);
+    if (d->H == 56 && d->C == 64) return launch_img<T, 64, 4, 56, PRO, DGRAD>(prm, st);
     return MSFWSI_EUNSUPPORTED;
 }
 
@@ -375,7 +383,8 @@ int dispatch_img(const msfwsi_conv_desc* d, const Img3Params& prm, hipStream_t s
 extern "C" int msfwsi_img3x3_supported(const msfwsi_conv_desc* d) {
     if (d == nullptr || (d->dtype != MSFWSI_DT_BF16 && d->dtype != MSFWSI_DT_F16)) return 0;
     if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->C != d->K || d->H != d->W || d->P != d->H || d->Q != d->W) return 0;
-    return ((d->H == 14 && d->C == 256) || (d->H == 28 && d->C == 128)) && (long)d->N * d->H * d->W <= 0x7fffffffL ? 1 : 0;
+    return ((d->H == 14 && d->C == 256) || (d->H == 28 && d->C == 128) || (d->H == 56 && d->C == 64)) &&
+                   (long)d->N * d->H * d->W <= 0x7fffffffL ? 1 : 0;
 }
 
 extern "C" int msfwsi_img3x3_pack_weights(int dtype, const void* w, void* wpk, int K, int C, int dgrad, void* stream) {

@@ -326,6 +326,10 @@ class Engine:
         # conv2 of layer2 / layer3 on the image-stationary kernels (csrc/img3x3.hip): bn1 + ReLU in the forward staging, bn2's
         # backward in the gradient staging, a1 for the weight gradient as a by-product of the gradient's gate
         self.img3x3 = os.environ.get("MSFWSI_IMG3X3", "1") != "0"
+        # layer1 (56x56x64): the weights-stationary kernel keeps the forward and the plain gradient (1.32 / 1.42 ms against 1.38
+        # / 1.58 ms per N = 4096 launch); the image kernel takes only the gradient WITH bn2's backward folded in (2.04 against
+        # 1.0 + 1.42 ms of msfwsi_bn_bwd_apply + gradient, profiles/r05_img3_kbench_c64.txt)
+        self.img3x3_layer1 = os.environ.get("MSFWSI_IMG3X3_L1", "1") != "0"
         self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
         self.panel_fwd_min_k = int(os.environ.get("MSFWSI_PANEL_FWD_MIN_K", "128"))  # 56x56 / 64 channels: the gather kernel is at the HBM roof
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
@@ -848,7 +852,8 @@ class Engine:
         a step like _panel_weights.  None for every other layer."""
         if (not self.img3x3 or dtype == torch.float32 or not isinstance(op, nn.Conv2d) or op.kernel_size != (3, 3)
                 or op.stride != (1, 1) or op.padding != (1, 1) or op.groups != 1 or op.bias is not None
-                or op.in_channels != op.out_channels or op.in_channels not in (128, 256)):
+                or op.in_channels != op.out_channels or op.in_channels not in (128, 256, 64)
+                or (op.in_channels == 64 and not (dgrad and self.img3x3_layer1))):
             return None
         return self.weights.derived("img3_dgrad" if dgrad else "img3_fwd", w,
                                     lambda t: kn.img3x3_pack_weights(t, torch.empty_like(t), dgrad))
@@ -1465,10 +1470,13 @@ class Engine:
             return False
         return kn.panel_supported(first.desc, True)
 
-    def _img3_dgrad_weights(self, u: Unit, prev: Unit, dtype) -> Optional[torch.Tensor]:
+    def _img3_dgrad_weights(self, u: Unit, prev: Unit, dtype, with_bn: bool = True) -> Optional[torch.Tensor]:
         """the packed filter if u's input gradient runs on the image-stationary kernel: a served 3x3 geometry whose operand
-        is prev's raw output under prev's BatchNorm + ReLU (conv2 of a Bottleneck of layer2 / layer3), else None"""
+        is prev's raw output under prev's BatchNorm + ReLU (conv2 of a Bottleneck of layer2 / layer3; of layer1 only when the
+        launch also forms the BatchNorm backward, with_bn), else None"""
         if u.x_pro is None or u.x is not prev.c or prev.st is None or u.s2d or not kn.img3x3_supported(u.desc):
+            return None
+        if u.desc.C == 64 and not with_bn:
             return None
         return self._img3_weights(u.op, self.weights.get(u.op.weight, dtype), dtype, dgrad=True)
 
@@ -1483,15 +1491,16 @@ class Engine:
         for i in range(top, 0, -1):
             u, prev = rec.units[i], rec.units[i - 1]
             s2 = kn.new_stats(prev.c.shape[-1], 2, dev)
-            wimg = self._img3_dgrad_weights(u, prev, dtype)
             bn_here = top_bn if i == top else None
+            wimg = self._img3_dgrad_weights(u, prev, dtype, with_bn=bn_here is not None)
             if wimg is not None:
                 # ONE launch: dc = bn backward of `cur` while the band is staged (written for the weight gradient: in place
                 # where a workgroup owns the whole image), da = gate(conv^T(dc)) + bn1's sums, and a1 = relu(bn1(c1)) --
                 # the weight gradient's operand -- stored from the gate's own arithmetic
                 d = u.desc
                 da = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dev)
-                a1 = torch.empty_like(prev.c)
+                # (64 channels: the output-stationary weight-gradient kernel normalises c1 in its own staging)
+                a1 = torch.empty_like(prev.c) if d.C != 64 else None
                 dc, bnb = cur, None
                 if bn_here is not None:
                     dc = cur if d.H == 14 else torch.empty_like(cur)

@@ -1,5 +1,5 @@
 """Image-stationary 3x3 kernels of the deep layers (csrc/img3x3.hip) on a real MI355X, through the C ABI: conv2 of the
-Bottlenecks of layer2 / layer3 (reference src/models/resnet.py:25-28,125-128) at 28x28x128 and 14x14x256 against a plain
+Bottlenecks of layer1 / layer2 / layer3 (reference src/models/resnet.py:25-28,125-128) at 56x56x64, 28x28x128 and 14x14x256 against a plain
 PyTorch fp64 CPU convolution of the same seeded, storage-rounded operands (bf16 <= 1.5e-2, fp16 <= 2e-3 rel-L2, the bounds of
 test_kernels_gpu.py), and against the gather kernel (msfwsi_conv_fwd / msfwsi_conv_dgrad) the engine ran before it."""
 import math
@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.bfloat16, torch.float16]
 # N, H (= W), channels: the two served geometries; N = 3 / 5 leaves the last wave of workgroups ragged
-GEOMS = [(3, 14, 256), (2, 28, 128), (5, 14, 256)]
+GEOMS = [(3, 14, 256), (2, 28, 128), (5, 14, 256), (2, 56, 64), (4, 56, 64)]  # (4 x 14 bands: the XCD-ordered band map)
 
 
 def tol(dt):
@@ -135,7 +135,7 @@ def test_img3x3_in_place_operand_only_where_a_workgroup_owns_the_image(hip_lib):
 
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(33)
-    for H, Cn, ok in ((14, 256, True), (28, 128, False)):
+    for H, Cn, ok in ((14, 256, True), (28, 128, False), (56, 64, False)):
         N = 2
         d = kn.conv_desc(dt, N, H, H, Cn, Cn, 3, 3, 1, 1)
         w = rnd((Cn, 3, 3, Cn), dt, g, 1.0 / math.sqrt(Cn * 9)).cuda()
@@ -159,7 +159,7 @@ def test_img3x3_in_place_operand_only_where_a_workgroup_owns_the_image(hip_lib):
 def test_img3x3_other_geometries_are_declined(hip_lib):
     from msf_wsi_amd import kernels as kn
 
-    for dt, N, H, Cn, K, R, stride in ((torch.bfloat16, 2, 7, 512, 512, 3, 1), (torch.bfloat16, 2, 56, 64, 64, 3, 1),
+    for dt, N, H, Cn, K, R, stride in ((torch.bfloat16, 2, 7, 512, 512, 3, 1), (torch.bfloat16, 2, 56, 128, 128, 3, 1),
                                        (torch.float32, 2, 14, 256, 256, 3, 1), (torch.bfloat16, 2, 14, 256, 256, 1, 1),
                                        (torch.bfloat16, 2, 28, 128, 128, 3, 2), (torch.bfloat16, 2, 14, 256, 128, 3, 1)):
         d = kn.conv_desc(dt, N, H, H, Cn, K, R, R, stride, R // 2)

@@ -261,7 +261,7 @@ def case_deep():
 
 def case_img3():
     """conv2 of layer2 / layer3: the image-stationary kernel (csrc/img3x3.hip) beside the gather kernel the engine runs"""
-    for H, Cn in ((14, 256), (28, 128)):
+    for H, Cn in ((14, 256), (28, 128), (56, 64)):
         N = NIMG
         M = N * H * H
         d = kn.conv_desc(DT, N, H, H, Cn, Cn, 3, 3, 1, 1)
@@ -280,6 +280,16 @@ def case_img3():
         fl = 2.0 * M * Cn * Cn * 9
         nb = 2 * M * Cn * 2
         tag = f"img3 {H}x{H} C{Cn}"
+        if H == 56:  # layer1: the engine runs the weights-stationary kernel (BatchNorm + ReLU already in its staging)
+            report(f"{tag} fwd weights-stationary (+stats)", timeit(lambda: kn.conv3x3_fwd(d, x, w, y, stats=kn.new_stats(Cn, 2, "cuda"))), nb, fl)
+            report(f"{tag} fwd weights-stationary, BN+ReLU in the staging",
+                   timeit(lambda: kn.conv3x3_fwd(d, x, w, y, stats=kn.new_stats(Cn, 2, "cuda"), pro=(sc, sh))), nb, fl)
+            report(f"{tag} dgrad weights-stationary + gate",
+                   timeit(lambda: kn.conv3x3_dgrad(d, dy, w, dx, mask=(x, sc, sh), sums=kn.new_stats(Cn, 2, "cuda"))), nb + M * Cn * 2, fl)
+            report(f"{tag} bn_bwd_apply + dgrad weights-stationary + gate",
+                   timeit(lambda: (kn.bn_bwd_apply(dy, y, k1, k2, k3, dc),
+                                   kn.conv3x3_dgrad(d, dc, w, dx, mask=(x, sc, sh), sums=kn.new_stats(Cn, 2, "cuda")))),
+                   nb * 2 + 2 * M * Cn * 2, fl)
         report(f"{tag} fwd gather (+stats)", timeit(lambda: kn.conv_fwd(d, x, w, y, stats=kn.new_stats(Cn, 2, "cuda"))), nb, fl)
         report(f"{tag} fwd image (+stats)", timeit(lambda: kn.img3x3_fwd(d, x, wf, y, stats=kn.new_stats(Cn, 2, "cuda"))), nb, fl)
         report(f"{tag} bn_act + fwd gather", timeit(lambda: (kn.bn_act(x, sc, sh, a, relu=True),
