@@ -50,10 +50,16 @@ struct Img3Params {
     int N, H;
 };
 
-// chunk XOR of a staged pixel row (see panel.hip panel_swz): rows of >= 256 bytes rotate through 16 chunk positions; at 64
-// channels two 128-byte rows share a 256-byte bank line and rotate together through the 8 chunks of a row
+// Chunk XOR of a staged pixel row.  A ds_read_b128 is served in four groups of 16 lanes (MI355X guide, LDS table), one LDS
+// cycle per group when its 16 lanes fall on 16 different 16-byte slots of the 256-byte bank line.  A group's lanes hold 16
+// output pixels with raster indices p that are distinct mod 16, and tap (r, s) sends pixel p to the staged row of LINEAR
+// index G = p + r * IW + s (pitch IW, not the padded pitch IW + 2): keyed on G, the XOR is distinct across the group for
+// every tap.  (Keyed on the padded position, as in round 5's first build, two image rows met on the same slots: 45 % of the
+// LDS cycles of the 14x14 kernel were conflict cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.)  Rows of >= 256 bytes
+// rotate through 16 chunk positions; at 64 channels two 128-byte rows share a bank line, told apart by G's parity (= the
+// position's parity, IW being even), and rotate together through the 8 chunks of a row.
 template <int C>
-__device__ __forceinline__ int img_swz(int row) { return C >= 128 ? (row & 15) : ((row >> 1) & 7); }
+__device__ __forceinline__ int img_swz(int G) { return C >= 128 ? (G & 15) : ((G >> 1) & 7); }
 
 template <typename T, int C, int KO, int BH, int IW, int PRO, bool DGRAD, int TN>
 __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3Params prm) {
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
     constexpr int KC = C / 16;                       // k steps per tap
     constexpr int R = 4;                             // weight-fragment ring
     constexpr int SCR_PITCH = 80, SCR_BYTES = 32 * SCR_PITCH;
-    static_assert(C % 64 == 0 && KO % (32 * TN) == 0 && NT % CPR == 0 && KC % R == 0 && (TN == 1 || TN == 2), "image kernel geometry");
+    static_assert(C % 64 == 0 && IW % 2 == 0 && KO % (32 * TN) == 0 && NT % CPR == 0 && KC % R == 0 && (TN == 1 || TN == 2), "image kernel geometry");
     typedef typename MmaFrag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
                     *reinterpret_cast<uint4*>(aout_img + (unsigned)((hh * IW + ww) * ROWB + cc * 16)) = t;
             }
             if (!ok) t = make_uint4(0, 0, 0, 0);  // zero padding AFTER the transform (relu(shift) is not zero)
-            if (pos < PP) *reinterpret_cast<uint4*>(img + pos * ROWB + ((cc ^ img_swz<C>(pos)) << 4)) = t;
+            if (pos < PP) *reinterpret_cast<uint4*>(img + pos * ROWB + ((cc ^ img_swz<C>(ph * IW + pw)) << 4)) = t;
         }
       }
     }
@@ -193,9 +199,8 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
         int rowb[TM], sw[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            const int row = pos0[tm] + shift;
-            rowb[tm] = row * ROWB;
-            sw[tm] = img_swz<C>(row) ^ lh;  // chunk (2 kc + lh) ^ swz = (2 kc) ^ (lh ^ swz)
+            rowb[tm] = (pos0[tm] + shift) * ROWB;
+            sw[tm] = img_swz<C>(tm * 32 + l31 + r * IW + s_) ^ lh;  // chunk (2 kc + lh) ^ swz = (2 kc) ^ (lh ^ swz)
         }
         frag_t xc[TM], xn[TN == 2 ? TM : 1];
 #pragma unroll

@@ -309,7 +309,34 @@ def case_img3():
         del x, y, a, dy, dx, dc
 
 
-CASES = {"img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+def case_s2pro():
+    """the strided 3x3 conv2 of layer2.0 / layer3.0 / layer4.0 (resnet.py:128 with stride 2): BatchNorm + ReLU of the operand
+    materialised first (what the engine does) against applied in the gather kernel's register staging"""
+    for H, Cn in ((56, 128), (28, 256), (14, 512)):
+        N = NIMG
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cn, Cn, 3, 3, 2, 1)
+        x = rnd(M, Cn)
+        a = torch.empty(M, Cn, dtype=DT, device="cuda")
+        w = rnd(Cn, 9 * Cn, scale=0.05).view(Cn, 3, 3, Cn)
+        y = torch.empty(N * d.P * d.Q, Cn, dtype=DT, device="cuda")
+        dy = rnd(N * d.P * d.Q, Cn, scale=0.05)
+        dw = torch.zeros(Cn, 9 * Cn, device="cuda")
+        sc, sh = torch.rand(Cn, device="cuda") + 0.5, torch.randn(Cn, device="cuda") * 0.3
+        fl = 2.0 * N * d.P * d.Q * Cn * Cn * 9
+        nb = (M * Cn + N * d.P * d.Q * Cn) * 2
+        tag = f"s2pro {H}x{H} C{Cn}"
+        report(f"{tag} fwd, operand materialised", timeit(lambda: kn.conv_fwd(d, x, w, y, stats=kn.new_stats(Cn, 2, "cuda"))), nb, fl)
+        report(f"{tag} bn_act + fwd", timeit(lambda: (kn.bn_act(x, sc, sh, a, relu=True),
+                                                     kn.conv_fwd(d, a, w, y, stats=kn.new_stats(Cn, 2, "cuda")))), nb + 2 * M * Cn * 2, fl)
+        report(f"{tag} fwd, BN+ReLU in the staging", timeit(lambda: kn.conv_fwd(d, x, w, y, stats=kn.new_stats(Cn, 2, "cuda"), pro=(sc, sh))), nb, fl)
+        report(f"{tag} bn_act + wgrad", timeit(lambda: (kn.bn_act(x, sc, sh, a, relu=True), kn.conv_wgrad(d, a, dy, dw))),
+               nb + 2 * M * Cn * 2, fl)
+        report(f"{tag} wgrad, BN+ReLU in the staging", timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=(sc, sh))), nb, fl)
+        del x, a, y, dy, dw
+
+
+CASES = {"s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():
