@@ -17,6 +17,7 @@ There is no CPU / eager-torch fallback: CPU tensors raise.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import threading
 import weakref
@@ -104,6 +105,7 @@ class StepRec:
     tgt_sorted: Dict[Tuple[int, int], torch.Tensor] = field(default_factory=dict)
     nosave: set = field(default_factory=set)
     dual: bool = False  # view-1 passes ran on the side stream (their activations live in that stream's pool)
+    head_streams: bool = False  # the context / target head groups ran on the context / view-1 streams (same for their records)
     tri: bool = False   # ... and both context passes on the third stream
     pair_bwd: bool = True  # the memory plan allows the two views' backward passes side by side (lockstep)
 
@@ -325,6 +327,10 @@ class Engine:
         self.panel_dgrad = os.environ.get("MSFWSI_PANEL_DGRAD", "1") != "0"
         # conv2 of layer2 / layer3 on the image-stationary kernels (csrc/img3x3.hip): bn1 + ReLU in the forward staging, bn2's
         # backward in the gradient staging, a1 for the weight gradient as a by-product of the gradient's gate
+        # the three head groups on the three streams of the multi-stream schedule (they are independent between the encoder
+        # passes and the loss, and again between the loss and the encoder backward): their ~400 launches are too small to
+        # fill the chip one after the other
+        self.heads_on_streams = os.environ.get("MSFWSI_HEAD_STREAMS", "1") != "0"
         self.img3x3 = os.environ.get("MSFWSI_IMG3X3", "1") != "0"
         # layer1 (56x56x64): the weights-stationary kernel keeps the forward and the plain gradient (1.32 / 1.42 ms against 1.38
         # / 1.58 ms per N = 4096 launch); the image kernel takes only the gradient WITH bn2's backward folded in (2.04 against
@@ -1885,36 +1891,55 @@ class Engine:
         rec.nosave = nosave
         rec.pair_bwd = self._pair_bwd
         outs = {}
+        # heads: context group on the context stream, target group on view 1's stream, fuser group here -- all three read
+        # finished encoder features; what they allocate lives in their stream's pool and is consumed there in the backward
+        hstream = {"context": third, "target": side, "inter": None} if (tri and self.heads_on_streams) else {}
+        rec.head_streams = bool(hstream)
+        if hstream:
+            for st in (side, third):
+                st.wait_stream(main)  # the joins above + the trainer's hook
+            for v in range(2):
+                for f in rec.enc[f"t{v}"].feats:
+                    f.record_stream(side)
+            for t in rec.idx:
+                t.record_stream(side)
         for grp in ("context", "target", "inter"):
-            proj = getattr(model, f"{grp}_projector")
-            pred = getattr(model, f"{grp}_predictor")
-            for s in range(4):
-                fs = []
-                for v in range(2):
-                    cf = rec.enc[f"c{v}"].feats[s]
-                    tf = rec.enc[f"t{v}"].feats[s]
-                    Cs = cf.shape[-1]
-                    if grp == "context":
-                        f = cf
-                    elif grp == "target":
-                        f = torch.empty_like(tf)
-                        kn.rows_permute(tf, rec.idx[v], f, B, K, Cs)
-                        rec.tgt_sorted[(s, v)] = f
+            with (torch.cuda.stream(hstream[grp]) if hstream.get(grp) is not None else contextlib.nullcontext()):
+                proj = getattr(model, f"{grp}_projector")
+                pred = getattr(model, f"{grp}_predictor")
+                for s in range(4):
+                    fs = []
+                    for v in range(2):
+                        cf = rec.enc[f"c{v}"].feats[s]
+                        tf = rec.enc[f"t{v}"].feats[s]
+                        Cs = cf.shape[-1]
+                        if grp == "context":
+                            f = cf
+                        elif grp == "target":
+                            f = torch.empty_like(tf)
+                            kn.rows_permute(tf, rec.idx[v], f, B, K, Cs)
+                            rec.tgt_sorted[(s, v)] = f
+                        else:
+                            D = (n_keep + 1) * Cs
+                            f = torch.empty(B, D, dtype=dtype, device=dev)
+                            kn.copy2d(cf, 0, Cs, f, 0, D, B, Cs)
+                            kn.copy2d(tf, 0, K * Cs, f, Cs, D, B, n_keep * Cs)
+                        fs.append(f)
+                    if self.pair_head_fwd:
+                        zrecs = self.chain_forward_pair(proj[s], fs, dtype)
+                        precs = self.chain_forward_pair(pred[s], [z.out for z in zrecs], dtype)
                     else:
-                        D = (n_keep + 1) * Cs
-                        f = torch.empty(B, D, dtype=dtype, device=dev)
-                        kn.copy2d(cf, 0, Cs, f, 0, D, B, Cs)
-                        kn.copy2d(tf, 0, K * Cs, f, Cs, D, B, n_keep * Cs)
-                    fs.append(f)
-                if self.pair_head_fwd:
-                    zrecs = self.chain_forward_pair(proj[s], fs, dtype)
-                    precs = self.chain_forward_pair(pred[s], [z.out for z in zrecs], dtype)
-                else:
-                    zrecs = [self.chain_forward(proj[s], f, dtype) for f in fs]
-                    precs = [self.chain_forward(pred[s], z.out, dtype) for z in zrecs]
-                for v in range(2):
-                    rec.heads[(grp, s, v)] = (zrecs[v], precs[v])
-                    outs[(grp, s, v)] = (precs[v].out, zrecs[v].out)
+                        zrecs = [self.chain_forward(proj[s], f, dtype) for f in fs]
+                        precs = [self.chain_forward(pred[s], z.out, dtype) for z in zrecs]
+                    for v in range(2):
+                        rec.heads[(grp, s, v)] = (zrecs[v], precs[v])
+                        outs[(grp, s, v)] = (precs[v].out, zrecs[v].out)
+                        if hstream.get(grp) is not None:  # read by the loss on the main stream
+                            precs[v].out.record_stream(main)
+                            zrecs[v].out.record_stream(main)
+        if hstream:
+            main.wait_stream(side)
+            main.wait_stream(third)
         result = []
         for grp in ("context", "target", "inter"):
             result.append((tuple(outs[(grp, s, 0)][0] for s in range(4)), tuple(outs[(grp, s, 1)][0] for s in range(4)),
@@ -1927,40 +1952,61 @@ class Engine:
         B, K, n_keep = rec.B, model.K, model.n_keep
         dcf = [[None] * 4 for _ in range(2)]
         dtf = [[None] * 4 for _ in range(2)]
+        dev0 = next(iter(dps.values())).device
+        main0 = torch.cuda.current_stream(dev0)
+        hstream = {}
+        if rec.head_streams:
+            # the groups' backward on the streams their forward ran on (their records live in those pools); the fuser group
+            # here.  Its feature gradients are ADDED to the other two groups', so it waits for them before its first add.
+            hstream = {"context": self._side_stream(dev0, "ctx"), "target": self._side_stream(dev0)}
+            for g2, st in hstream.items():
+                st.wait_stream(main0)  # the loss produced the dps
+                for (g3, _, _), t in dps.items():
+                    if g3 == g2:
+                        t.record_stream(st)
+        joined = not hstream
         for grp in ("context", "target", "inter"):
-            # the fuser heads from the widest scale down: its 18432-wide layers are 2/3 of all gradient bytes, and their
-            # bucket of the gradient exchange (on_group_done("inter", part=...)) leaves first
-            for s in (range(3, -1, -1) if grp == "inter" else range(4)):
-                pair = None
-                if self.pair_head_wgrad:
-                    hz, hp = zip(*(rec.heads.pop((grp, s, v)) for v in range(2)))
-                    dzs = self.chain_backward_pair(hp, [dps[(grp, s, v)] for v in range(2)], grads, dtype)
-                    pair = self.chain_backward_pair(hz, [d.contiguous() for d in dzs], grads, dtype)
-                for v in range(2):
-                    if pair is not None:
-                        df = pair[v]
-                    else:
-                        zrec, prec = rec.heads.pop((grp, s, v))
-                        dp = dps[(grp, s, v)]
-                        dz = self.chain_backward(prec, dp, grads, dtype)
-                        df = self.chain_backward(zrec, dz.contiguous(), grads, dtype)
-                    Cs = rec.enc[f"c{v}"].feats[s].shape[-1]
-                    if grp == "context":
-                        dcf[v][s] = df
-                    elif grp == "target":
-                        out = torch.empty_like(df)
-                        kn.rows_permute(df, rec.idx[v], out, B, K, Cs, scatter=True)
-                        dtf[v][s] = out
-                    else:
-                        D = (n_keep + 1) * Cs
-                        kn.copy2d(df, 0, D, dcf[v][s], 0, Cs, B, Cs, accumulate=True)
-                        kn.copy2d(df, Cs, D, dtf[v][s], 0, K * Cs, B, n_keep * Cs, accumulate=True)
-                if grp == "inter" and on_group_done is not None and self.bucket_inter:
-                    # this scale's projector / predictor weight gradients are complete: their buckets may travel
-                    on_group_done("inter", part=f"inter_predictor.{s}.")
-                    on_group_done("inter", part=f"inter_projector.{s}.")
-            if grp == "inter" and on_group_done is not None:
-                on_group_done("inter")  # whatever no bucket covered (nothing, unless bucketing is off)
+            with (torch.cuda.stream(hstream[grp]) if grp in hstream else contextlib.nullcontext()):
+                # the fuser heads from the widest scale down: its 18432-wide layers are 2/3 of all gradient bytes, and their
+                # bucket of the gradient exchange (on_group_done("inter", part=...)) leaves first
+                for s in (range(3, -1, -1) if grp == "inter" else range(4)):
+                    pair = None
+                    if self.pair_head_wgrad:
+                        hz, hp = zip(*(rec.heads.pop((grp, s, v)) for v in range(2)))
+                        dzs = self.chain_backward_pair(hp, [dps[(grp, s, v)] for v in range(2)], grads, dtype)
+                        pair = self.chain_backward_pair(hz, [d.contiguous() for d in dzs], grads, dtype)
+                    for v in range(2):
+                        if pair is not None:
+                            df = pair[v]
+                        else:
+                            zrec, prec = rec.heads.pop((grp, s, v))
+                            dp = dps[(grp, s, v)]
+                            dz = self.chain_backward(prec, dp, grads, dtype)
+                            df = self.chain_backward(zrec, dz.contiguous(), grads, dtype)
+                        Cs = rec.enc[f"c{v}"].feats[s].shape[-1]
+                        if grp == "context":
+                            dcf[v][s] = df
+                        elif grp == "target":
+                            out = torch.empty_like(df)
+                            kn.rows_permute(df, rec.idx[v], out, B, K, Cs, scatter=True)
+                            dtf[v][s] = out
+                        else:
+                            if not joined:
+                                for st in hstream.values():
+                                    main0.wait_stream(st)
+                                for row in dcf + dtf:
+                                    for t in row:
+                                        t.record_stream(main0)
+                                joined = True
+                            D = (n_keep + 1) * Cs
+                            kn.copy2d(df, 0, D, dcf[v][s], 0, Cs, B, Cs, accumulate=True)
+                            kn.copy2d(df, Cs, D, dtf[v][s], 0, K * Cs, B, n_keep * Cs, accumulate=True)
+                    if grp == "inter" and on_group_done is not None and self.bucket_inter:
+                        # this scale's projector / predictor weight gradients are complete: their buckets may travel
+                        on_group_done("inter", part=f"inter_predictor.{s}.")
+                        on_group_done("inter", part=f"inter_projector.{s}.")
+                if grp == "inter" and on_group_done is not None:
+                    on_group_done("inter")  # whatever no bucket covered (nothing, unless bucketing is off)
         # saved passes first (frees their activations), then the features-only ones are re-materialised
         order = sorted((("t0", dtf[0]), ("t1", dtf[1])), key=lambda nd: not rec.enc[nd[0]].saved)
         # view 1 on the side stream again (its activations live in that stream's pool); both views add into the same

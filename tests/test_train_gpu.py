@@ -180,3 +180,32 @@ def test_infonce_variant_matches_torch_restatement(hip_lib):
     rels = np.array([rel(ts.grads.logical(p), g64[n]) for n, p in named])
     box = np.array([rel(g32[n], g64[n]) for n in names])
     spread_gate(rels, names, [box], "InfoNCE gradients vs the torch restatement (fp64)")
+
+
+def test_three_streams_equal_one_stream(hip_lib, reproducible_sums):
+    """The multi-stream schedule (view 1 of an encoder on a second stream, the context passes on a third, the context /
+    target head groups on those streams too) against the one-stream schedule: the same kernels on the same data in another
+    interleaving.  With one workgroup per weight-gradient tile (reproducible_sums) the only order-dependent arithmetic left
+    is the fp32 atomics of two views adding into shared accumulators: three steps, losses equal to 1e-6, weights to 1e-5."""
+    from msf_wsi_amd.train import PretrainStep
+    from oracle import msfwsi_oracle as orc
+
+    vec, man = load_golden("r18_b8_s64")
+    B, size = man["B"], man["size"]
+    gb = _gpu_batch(orc.synthetic_batch(B, size, 16, man["data_seed"]))
+    runs = {}
+    for mode in ("one", "three"):
+        model = build_product("resnet18").cuda().train()
+        ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=True, init_scale=1024.0)
+        ts.engine.dual_stream = False if mode == "one" else None  # None: automatic (from the second step of a shape on)
+        losses = [float(ts.step(gb)) for _ in range(3)]
+        torch.cuda.synchronize()
+        runs[mode] = (losses, {k: v.detach().double().cpu() for k, v in model.state_dict().items()}, ts.engine.last_plan)
+    assert "dual-stream" not in runs["one"][2]
+    assert "dual-stream+context-stream" in runs["three"][2], runs["three"][2]
+    for a, b in zip(runs["one"][0], runs["three"][0]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (runs["one"][0], runs["three"][0])
+    worst = max(rel(runs["three"][1][k], v) for k, v in runs["one"][1].items()
+                if v.dtype.is_floating_point and v.numel() > 1 and float(v.norm()) > 0)
+    print(f"three streams vs one: worst weight rel-L2 {worst:.2e}")
+    assert worst <= 1e-5
