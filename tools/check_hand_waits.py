@@ -161,13 +161,17 @@ def main():
     if len(sys.argv) > 1:
         files = [(a, None) for a in sys.argv[1:]]
     else:
-        files = []
-        for src, _ in targets:
-            path = f"/tmp/msfwsi_audit_{src}.s"
-            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics",
-                            "-Wno-inline-asm", "-S", "--cuda-device-only", os.path.join(ROOT, "msf_wsi_amd", "csrc", src),
-                            "-o", path], check=True, stderr=subprocess.DEVNULL)
+        files, jobs = [], []
+        for src, _ in targets:  # both compiles at once
+            path = f"/tmp/msfwsi_audit_{os.getpid()}_{src}.s"
+            jobs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
+                                          "-munsafe-fp-atomics", "-Wno-inline-asm", "-S", "--cuda-device-only",
+                                          os.path.join(ROOT, "msf_wsi_amd", "csrc", src), "-o", path],
+                                         stderr=subprocess.DEVNULL))
             files.append((path, src))
+        for j in jobs:
+            if j.wait() != 0:
+                raise SystemExit("hipcc failed on a hand-counted source")
     found, n = [], 0
     for path, _ in files:
         lines = open(path).read().splitlines()
