@@ -745,6 +745,17 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
             slots = pro ? resident_slots(wgrad_kernel<T, BI, BJ, true, false>, threads, lds_pro)
                         : resident_slots(wgrad_kernel<T, BI, BJ, false, true>, threads, lds_dma);
         splits = slots / tiles;
+        // Small launches (the context passes, N = 256): every split ends with an atomic add of its whole tile (fp64 for a
+        // Gram matrix) -- at 196 rows per split the adds of a 256 x 256 tile move five times the bytes of the operands.  At
+        // least ~1024 rows per split, but never fewer than 64 workgroups (`profiles/r05_kbench_gram_splits.txt`: the
+        // 14 x 14 x 256 Gram launch 0.138 -> 0.055 ms, 7 x 7 x 512 0.096 -> 0.047).  Launches of the heads (M < 8192) keep
+        // the old rule.
+        if (prm.M >= 8192) {
+            long want = prm.M / 1024;
+            const long floor_splits = (64 + tiles - 1) / tiles;
+            if (want < floor_splits) want = floor_splits;
+            if (splits > want) splits = want;
+        }
     }
     const long max_splits = (prm.M + Cfg::BKM - 1) / Cfg::BKM;
     if (splits > max_splits) splits = max_splits;

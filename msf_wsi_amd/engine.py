@@ -1190,14 +1190,6 @@ class Engine:
         if self.fold_bn3 and c3_fraction > 0:  # conv3 outputs are never kept on the folded path
             per_image_bytes *= 1.0 - c3_fraction
             c3_fraction = 0.0
-        if mode == "off":
-            return set(), False, True
-        if mode == "c3":
-            return set(), c3_fraction > 0, True
-        if mode == "t1":
-            return {"t1"}, False, True
-        if mode == "targets":
-            return {"t0", "t1"}, False, True
         free, _ = torch.cuda.mem_get_info(device)
         avail = free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         # head room: 6 GiB for the allocator's fragmentation; with more than one rank another 4 GiB for RCCL's channel
@@ -1209,6 +1201,14 @@ class Engine:
         one_target = per_image_bytes * B * K
         transients = 0.26 * one_target
         ctx = per_image_bytes * B * ctx_passes  # the second context pass (both, when the plan precedes the first)
+        forced = {"off": (set(), False), "c3": (set(), c3_fraction > 0), "t1": ({"t1"}, False),
+                  "targets": ({"t0", "t1"}, False)}.get(mode)
+        if forced is not None:
+            # MSFWSI_RECOMPUTE=<mode> fixes WHAT is kept; whether two sets of backward transients (and with them the
+            # multi-stream schedule's extra allocator pools) fit beside it is still a question of memory
+            kept = 2 - len(forced[0])
+            slim = 1.0 - c3_fraction if forced[1] else 1.0
+            return forced[0], forced[1], (ctx + kept * one_target) * slim + 2 * transients < budget
         if ctx + 2 * one_target + transients < budget:
             # lockstep backward of the two target passes holds two sets of transients at once
             return set(), False, ctx + 2 * one_target + 2 * transients < budget

@@ -1274,8 +1274,8 @@ def img3x3_pack_weights(w, wpk, dgrad: bool):
 
 def _img3_symbol(d: ConvDesc, dt, pro: int, dgrad: bool) -> str:
     t = "DF16_" if dt == torch.float16 else "DF16b"
-    bh = 14 if d.H == 14 else 7
-    return f"img3x3_kernelI{t}Li{d.C}ELi{d.K}ELi{bh}ELi{d.W}ELi{pro}ELb{int(dgrad)}EE"
+    bh = {14: 14, 28: 7, 56: 4}[d.H]
+    return f"img3x3_kernelI{t}Li{d.C}ELi{d.K}ELi{bh}ELi{d.W}ELi{pro}ELb{int(dgrad)}ELi1EE"  # (TN = 1: csrc/img3x3.hip)
 
 
 def img3x3_fwd(d: ConvDesc, x, wpk, y, stats=None, pro=None) -> bool:

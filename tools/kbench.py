@@ -336,7 +336,30 @@ def case_s2pro():
         del x, a, y, dy, dw
 
 
-CASES = {"s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+def case_gramsplit():
+    """small-M weight-gradient / Gram launches of the context passes (N = 256) against the cap on the pixel splits (tuning
+    key 15): every split ends with an atomic add of its whole tile (fp64 for the Gram)"""
+    lib = _lib.load()
+    for N, H, Cn, K, gram in ((256, 14, 256, 256, True), (256, 14, 256, 1024, False), (256, 14, 1024, 256, False),
+                              (256, 7, 512, 512, True), (256, 7, 512, 2048, False), (256, 28, 128, 512, False)):
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cn, K, 1, 1, 1, 0)
+        x = rnd(M, Cn)
+        dy = rnd(M, K, scale=0.05)
+        dw = torch.zeros(K, Cn, device="cuda")
+        A = torch.zeros(Cn, 1, 1, Cn, device="cuda")
+        for cap in (0, 128, 64, 32, 16):
+            lib.msfwsi_set_tuning(15, cap)
+            if gram:
+                ms = timeit(lambda: kn.gram(kn.conv_desc(DT, N, H, H, Cn, Cn, 1, 1, 1, 0), x, A), iters=20)
+            else:
+                ms = timeit(lambda: kn.conv_wgrad(d, x, dy, dw), iters=20)
+            report(f"{'gram ' if gram else 'wgrad'} N{N} {H}x{H} C{Cn}->K{Cn if gram else K} max splits {cap or 'none'}", ms,
+                   (M * Cn + (0 if gram else M * K)) * 2, 2.0 * M * Cn * (Cn if gram else K))
+        lib.msfwsi_set_tuning(15, 0)
+
+
+CASES = {"gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():
