@@ -167,7 +167,8 @@ int msfwsi_panel_gram(int dtype, const void* c, const float* scale, const float*
  * return MSFWSI_EUNSUPPORTED and callers use msfwsi_conv_fwd / msfwsi_conv_dgrad. */
 int msfwsi_img3x3_supported(const msfwsi_conv_desc* d);
 /* wpk <- the filter w [K][3][3][C] in fragment order: [n/32][tap*(Ck/16) + c/16][64 lanes][8]; dgrad = 0: output channel n
- * = K index, operand channel c = C index; dgrad = 1: n = C index, c = K index, taps flipped (the transposed convolution). */
+ * = K index, operand channel c = C index; dgrad = 1: n = C index, c = K index, taps flipped (the transposed convolution);
+ * dgrad = 2 (K == C): the strided gradient's order, see msfwsi_img3x3_s2_dgrad. */
 int msfwsi_img3x3_pack_weights(int dtype, const void* w, void* wpk, int K, int C, int dgrad, void* stream);
 /* y = conv3x3(act(x), W) with act = relu(pro_scale*x + pro_shift) when pro_* != NULL (x = the producer's raw conv output,
  * resnet.py:125-128 fused; the zero padding stays zero), else x.  stats as in msfwsi_conv_fwd. */
@@ -184,6 +185,18 @@ int msfwsi_img3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c
                         const float* k3, void* dc_out, const void* wpk, void* dx, const void* mask_c,
                         const float* mask_scale, const float* mask_shift, void* act_out, double* sums, int nshard,
                         void* stream);
+
+/* The same for the STRIDED conv2 of layer2.0 / layer3.0 (3x3 / stride 2 / pad 1, C == K; src/models/resnet.py:128 with
+ * stride 2): the input gradient dx [N][2P][2Q][C] from dy [N][P][Q][C] at P = 28, C = 128 and P = 14, C = 256 (d describes the
+ * forward conv: H = 2P).  One launch instead of msfwsi_conv_dgrad's four parity launches: a band of dy is staged once and
+ * serves the four parities of the output position.  Arguments as msfwsi_img3x3_dgrad: c / k1..k3 / dc_out at dy's
+ * resolution (dc_out may alias dy only at P = 14), mask_c / act_out / sums at dx's.  wpk from msfwsi_img3x3_pack_weights
+ * with dgrad = 2 (the passes' tap order). */
+int msfwsi_img3x3_s2_dgrad_supported(const msfwsi_conv_desc* d);
+int msfwsi_img3x3_s2_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c, const float* k1, const float* k2,
+                           const float* k3, void* dc_out, const void* wpk, void* dx, const void* mask_c,
+                           const float* mask_scale, const float* mask_shift, void* act_out, double* sums, int nshard,
+                           void* stream);
 
 /* Specialised 3x3 / stride 1 / pad 1 path: the input patch of 256 raster pixels (+ halo) is staged once per
  * channel slab in LDS and reused by all nine taps (see csrc/conv3x3.hip).  Same results as msfwsi_conv_fwd /

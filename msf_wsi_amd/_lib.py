@@ -101,6 +101,8 @@ SIGNATURES = {
     "msfwsi_img3x3_pack_weights": [_i, _vp, _vp, _i, _i, _i, _vp],
     "msfwsi_img3x3_fwd": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_img3x3_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_img3x3_s2_dgrad_supported": [_desc],
+    "msfwsi_img3x3_s2_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_panel_gram": [_i, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
     "msfwsi_panel_supported": [_desc, _i],
     "msfwsi_panel_pack_weights": [_i, _vp, _vp, _i, _i, _l, _l, _vp],

@@ -359,6 +359,330 @@ __global__ void img3x3_pack_kernel(const U* __restrict__ w, U* __restrict__ wpk,
     wpk[i] = dgrad ? w[((long)c * 9 + (8 - tap)) * C + n] : w[((long)n * 9 + tap) * C + c];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Input gradient of the STRIDED conv2 (3x3 / stride 2 / pad 1, C -> C) of layer2.0 / layer3.0 (resnet.py:128 with
+// stride 2): dx [N][2 IH][2 IW][C] from dy [N][IH][IW][C].  The gather kernel runs it as four launches (one per parity
+// class of the output position), each reading dy and its part of the mask again and writing a quarter of the pixels.  Here a
+// workgroup stages a band of dy ONCE (BH rows + one halo row below, IW + 1 columns: 196 gradient pixels = seven MFMA tiles)
+// and makes four passes over it, one per parity (a, b) of the output position (2h + a, 2w + b):
+//     dx(2h+a, 2w+b) = sum over r in R(a), s in R(b) of  dy(h + dh(a, r), w + dh(b, s)) . w[.][r][s][.]
+//     R(0) = {1}, dh = 0;    R(1) = {0, 2}, dh(1, 0) = 1, dh(1, 2) = 0                      (1 + 2 + 2 + 4 = 9 taps in all)
+// -- the same seven accumulator tiles, weight ring and address-shift taps as img3x3_kernel; each pass ends with the epilogue
+// of its 196 output pixels (ReLU gate from the raw c1 at the output resolution, BatchNorm sums, optionally a1 = relu(bn1(c1))
+// for the weight gradient, as in msfwsi_img3x3_dgrad).  PRO 2: dc = k1 dy + k2 c2 + k3 in the staging, written back.
+// The filter is packed in pass order (msfwsi_img3x3_pack_weights, mode 2).
+struct Img3S2Params {
+    const void* src;    // [N][IH][IW][C]: PRO 0 the gradient operand, PRO 2 the gated gradient g
+    const void* src_c;  // PRO 2: conv2's raw output c2
+    const float* p0;    // PRO 2: k1, k2, k3
+    const float* p1;
+    const float* p2;
+    void* aout;         // PRO 2, nullable: dc [N][IH][IW][C]
+    const void* wpk;    // [C/32][9 * C/16][64][8], steps in pass order
+    void* out;          // dx [N][2 IH][2 IW][C]
+    double* stats;      // {sum g, sum g*c} of the gated result, [nshard][2][C]
+    int nshard;
+    const void* mask_c;  // [N][2 IH][2 IW][C] raw conv output whose BatchNorm+ReLU gates dx, nullable
+    const float* mask_scale;
+    const float* mask_shift;
+    void* act_out;       // nullable (needs mask_c): relu(mask_scale * mask_c + mask_shift)
+    int N, IH;
+};
+
+template <typename T, int C, int BH, int IW, int PRO>
+__global__ __launch_bounds__(C * 2, 2) void img3x3_s2d_kernel(const Img3S2Params prm) {
+    constexpr int NW = C / 32, NT = 64 * NW;
+    constexpr int PW = IW + 1, PP = (BH + 1) * PW;  // staged positions: one halo row below, one halo column right
+    constexpr int CPR = C / 8, ROWB = C * 2;
+    constexpr int NCHT = (PP * CPR + NT - 1) / NT;
+    constexpr int NPASS = (NCHT + 15) / 16;
+    constexpr int NCH = (NCHT + NPASS - 1) / NPASS;
+    constexpr int MB = BH * IW;
+    constexpr int TM = (MB + 31) / 32;
+    constexpr int KC = C / 16;
+    constexpr int R = 4;
+    constexpr int KU = KC > 8 ? 8 : KC;
+    constexpr int OW = 2 * IW;
+    constexpr int SCR_PITCH = 80, SCR_BYTES = 32 * SCR_PITCH + 256;  // + this wave's 2 x 32 fp32 statistics
+    static_assert(C % 128 == 0 && IW % 2 == 0 && NT % CPR == 0 && KU % R == 0 && KC % KU == 0, "strided image kernel geometry");
+    typedef typename MmaFrag<T>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* img = smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    char* scratch = smem + PP * ROWB + wave * SCR_BYTES;
+
+    unsigned bid = blockIdx.x;  // bands in memory order per XCD, see img3x3_kernel
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+    const int nband = prm.IH / BH;
+    const int image = bid / nband, band = bid - image * nband;
+    const int row0 = band * BH;
+
+    // ---------------- stage the band of the gradient (+ halo row / column, zero outside the image) ----------------
+    {
+        const int cc = tid % CPR;
+        const char* src_img = reinterpret_cast<const char*>(prm.src) + (long)image * prm.IH * IW * ROWB;
+        const char* srcc_img = PRO == 2 ? reinterpret_cast<const char*>(prm.src_c) + (long)image * prm.IH * IW * ROWB : nullptr;
+        float c0[PRO ? 8 : 1], c1[PRO ? 8 : 1], c2[PRO ? 8 : 1];
+        if constexpr (PRO == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                c0[e] = prm.p0[cc * 8 + e];
+                c1[e] = prm.p1[cc * 8 + e];
+                c2[e] = prm.p2[cc * 8 + e];
+            }
+        }
+        char* aout_img = PRO == 2 && prm.aout != nullptr ? reinterpret_cast<char*>(prm.aout) + (long)image * prm.IH * IW * ROWB : nullptr;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int tbase = tid + pass * NCH * NT;
+            uint4 v[NCH], vc[PRO == 2 ? NCH : 1];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int pos = (tbase + i * NT) / CPR;
+                const int ph = pos / PW, pw = pos - ph * PW;
+                const int hh = row0 + ph;
+                const bool ok = pos < PP && hh < prm.IH && pw < IW;
+                const unsigned off = (unsigned)((ok ? hh * IW + pw : row0 * IW) * ROWB + cc * 16);
+                v[i] = *reinterpret_cast<const uint4*>(src_img + off);
+                if constexpr (PRO == 2) vc[i] = *reinterpret_cast<const uint4*>(srcc_img + off);
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int pos = (tbase + i * NT) / CPR;
+                const int ph = pos / PW, pw = pos - ph * PW;
+                const int hh = row0 + ph;
+                const bool ok = pos < PP && hh < prm.IH && pw < IW;
+                uint4 t = v[i];
+                if constexpr (PRO == 2) {
+                    float g[8], c[8];
+                    unpack16<T>(t, g);
+                    unpack16<T>(vc[i], c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = fmaf(c0[e], g[e], fmaf(c1[e], c[e], c2[e]));  // = msfwsi_bn_bwd_apply
+                    t = pack16<T>(g);
+                    if (aout_img != nullptr && ok && ph < BH)  // the band that owns the row writes it
+                        *reinterpret_cast<uint4*>(aout_img + (unsigned)((hh * IW + pw) * ROWB + cc * 16)) = t;
+                }
+                if (!ok) t = make_uint4(0, 0, 0, 0);
+                if (pos < PP) *reinterpret_cast<uint4*>(img + pos * ROWB + ((cc ^ img_swz<C>(ph * IW + pw)) << 4)) = t;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), visible to hipcc's wait-count pass (see img3x3_kernel)
+    __syncthreads();
+
+    const char* wb = reinterpret_cast<const char*>(prm.wpk) + (long)wave * (9 * KC) * 1024;
+    const int q = lane & 3, r4 = lane >> 2;
+    const int ncol = wave * 32 + q * 8;
+    const long opix0 = ((long)image * 2 * prm.IH + 2 * row0) * OW;  // first output pixel of the band's first output row
+    T* __restrict__ out = reinterpret_cast<T*>(prm.out) + opix0 * C;
+    const T* __restrict__ mask_c = reinterpret_cast<const T*>(prm.mask_c);
+    if (mask_c != nullptr) mask_c += opix0 * C;
+    T* __restrict__ act = prm.act_out != nullptr ? reinterpret_cast<T*>(prm.act_out) + opix0 * C : nullptr;
+    // the passes' statistics meet in LDS (registers are the kernel's scarce resource: 7 accumulator tiles + ring + addresses)
+    float* wstat = reinterpret_cast<float*>(scratch + 32 * SCR_PITCH);
+    wstat[lane] = 0.f;
+
+    int sbase = 0;  // steps of the passes before this one
+#pragma unroll 1
+    for (int par = 0; par < 4; ++par) {
+        const int a = par >> 1, b = par & 1;
+        const int ntap = (1 + a) * (1 + b);
+        const int send = sbase + ntap * KC;
+        u32x4 wf[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) pl_load16<true>(wf[i], wb, (unsigned)((sbase + i) * 1024 + lane * 16));
+        f32x16 acc[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[tm][j] = 0.f;
+        int step = sbase;
+#pragma unroll 1
+        for (int t = 0; t < ntap; ++t) {
+            // taps of the pass in (r, s) order: rows r in R(a), columns s in R(b); the FIRST element of R(1) = {0, 2} reads one
+            // row (column) further on
+            const int tr = b ? (t >> 1) : t, ts = b ? (t & 1) : 0;
+            const int dh = (a && tr == 0) ? 1 : 0, dw = (b && ts == 0) ? 1 : 0;
+            const int shift = dh * PW + dw;
+            int rowb[TM], sw[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int p = tm * 32 + l31;  // (recomputed per tap: three VALU against 16 MFMAs; registers are scarce)
+                const int h = p / IW, w = p - h * IW;
+                rowb[tm] = ((p < MB ? h * PW + w : 0) + shift) * ROWB;
+                sw[tm] = img_swz<C>(p + dh * IW + dw) ^ lh;
+            }
+            frag_t xc[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) xc[tm] = *reinterpret_cast<const frag_t*>(img + rowb[tm] + ((0 ^ sw[tm]) << 4));
+            // KU steps unrolled; at 256 channels two rounds of them (16 unrolled steps + the epilogue's state spill)
+#pragma unroll 1
+            for (int k0 = 0; k0 < KC; k0 += KU) {
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    const int kc = k0 + u;
+                    pl_wait<true, R - 1>(wf[u % R]);
+                    const frag_t wfr = __builtin_bit_cast(frag_t, wf[u % R]);
+                    const int kn = kc + 1 < KC ? kc + 1 : KC - 1;  // (the tap's last step re-reads its own chunk: never used)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        mma32<T>(acc[tm], wfr, xc[tm]);
+                        xc[tm] = *reinterpret_cast<const frag_t*>(img + rowb[tm] + (((2 * kn) ^ sw[tm]) << 4));
+                    }
+                    // the step R ahead takes the slot just consumed (past the pass's end: its last step again, never used)
+                    const int nxt = step + kc + R < send ? step + kc + R : send - 1;
+                    pl_load16<true>(wf[u % R], wb, (unsigned)(nxt * 1024 + lane * 16));
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            step += KC;
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) pl_drain<true>(wf[i]);  // the trailing re-requests land before anything re-uses their registers
+        sbase = send;
+        // an opaque zero: the epilogue's 14 output addresses depend only on the pass, and hipcc would otherwise compute them
+        // BEFORE the k loop and carry them through it (-> 80 spilled registers)
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        const int r4z = r4 + zero;
+
+        // ---- epilogue of the pass: output pixel (2h + a, 2w + b) of gradient pixel (h, w); mask operands in two halves ----
+        float msc[8], msh[8], s0[8], s1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+        if (mask_c != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                msc[e] = prm.mask_scale[ncol + e];
+                msh[e] = prm.mask_shift[ncol + e];
+            }
+        }
+        constexpr int TH = (TM + 1) / 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int tm_lo = half * TH, tm_hi = half ? TM : TH;
+            uint4 mk[TH * 2];
+            if (mask_c != nullptr) {
+#pragma unroll
+                for (int t2 = 0; t2 < (tm_hi - tm_lo) * 2; ++t2) {
+                    const int p = (tm_lo + (t2 >> 1)) * 32 + (t2 & 1) * 16 + r4z;
+                    const int h = p / IW, w = p - h * IW;
+                    const int op = p < MB ? (2 * h + a) * OW + 2 * w + b : 0;
+                    mk[t2] = *reinterpret_cast<const uint4*>(mask_c + (long)op * C + ncol);
+                }
+            }
+#pragma unroll
+            for (int tm = tm_lo; tm < tm_hi; ++tm) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2*>(scratch + l31 * SCR_PITCH + (8 * g + 4 * lh) * 2) =
+                        pack4<T>(acc[tm][4 * g], acc[tm][4 * g + 1], acc[tm][4 * g + 2], acc[tm][4 * g + 3]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int p = tm * 32 + i * 16 + r4z;
+                    uint4 cv = *reinterpret_cast<const uint4*>(scratch + (i * 16 + r4) * SCR_PITCH + q * 16);
+                    if (p < MB) {
+                        const int h = p / IW, w = p - h * IW;
+                        const long op = (long)((2 * h + a) * OW + 2 * w + b) * C + ncol;
+                        if (mask_c != nullptr) {
+                            float f[8], c[8], av[8];
+                            unpack16<T>(cv, f);
+                            unpack16<T>(mk[(tm - tm_lo) * 2 + i], c);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                av[e] = fmaxf(fmaf(c[e], msc[e], msh[e]), 0.f);
+                                if (!(av[e] > 0.f)) f[e] = 0.f;
+                                s0[e] += f[e];
+                                s1[e] = fmaf(f[e], c[e], s1[e]);
+                            }
+                            cv = pack16<T>(f);
+                            if (act != nullptr) *reinterpret_cast<uint4*>(act + op) = pack16<T>(av);
+                        }
+                        *reinterpret_cast<uint4*>(out + op) = cv;
+                    }
+                }
+            }
+        }
+        if (prm.stats != nullptr) {  // this pass's sums: lanes with the same chunk q meet, lanes 0-3 add them to the wave's LDS row
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) {
+                    s0[e] += __shfl_xor(s0[e], off, 64);
+                    s1[e] += __shfl_xor(s1[e], off, 64);
+                }
+            }
+            if (lane < 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    wstat[q * 8 + e] += s0[e];
+                    wstat[32 + q * 8 + e] += s1[e];
+                }
+            }
+        }
+    }
+    if (prm.stats != nullptr && lane < 32) {  // (wave-private LDS row: program order suffices)
+        double* dst = prm.stats + (long)(blockIdx.x % prm.nshard) * 2 * C + wave * 32 + lane;
+        atomicAdd(dst, (double)wstat[lane]);
+        atomicAdd(dst + C, (double)wstat[32 + lane]);
+    }
+}
+
+// pass order of the strided gradient: step = sum of the earlier passes' taps * (C/16) + tap * (C/16) + k/16;
+// W'(n, pass (a, b), tap (r, s), k) = w[k][r][s][n],  r in R(a), s in R(b), R(0) = {1}, R(1) = {0, 2}
+template <typename U>
+__global__ void img3x3_pack_s2d_kernel(const U* __restrict__ w, U* __restrict__ wpk, int C) {
+    const long total = (long)C * 9 * C;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long frag = i >> 9;
+    const int kcs = C >> 4, steps = 9 * kcs;
+    const int step = (int)(frag % steps), nb = (int)(frag / steps);
+    int tap = step / kcs;  // 0 .. 8 in pass order: 1 + 2 + 2 + 4
+    const int k = (step - tap * kcs) * 16 + 8 * (lane >> 5) + j;
+    int a, b;
+    if (tap < 1) { a = 0; b = 0; }
+    else if (tap < 3) { a = 0; b = 1; tap -= 1; }
+    else if (tap < 5) { a = 1; b = 0; tap -= 3; }
+    else { a = 1; b = 1; tap -= 5; }
+    const int tr = b ? (tap >> 1) : tap, ts = b ? (tap & 1) : 0;
+    const int r = a ? 2 * tr : 1, s_ = b ? 2 * ts : 1;
+    const int n = nb * 32 + (lane & 31);
+    wpk[i] = w[(((long)k * 3 + r) * 3 + s_) * C + n];
+}
+
+template <typename T, int C, int BH, int IW, int PRO>
+int launch_img_s2d(const Img3S2Params& prm, hipStream_t stream) {
+    constexpr int LDS = (BH + 1) * (IW + 1) * C * 2 + (C / 32) * (32 * 80 + 256);
+    void (*kern)(const Img3S2Params) = img3x3_s2d_kernel<T, C, BH, IW, PRO>;
+    if (LDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long nwg = (long)prm.N * (prm.IH / BH);
+    if (nwg <= 0 || nwg > 0x7fffffffL) return MSFWSI_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(C * 2), LDS, stream, prm);
+    return msfwsi_launch_status();
+}
+
+template <typename T, int PRO>
+int dispatch_img_s2d(const msfwsi_conv_desc* d, const Img3S2Params& prm, hipStream_t st) {
+    if (d->P == 28 && d->C == 128) return launch_img_s2d<T, 128, 7, 28, PRO>(prm, st);
+    if (d->P == 14 && d->C == 256) return launch_img_s2d<T, 256, 14, 14, PRO>(prm, st);
+    return MSFWSI_EUNSUPPORTED;
+}
+
 template <typename T, int C, int BH, int IW, int PRO, bool DGRAD>
 int launch_img(const Img3Params& prm, hipStream_t stream) {
     constexpr int KO = C;
@@ -393,9 +717,16 @@ extern "C" int msfwsi_img3x3_supported(const msfwsi_conv_desc* d) {
 }
 
 extern "C" int msfwsi_img3x3_pack_weights(int dtype, const void* w, void* wpk, int K, int C, int dgrad, void* stream) {
-    MSFWSI_CHECK_ARG(w != nullptr && wpk != nullptr && K > 0 && C > 0);
+    MSFWSI_CHECK_ARG(w != nullptr && wpk != nullptr && K > 0 && C > 0 && dgrad >= 0 && dgrad <= 2);
     if ((dtype != MSFWSI_DT_BF16 && dtype != MSFWSI_DT_F16) || K % 32 != 0 || C % 32 != 0) return MSFWSI_EUNSUPPORTED;
     const long n = (long)K * 9 * C;
+    if (dgrad == 2) {  // the strided gradient's pass order
+        if (K != C) return MSFWSI_EUNSUPPORTED;
+        hipLaunchKernelGGL(img3x3_pack_s2d_kernel<unsigned short>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(w),
+                           reinterpret_cast<unsigned short*>(wpk), C);
+        return msfwsi_launch_status();
+    }
     hipLaunchKernelGGL(img3x3_pack_kernel<unsigned short>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(w),
                        reinterpret_cast<unsigned short*>(wpk), K, C, dgrad ? 1 : 0);
@@ -440,4 +771,35 @@ extern "C" int msfwsi_img3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, co
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MSFWSI_DT_BF16) return pro ? dispatch_img<__bf16, 2, true>(d, prm, st) : dispatch_img<__bf16, 0, true>(d, prm, st);
     return pro ? dispatch_img<_Float16, 2, true>(d, prm, st) : dispatch_img<_Float16, 0, true>(d, prm, st);
+}
+
+extern "C" int msfwsi_img3x3_s2_dgrad_supported(const msfwsi_conv_desc* d) {
+    if (d == nullptr || (d->dtype != MSFWSI_DT_BF16 && d->dtype != MSFWSI_DT_F16)) return 0;
+    if (d->R != 3 || d->S != 3 || d->stride != 2 || d->pad != 1 || d->C != d->K || d->H != d->W || d->P != d->Q) return 0;
+    if (d->H != 2 * d->P) return 0;
+    return ((d->P == 28 && d->C == 128) || (d->P == 14 && d->C == 256)) && (long)d->N * d->H * d->W <= 0x7fffffffL ? 1 : 0;
+}
+
+extern "C" int msfwsi_img3x3_s2_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* c, const float* k1, const float* k2,
+                                      const float* k3, void* dc_out, const void* wpk, void* dx, const void* mask_c,
+                                      const float* mask_scale, const float* mask_shift, void* act_out, double* sums, int nshard,
+                                      void* stream) {
+    if (!msfwsi_img3x3_s2_dgrad_supported(d)) return d == nullptr ? MSFWSI_EINVAL : MSFWSI_EUNSUPPORTED;
+    MSFWSI_CHECK_ARG(dy != nullptr && wpk != nullptr && dx != nullptr);
+    const bool pro = c != nullptr;
+    MSFWSI_CHECK_ARG(pro == (k1 != nullptr) && pro == (k2 != nullptr) && pro == (k3 != nullptr) && (pro || dc_out == nullptr));
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
+    MSFWSI_CHECK_ARG(act_out == nullptr || (mask_c != nullptr && act_out != mask_c && act_out != dx));
+    // bands read their halo row from the gradient of the band below: in place only where a workgroup owns the whole image
+    MSFWSI_CHECK_ARG(dc_out == nullptr || dc_out != dy || d->P == 14);
+    Img3S2Params prm{};
+    prm.src = dy; prm.src_c = c; prm.p0 = k1; prm.p1 = k2; prm.p2 = k3; prm.aout = dc_out;
+    prm.wpk = wpk; prm.out = dx;
+    prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift; prm.act_out = act_out;
+    prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = d->N; prm.IH = d->P;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MSFWSI_DT_BF16) return pro ? dispatch_img_s2d<__bf16, 2>(d, prm, st) : dispatch_img_s2d<__bf16, 0>(d, prm, st);
+    return pro ? dispatch_img_s2d<_Float16, 2>(d, prm, st) : dispatch_img_s2d<_Float16, 0>(d, prm, st);
 }

@@ -336,6 +336,9 @@ class Engine:
         # / 1.58 ms per N = 4096 launch); the image kernel takes only the gradient WITH bn2's backward folded in (2.04 against
         # 1.0 + 1.42 ms of msfwsi_bn_bwd_apply + gradient, profiles/r05_img3_kbench_c64.txt)
         self.img3x3_layer1 = os.environ.get("MSFWSI_IMG3X3_L1", "1") != "0"
+        # the strided conv2 of layer2.0 / layer3.0: input gradient in ONE launch (msfwsi_img3x3_s2_dgrad) instead of four
+        # parity launches, with bn2's backward and the a1 by-product as above
+        self.img3x3_s2 = os.environ.get("MSFWSI_IMG3X3_S2", "1") != "0"
         self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
         self.panel_fwd_min_k = int(os.environ.get("MSFWSI_PANEL_FWD_MIN_K", "128"))  # 56x56 / 64 channels: the gather kernel is at the HBM roof
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
@@ -857,8 +860,13 @@ class Engine:
         they stream (msfwsi_img3x3_pack_weights; the gradient's copy transposed with flipped taps); shared by the passes of
         a step like _panel_weights.  None for every other layer."""
         if (not self.img3x3 or dtype == torch.float32 or not isinstance(op, nn.Conv2d) or op.kernel_size != (3, 3)
-                or op.stride != (1, 1) or op.padding != (1, 1) or op.groups != 1 or op.bias is not None
-                or op.in_channels != op.out_channels or op.in_channels not in (128, 256, 64)
+                or op.padding != (1, 1) or op.groups != 1 or op.bias is not None or op.in_channels != op.out_channels):
+            return None
+        if op.stride == (2, 2):  # conv2 of layer2.0 / layer3.0: the input gradient only, in the passes' tap order
+            if not (dgrad and self.img3x3_s2 and op.in_channels in (128, 256)):
+                return None
+            return self.weights.derived("img3_s2d", w, lambda t: kn.img3x3_pack_weights(t, torch.empty_like(t), 2))
+        if (op.stride != (1, 1) or op.in_channels not in (128, 256, 64)
                 or (op.in_channels == 64 and not (dgrad and self.img3x3_layer1))):
             return None
         return self.weights.derived("img3_dgrad" if dgrad else "img3_fwd", w,
@@ -1480,7 +1488,9 @@ class Engine:
         """the packed filter if u's input gradient runs on the image-stationary kernel: a served 3x3 geometry whose operand
         is prev's raw output under prev's BatchNorm + ReLU (conv2 of a Bottleneck of layer2 / layer3; of layer1 only when the
         launch also forms the BatchNorm backward, with_bn), else None"""
-        if u.x_pro is None or u.x is not prev.c or prev.st is None or u.s2d or not kn.img3x3_supported(u.desc):
+        if u.x_pro is None or u.x is not prev.c or prev.st is None or u.s2d:
+            return None
+        if not (kn.img3x3_supported(u.desc) or kn.img3x3_s2_dgrad_supported(u.desc)):
             return None
         if u.desc.C == 64 and not with_bn:
             return None
@@ -1508,12 +1518,15 @@ class Engine:
                 # (64 channels: the output-stationary weight-gradient kernel normalises c1 in its own staging)
                 a1 = torch.empty_like(prev.c) if d.C != 64 else None
                 dc, bnb = cur, None
+                strided = d.stride == 2
                 if bn_here is not None:
-                    dc = cur if d.H == 14 else torch.empty_like(cur)
+                    # in place where a workgroup owns the whole (gradient) image: bands read their neighbours' halo rows
+                    dc = cur if (d.P if strided else d.H) == 14 else torch.empty_like(cur)
                     bnb = (bn_here[0], bn_here[1][0], bn_here[1][1], bn_here[1][2])
-                if not kn.img3x3_dgrad(d, cur, wimg, da, bnbwd=bnb, dc_out=dc if bnb is not None else None,
-                                       mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2, act_out=a1):
-                    raise _lib.MsfwsiHipError("img3x3_dgrad refused a geometry msfwsi_img3x3_supported accepted")
+                launch = kn.img3x3_s2_dgrad if strided else kn.img3x3_dgrad
+                if not launch(d, cur, wimg, da, bnbwd=bnb, dc_out=dc if bnb is not None else None,
+                              mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2, act_out=a1):
+                    raise _lib.MsfwsiHipError("the image-stationary gradient refused a geometry its `supported` accepted")
                 self._unit_wgrad(u, dc, grads, dtype, x_mat=a1)
                 del a1, dc
             else:

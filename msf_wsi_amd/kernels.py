@@ -1262,8 +1262,9 @@ def img3x3_supported(d: ConvDesc) -> bool:
     return bool(_lib.load().msfwsi_img3x3_supported(C.byref(d)))
 
 
-def img3x3_pack_weights(w, wpk, dgrad: bool):
-    """wpk <- w [K][3][3][C] in the fragment order the kernel streams (dgrad: transposed, taps flipped)"""
+def img3x3_pack_weights(w, wpk, dgrad):
+    """wpk <- w [K][3][3][C] in the fragment order the kernel streams (dgrad True / 1: transposed, taps flipped; 2: the
+    pass order of the strided gradient, img3x3_s2_dgrad)"""
     K, Cc = w.shape[0], w.shape[-1]
     _req(w, "w", w.dtype, K * 9 * Cc)
     _req(wpk, "wpk", w.dtype, K * 9 * Cc)
@@ -1272,9 +1273,58 @@ def img3x3_pack_weights(w, wpk, dgrad: bool):
     return wpk
 
 
+def img3x3_s2_dgrad_supported(d: ConvDesc) -> bool:
+    """the strided conv2 of layer2.0 / layer3.0 (resnet.py:128 with stride 2): dy 28x28x128 / 14x14x256, 16-bit storage"""
+    return bool(_lib.load().msfwsi_img3x3_s2_dgrad_supported(C.byref(d)))
+
+
+def img3x3_s2_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, mask=None, sums=None, act_out=None) -> bool:
+    """input gradient of a 3x3 / stride 2 conv in ONE launch (d: the forward conv); arguments as img3x3_dgrad, bnbwd / dc_out
+    at dy's resolution, mask / act_out / sums at dx's.  False where the geometry is not served."""
+    lib = _lib.load()
+    dt = dy.dtype
+    n_out = d.N * d.P * d.Q * d.K
+    n_in = d.N * d.H * d.W * d.C
+    _req(dy, "dy", dt, n_out)
+    _req(wpk, "wpk", dt, d.K * 9 * d.C)
+    _req(dx, "dx", dt, n_in)
+    cc = k1 = k2 = k3 = None
+    if bnbwd is not None:
+        cc, k1, k2, k3 = bnbwd
+        _req(cc, "c", dt, n_out)
+        for nm, t in (("k1", k1), ("k2", k2), ("k3", k3)):
+            _req(t, nm, torch.float32, d.K)
+    _opt(dc_out, "dc_out", dt, n_out)
+    _opt(act_out, "act_out", dt, n_in)
+    mc = msc = msh = None
+    nsh = 1
+    if mask is not None:
+        mc, msc, msh = mask
+        _req(mc, "mask_c", dt, n_in)
+        _req(msc, "mask_scale", torch.float32, d.C)
+        _req(msh, "mask_shift", torch.float32, d.C)
+        _req(sums, "sums", torch.float64)
+        nsh = sums.numel() // (2 * d.C)
+        if nsh * 2 * d.C != sums.numel():
+            raise ValueError("sums must be [nshard,2,C]")
+    elif sums is not None:
+        raise ValueError("sums without mask")
+    bh = {28: 7, 14: 14}.get(d.P, 0)
+    t = "DF16_" if dt == torch.float16 else "DF16b"
+    rc = _timed("conv_dgrad", d, dy.element_size(), lambda: lib.msfwsi_img3x3_s2_dgrad(
+        C.byref(d), _p(dy), _p(cc), _p(k1), _p(k2), _p(k3), _p(dc_out), _p(wpk), _p(dx), _p(mc), _p(msc), _p(msh), _p(act_out),
+        _p(sums), nsh, _stream()),
+        extra_elems=n_in * ((mask is not None) + (act_out is not None)) + n_out * ((bnbwd is not None) + (dc_out is not None)),
+        dtype=dy.dtype, symbol_override=f"img3x3_s2d_kernelI{t}Li{d.C}ELi{bh}ELi{d.Q}ELi{2 if bnbwd is not None else 0}EE")
+    if rc == -2:
+        return False
+    _lib.check(rc, "img3x3_s2_dgrad")
+    return True
+
+
 def _img3_symbol(d: ConvDesc, dt, pro: int, dgrad: bool) -> str:
     t = "DF16_" if dt == torch.float16 else "DF16b"
-    bh = {14: 14, 28: 7, 56: 4}[d.H]
+    bh = {14: 14, 28: 7, 56: 4}.get(d.H, 0)
     return f"img3x3_kernelI{t}Li{d.C}ELi{d.K}ELi{bh}ELi{d.W}ELi{pro}ELb{int(dgrad)}ELi1EE"  # (TN = 1: csrc/img3x3.hip)
 
 

@@ -201,8 +201,13 @@ def test_deep_blocks_on_the_image_stationary_kernels(hip_lib, monkeypatch, arch,
     bounds as the 64 x 64 run; the launches are counted so that a silent fallback to the gather kernel fails the test."""
     from msf_wsi_amd import kernels as kn
 
-    calls = {"fwd": 0, "dgrad": 0, "fused_bn": 0}
-    fwd, dgrad = kn.img3x3_fwd, kn.img3x3_dgrad
+    calls = {"fwd": 0, "dgrad": 0, "fused_bn": 0, "s2": 0}
+    fwd, dgrad, s2dgrad = kn.img3x3_fwd, kn.img3x3_dgrad, kn.img3x3_s2_dgrad
+
+    def count_s2(d, *a, **k):
+        calls["s2"] += 1
+        assert k.get("bnbwd") is not None and k.get("act_out") is not None
+        return s2dgrad(d, *a, **k)
 
     def count_fwd(*a, **k):
         calls["fwd"] += 1
@@ -218,15 +223,17 @@ def test_deep_blocks_on_the_image_stationary_kernels(hip_lib, monkeypatch, arch,
 
     monkeypatch.setattr(kn, "img3x3_fwd", count_fwd)
     monkeypatch.setattr(kn, "img3x3_dgrad", count_dgrad)
+    monkeypatch.setattr(kn, "img3x3_s2_dgrad", count_s2)
     stages = ("layer1.", "layer2.", "layer3.") if arch == "resnet50" else ("layer2.", "layer3.")
-    deep = lambda name: name.startswith(stages) and not name.endswith(".0")
+    # (resnet50: the strided first blocks of layer2 / layer3 too -- their conv2's input gradient is the one-launch strided kernel)
+    deep = lambda name: name.startswith(stages) and (not name.endswith(".0") or (arch == "resnet50" and name[:6] in ("layer2", "layer3")))
     worst, bad = run_blocks(arch, dtype, batch=3, size=224, only=deep)
     _report(f"deep blocks {arch} {dtype}", worst)
     assert not bad, [(k, f"{worst[k]:.2e}") for k in bad]
     nblk = {"resnet50": 2 + 3 + 5, "resnet18": 1 + 1}[arch]
-    assert len([k for k in worst if k.endswith(": out")]) == nblk
-    if arch == "resnet50":   # conv2 of every Bottleneck of the two stages but the strided first ones; bn2 folded into each
-        assert calls == {"fwd": 3 + 5, "dgrad": nblk, "fused_bn": nblk}  # (layer1's forward stays weights-stationary)
+    assert len([k for k in worst if k.endswith(": out")]) == nblk + (2 if arch == "resnet50" else 0)
+    if arch == "resnet50":   # conv2 of every Bottleneck of the three stages; bn2 folded into each gradient launch
+        assert calls == {"fwd": 3 + 5, "dgrad": nblk, "fused_bn": nblk, "s2": 2}  # (layer1's forward stays weights-stationary)
     else:                    # BasicBlocks: both 3x3 convs forward (the strided blocks' conv2 too), conv2's gradient
         assert calls["fwd"] == 2 * nblk + 2 and calls["dgrad"] == nblk and calls["fused_bn"] == 0
 

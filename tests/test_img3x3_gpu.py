@@ -169,3 +169,86 @@ def test_img3x3_other_geometries_are_declined(hip_lib):
     w = torch.zeros(512, 3, 3, 512, dtype=torch.bfloat16, device="cuda")
     assert not kn.img3x3_fwd(d, x, w, torch.empty_like(x))
     assert not kn.img3x3_dgrad(d, x, w, torch.empty_like(x))
+
+
+# N, P (= Q: the gradient's height), channels: dy [N, P, P, C] -> dx [N, 2P, 2P, C]
+S2_GEOMS = [(3, 28, 128), (2, 14, 256), (5, 14, 256), (4, 28, 128)]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", S2_GEOMS)
+@pytest.mark.parametrize("gate", [False, True])
+@pytest.mark.parametrize("bnbwd", [False, True])
+def test_img3x3_s2_dgrad(hip_lib, dt, geom, gate, bnbwd):
+    """the strided conv2's input gradient in one launch (four parity passes over one staged band) against fp64
+    conv2d_input and against msfwsi_conv_dgrad's four parity launches"""
+    from msf_wsi_amd import kernels as kn
+
+    N, P, Cn = geom
+    H = 2 * P
+    g = torch.Generator().manual_seed(34)
+    w = rnd((Cn, Cn, 3, 3), dt, g, 1.0 / math.sqrt(Cn * 9))
+    dy = rnd((N, Cn, P, P), dt, g)
+    c2 = rnd((N, Cn, P, P), dt, g)
+    c1 = rnd((N, Cn, H, H), dt, g)
+    k1, k2, k3 = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.1, torch.randn(Cn, generator=g) * 0.01
+    sc, sh = torch.rand(Cn, generator=g) - 0.3, torch.randn(Cn, generator=g) * 0.3
+    d = kn.conv_desc(dt, N, H, H, Cn, Cn, 3, 3, 2, 1)
+    assert (d.P, d.Q) == (P, P) and kn.img3x3_s2_dgrad_supported(d)
+    dyd, wd = nhwc(dy).cuda(), nhwc(w).cuda()
+    wpk = kn.img3x3_pack_weights(wd, torch.empty_like(wd), 2)
+    dc_ref, kw, dc = dy, {}, None
+    if bnbwd:
+        v = lambda t: t.view(1, -1, 1, 1)
+        dc_ref = torch.addcmul(torch.addcmul(v(k3), v(k2), c2.float()), v(k1), dy.float()).to(dt)
+        dc = torch.empty(N, P, P, Cn, dtype=dt, device="cuda")
+        kw = dict(bnbwd=(nhwc(c2).cuda(), k1.cuda(), k2.cuda(), k3.cuda()), dc_out=dc)
+    ref = torch.nn.grad.conv2d_input((N, Cn, H, H), w.double(), dc_ref.double(), stride=2, padding=1)
+    if gate:
+        ref = ref * ((c1.float() * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0)
+        sums = kn.new_stats(Cn)
+        c1d = nhwc(c1).cuda()
+        act = torch.empty(N, H, H, Cn, dtype=dt, device="cuda")
+        kw.update(mask=(c1d, sc.cuda(), sh.cuda()), sums=sums, act_out=act)
+    dx = torch.full((N, H, H, Cn), float("nan"), dtype=dt, device="cuda")  # every output pixel must be written
+    assert kn.img3x3_s2_dgrad(d, dyd, wpk, dx, **kw)
+    torch.cuda.synchronize()
+    assert rel(dx.float().cpu().permute(0, 3, 1, 2), ref) < tol(dt) * 2
+    if bnbwd:
+        got, want = dc.float().cpu().permute(0, 3, 1, 2), dc_ref.float()
+        assert (got != want).float().mean().item() < 2e-3 and rel(got, want) < 1e-3
+    if gate:
+        s = sums.sum(0).cpu()
+        gd = dx.double().cpu().reshape(-1, Cn)
+        assert torch.allclose(s[0], gd.sum(0), rtol=1e-5, atol=1e-4)
+        assert torch.allclose(s[1], (gd * c1d.double().cpu().reshape(-1, Cn)).sum(0), rtol=1e-5, atol=1e-4)
+        want = torch.empty_like(act)
+        kn.bn_act(c1d, sc.cuda(), sh.cuda(), want, relu=True)
+        torch.cuda.synchronize()
+        assert torch.equal(act, want)
+    dx2 = torch.empty_like(dx)
+    kw2 = dict(mask=kw["mask"], sums=kn.new_stats(Cn)) if gate else {}
+    kn.conv_dgrad(d, nhwc(dc_ref).cuda(), wd, dx2, **kw2)
+    torch.cuda.synchronize()
+    assert rel(dx, dx2) < tol(dt) / 2
+
+
+def test_img3x3_s2_dgrad_declines_other_geometries(hip_lib):
+    from msf_wsi_amd import kernels as kn
+    from msf_wsi_amd._lib import MsfwsiHipError
+
+    for dt, H, Cn, K, stride in ((torch.bfloat16, 28, 512, 512, 2), (torch.bfloat16, 56, 128, 128, 1),
+                                 (torch.float32, 56, 128, 128, 2), (torch.bfloat16, 56, 128, 256, 2)):
+        assert not kn.img3x3_s2_dgrad_supported(kn.conv_desc(dt, 2, H, H, Cn, K, 3, 3, stride, 1))
+    d = kn.conv_desc(torch.bfloat16, 2, 28, 28, 512, 512, 3, 3, 2, 1)
+    dy = torch.zeros(2, 14, 14, 512, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(512, 3, 3, 512, dtype=torch.bfloat16, device="cuda")
+    assert not kn.img3x3_s2_dgrad(d, dy, w, torch.zeros(2, 28, 28, 512, dtype=torch.bfloat16, device="cuda"))
+    # in place only where a workgroup owns the whole gradient image
+    d = kn.conv_desc(torch.bfloat16, 2, 56, 56, 128, 128, 3, 3, 2, 1)
+    dy = torch.zeros(2, 28, 28, 128, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(128, 3, 3, 128, dtype=torch.bfloat16, device="cuda")
+    k = [torch.ones(128, device="cuda") for _ in range(3)]
+    with pytest.raises(MsfwsiHipError):
+        kn.img3x3_s2_dgrad(d, dy, w, torch.zeros(2, 56, 56, 128, dtype=torch.bfloat16, device="cuda"),
+                           bnbwd=(torch.zeros_like(dy), *k), dc_out=dy)

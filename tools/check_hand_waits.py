@@ -45,37 +45,42 @@ def kernels(lines):
 
 
 def loop_body(body):
-    """instructions of the MFMA loop in execution order of one iteration: hipcc labels every block of a loop with
-    `in Loop: Header=BBx_y`; blocks that sit before the header in the text (the latch) run at the end of an iteration"""
-    header = None
-    for i, ln in enumerate(body):
-        m = re.match(r"^\.L(BB\d+_\d+):.*Loop Header", ln)
-        if m:
-            for nxt in body[i + 1:]:
-                if re.match(r"^\.LBB", nxt):
-                    break
-                if "v_mfma" in nxt:
-                    header = m.group(1)
-                    break
-        if header:
-            break
-    if header is None:
-        return None
-    before, after, tail, cur, seen_header = [], [], [], None, False
+    """(instructions of the MFMA loop in execution order of one iteration, the code behind the loop in text order).
+    hipcc marks a loop header `.LBBx_y: ... Loop Header` (for nested loops on comment lines under the label) and every other
+    block of the loop `in Loop: Header=BBx_y`; blocks that sit before the header in the text (the latch) run at the end of an
+    iteration.  The loop taken is the first (innermost) one whose own blocks hold MFMAs."""
+    # split into blocks: (label or None, marker text, lines)
+    blocks, cur = [], [None, "", []]
     for ln in body:
         m = re.match(r"^\.L(BB\d+_\d+):(.*)", ln)
-        if m:
-            if m.group(1) == header:
-                cur, seen_header = after, True
-            elif f"Header={header} " in m.group(2) + " ":
-                cur = after if seen_header else before
-            else:
-                cur = tail if seen_header else None  # code after the loop (in text order)
-            continue
-        if re.match(r"^; %bb\.", ln) and cur is after and seen_header and after and re.search(r"s_cbranch_\w+\s+\.L" + header, after[-1]):
-            cur = tail  # the fall-through block behind the back-edge branch
-        if cur is not None:
-            cur.append(ln)
+        m2 = re.match(r"^; %bb\.\d+:(.*)", ln)
+        if m or m2:
+            blocks.append(cur)
+            cur = [m.group(1) if m else None, (m.group(2) if m else m2.group(1)), []]
+        elif re.match(r"^\s+;", ln) and not cur[2]:
+            cur[1] += " " + ln.strip()  # continuation of the block's marker comment (nested loops)
+        else:
+            cur[2].append(ln)
+    blocks.append(cur)
+    header = None
+    for label, mark, lines in blocks:
+        if label and "Loop Header" in mark:
+            own = [b for b in blocks if b[0] == label or f"in Loop: Header={label} " in b[1] + " "]
+            if any("v_mfma" in ln for b in own for ln in b[2]):
+                header = label
+                break
+    if header is None:
+        return None
+    before, after, tail, seen, done = [], [], [], False, False
+    for label, mark, lines in blocks:
+        mine = label == header or f"in Loop: Header={header} " in mark + " "
+        if label == header:
+            seen = True
+        if mine and not done:
+            (after if seen else before).extend(lines)
+        elif seen:
+            done = True  # the first foreign block behind the header ends the loop's text
+            tail.extend(lines)
     return after + before, tail
 
 
@@ -157,7 +162,7 @@ def audit(name, body):
 def main():
     # (source, kernel-name test): every instance whose block / k loop issues its loads from inline asm
     targets = [("panel.hip", lambda n: "panel_kernel" in n and n.endswith("Lb1EEEvNS_11PanelParamsE")),
-               ("img3x3.hip", lambda n: "img3x3_kernel" in n)]
+               ("img3x3.hip", lambda n: "img3x3_kernel" in n or "img3x3_s2d_kernel" in n)]
     if len(sys.argv) > 1:
         files = [(a, None) for a in sys.argv[1:]]
     else:
@@ -179,6 +184,9 @@ def main():
             if any(test(name) for _, test in targets):
                 n += 1
                 found += audit(name, body)
+    if len(sys.argv) <= 1:
+        for path, _ in files:
+            os.remove(path)
     print(f"{n} hand-counted instances audited, {len(found)} findings")
     for f in found:
         print("  " + f)

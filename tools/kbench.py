@@ -359,7 +359,37 @@ def case_gramsplit():
         lib.msfwsi_set_tuning(15, 0)
 
 
-CASES = {"gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+def case_s2dgrad():
+    """the strided conv2's input gradient (layer2.0 / layer3.0): four parity launches of the gather kernel (+ the stand-alone
+    BatchNorm passes around them) against the one-launch image-stationary kernel with both folded in"""
+    for P, Cn in ((28, 128), (14, 256)):
+        N, H = NIMG, 2 * P
+        d = kn.conv_desc(DT, N, H, H, Cn, Cn, 3, 3, 2, 1)
+        Mo, Mi = N * P * P, N * H * H
+        dy, c2 = rnd(Mo, Cn, scale=0.05), rnd(Mo, Cn)
+        dc = torch.empty(Mo, Cn, dtype=DT, device="cuda")
+        c1 = rnd(Mi, Cn)
+        a1 = torch.empty(Mi, Cn, dtype=DT, device="cuda")
+        dx = torch.empty(Mi, Cn, dtype=DT, device="cuda")
+        w = rnd(Cn, 9 * Cn, scale=0.05).view(Cn, 3, 3, Cn)
+        wpk = kn.img3x3_pack_weights(w, torch.empty_like(w), 2)
+        sc, sh = torch.rand(Cn, device="cuda") + 0.5, torch.randn(Cn, device="cuda") * 0.3
+        k1, k2, k3 = torch.rand(Cn, device="cuda"), torch.randn(Cn, device="cuda") * 0.1, torch.randn(Cn, device="cuda") * 0.01
+        fl = 2.0 * Mo * Cn * Cn * 9
+        nb = (Mo + 2 * Mi) * Cn * 2
+        tag = f"s2dgrad {P}x{P} -> {H}x{H} C{Cn}"
+        report(f"{tag} gather (4 launches) + gate", timeit(lambda: kn.conv_dgrad(d, dy, w, dx, mask=(c1, sc, sh), sums=kn.new_stats(Cn, 2, "cuda"))), nb, fl)
+        report(f"{tag} image + gate", timeit(lambda: kn.img3x3_s2_dgrad(d, dy, wpk, dx, mask=(c1, sc, sh), sums=kn.new_stats(Cn, 2, "cuda"))), nb, fl)
+        report(f"{tag} bn_bwd_apply + gather + gate + bn_act (a1)",
+               timeit(lambda: (kn.bn_bwd_apply(dy, c2, k1, k2, k3, dc), kn.conv_dgrad(d, dc, w, dx, mask=(c1, sc, sh), sums=kn.new_stats(Cn, 2, "cuda")),
+                               kn.bn_act(c1, sc, sh, a1, relu=True))), nb + 3 * Mo * Cn * 2 + 2 * Mi * Cn * 2, fl)
+        report(f"{tag} image + gate, BN backward in the staging, a1 from the gate",
+               timeit(lambda: kn.img3x3_s2_dgrad(d, dy, wpk, dx, bnbwd=(c2, k1, k2, k3), dc_out=dc, mask=(c1, sc, sh),
+                                                 sums=kn.new_stats(Cn, 2, "cuda"), act_out=a1)), nb + 2 * Mo * Cn * 2 + Mi * Cn * 2, fl)
+        del dy, c2, dc, c1, a1, dx
+
+
+CASES = {"s2dgrad": case_s2dgrad, "gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():
