@@ -1,11 +1,12 @@
 #!/bin/bash
 # GPU box: the evidence set of a round -- kernel traces (three streams / one stream), counter summary, layer report, the default
-# bench line, and the single-rank RCCL run beside a plain run on the same box.   usage: tools/final_profile.sh (edit the tag)
-tools/profile_step.sh r05c_c2_resnet50_b256_bf16 > gpurun_out/r05c_profile.log 2>&1; tail -2 gpurun_out/r05c_profile.log
-KT_ONLY=1 MSFWSI_DUAL_STREAM=0 tools/profile_step.sh r05c_c2_resnet50_b256_bf16_one_stream > gpurun_out/r05c_profile1.log 2>&1
-timeout -k 10 400 python bench.py --steps 3 --warmup 2 --layer-report gpurun_out/r05c_layer_report.tsv > gpurun_out/r05c_bench_layers.json 2>/dev/null
-timeout -k 10 400 python bench.py > gpurun_out/r05c_bench_default.json 2>gpurun_out/r05c_bench_default.err
+# bench line, and the single-rank RCCL run beside a plain run on the same box.   usage: tools/final_profile.sh [tag]   (default r05c)
+TAG=${1:-r05c}
+tools/profile_step.sh ${TAG}_c2_resnet50_b256_bf16 > gpurun_out/${TAG}_profile.log 2>&1; tail -2 gpurun_out/${TAG}_profile.log
+KT_ONLY=1 MSFWSI_DUAL_STREAM=0 tools/profile_step.sh ${TAG}_c2_resnet50_b256_bf16_one_stream > gpurun_out/${TAG}_profile1.log 2>&1
+timeout -k 10 400 python bench.py --steps 3 --warmup 2 --layer-report gpurun_out/${TAG}_layer_report.tsv > gpurun_out/${TAG}_bench_layers.json 2>/dev/null
+timeout -k 10 400 python bench.py > gpurun_out/${TAG}_bench_default.json 2>gpurun_out/${TAG}_bench_default.err
 PORT=29517
-MSFWSI_FORCE_SYNC=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT timeout -k 10 400 python bench.py --gpus 1 --steps 5 --warmup 3 --no-cpu-baseline > gpurun_out/r05c_bench_force_sync_rccl.json 2>gpurun_out/r05c_force_sync.err
-timeout -k 10 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline > gpurun_out/r05c_bench_plain_same_box.json 2>/dev/null
-cut -c1-200 gpurun_out/r05c_bench_default.json gpurun_out/r05c_bench_force_sync_rccl.json gpurun_out/r05c_bench_plain_same_box.json
+MSFWSI_FORCE_SYNC=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT timeout -k 10 400 python bench.py --gpus 1 --steps 5 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_force_sync_rccl.json 2>gpurun_out/${TAG}_force_sync.err
+timeout -k 10 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_plain_same_box.json 2>/dev/null
+cut -c1-200 gpurun_out/${TAG}_bench_default.json gpurun_out/${TAG}_bench_force_sync_rccl.json gpurun_out/${TAG}_bench_plain_same_box.json
