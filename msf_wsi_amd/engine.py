@@ -339,6 +339,8 @@ class Engine:
         # the strided conv2 of layer2.0 / layer3.0: input gradient in ONE launch (msfwsi_img3x3_s2_dgrad) instead of four
         # parity launches, with bn2's backward and the a1 by-product as above
         self.img3x3_s2 = os.environ.get("MSFWSI_IMG3X3_S2", "1") != "0"
+        self.img3x3_min_fill = float(os.environ.get("MSFWSI_IMG3X3_MIN_FILL", "1.0"))  # rounds of workgroups, see _img3_fills
+        self._ncu: Dict[object, int] = {}
         self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
         self.panel_fwd_min_k = int(os.environ.get("MSFWSI_PANEL_FWD_MIN_K", "128"))  # 56x56 / 64 channels: the gather kernel is at the HBM roof
         self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
@@ -732,7 +734,8 @@ class Engine:
         bias = getattr(op, "bias", None)
         xin, pro = x, (x_pro.scale, x_pro.shift) if x_pro is not None else None
         fuse_pro = (pro is not None and self.fuse_pro3x3 and bias is None and not pad_c and kn.conv3x3_stationary(d))
-        wimg = self._img3_weights(op, w, dtype, dgrad=False) if not pad_c and kn.img3x3_supported(d) else None
+        wimg = (self._img3_weights(op, w, dtype, dgrad=False)
+                if not pad_c and kn.img3x3_supported(d) and self._img3_fills(d, x.device) else None)
         if wimg is not None:
             # image-stationary kernel: the band is staged once, BatchNorm + ReLU of the producer applied on the way
             if not kn.img3x3_fwd(d, x, wimg, c, stats=stats, pro=pro):
@@ -1484,6 +1487,17 @@ class Engine:
             return False
         return kn.panel_supported(first.desc, True)
 
+    def _img3_fills(self, d, dev) -> bool:
+        """an image-stationary launch has one workgroup per band of an image: it pays only when the bands fill the chip at
+        least once (ResNet-18 at 8 tile pairs has 128 images per view: 128 workgroups of 55 us each on 256 CUs were 10 %
+        of the step slower than the gather kernel's 392 small tiles, profiles/r05_ab_small_batches.txt)"""
+        rows = d.P if d.stride == 2 else d.H  # the staged tensor: the gradient for the strided layer
+        bands, per_cu = {14: (1, 1), 28: (4, 2), 56: (14, 3)}.get(rows, (0, 1))
+        ncu = self._ncu.get(dev)
+        if ncu is None:
+            ncu = self._ncu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+        return d.N * bands >= self.img3x3_min_fill * ncu * per_cu
+
     def _img3_dgrad_weights(self, u: Unit, prev: Unit, dtype, with_bn: bool = True) -> Optional[torch.Tensor]:
         """the packed filter if u's input gradient runs on the image-stationary kernel: a served 3x3 geometry whose operand
         is prev's raw output under prev's BatchNorm + ReLU (conv2 of a Bottleneck of layer2 / layer3; of layer1 only when the
@@ -1491,6 +1505,8 @@ class Engine:
         if u.x_pro is None or u.x is not prev.c or prev.st is None or u.s2d:
             return None
         if not (kn.img3x3_supported(u.desc) or kn.img3x3_s2_dgrad_supported(u.desc)):
+            return None
+        if not self._img3_fills(u.desc, prev.c.device):
             return None
         if u.desc.C == 64 and not with_bn:
             return None
