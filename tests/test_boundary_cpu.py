@@ -128,3 +128,57 @@ def test_panel_hand_counted_waits_audit():
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 findings" in r.stdout
+
+
+def test_gate_byte_layout_matches_the_header():
+    """the ReLU-gate bytes' layout (include/msfwsi_hip.h at msfwsi_conv_fwd_post, csrc/common.h gate_off) restated from the
+    header's words, against the host-side index kernels.gate_pack / gate_unpack use: linear where a row does not hold whole
+    dwords of gate bytes, else 512-byte groups of 128 rows x 4 chunks; pack -> unpack is the identity, the buffer is padded
+    to whole 128-row groups, and no two (row, chunk) pairs share a byte"""
+    import torch
+
+    from msf_wsi_amd import kernels as kn
+
+    for rows, Cn, dt in ((5, 24, torch.bfloat16), (130, 64, torch.bfloat16), (257, 256, torch.float16), (128, 32, torch.float32),
+                         (3, 2048, torch.bfloat16), (200, 96, torch.bfloat16)):
+        vec = 4 if dt == torch.float32 else 8
+        cpr = Cn // vec
+
+        def header_offset(m, c):
+            if cpr % 4:
+                return m * cpr + c
+            return ((m // 128) * (cpr // 4) + c // 4) * 512 + (m % 128) * 4 + c % 4
+
+        idx = kn._gate_index(rows, cpr, "cpu")
+        want = torch.tensor([[header_offset(m, c) for c in range(cpr)] for m in range(rows)])
+        assert torch.equal(idx, want)
+        n = kn.gate_numel(rows, Cn, dt)
+        assert n == (rows * cpr if cpr % 4 else (rows + 127) // 128 * 128 * cpr)
+        assert int(idx.max()) < n and idx.unique().numel() == rows * cpr
+        g = torch.Generator().manual_seed(rows)
+        lin = torch.randint(0, 256, (rows, cpr), generator=g, dtype=torch.uint8)
+        buf = kn.gate_pack(lin, Cn, dt)
+        assert buf.numel() == n and torch.equal(kn.gate_unpack(buf, rows, Cn, dt), lin)
+
+
+def test_image_kernels_are_chosen_only_when_their_bands_fill_the_chip(monkeypatch):
+    """Engine._img3_fills: one workgroup per band of an image -- 14 x 14: one band, one workgroup per CU; 28 x 28: four bands,
+    two per CU; 56 x 56: fourteen bands, three per CU; the strided gradient is keyed on the gradient's height"""
+    import types
+
+    import torch
+
+    from msf_wsi_amd import engine as eng_mod
+
+    e = eng_mod.Engine.__new__(eng_mod.Engine)
+    e.img3x3_min_fill = 1.0
+    e._ncu = {"dev": 256}
+    d = lambda N, H, stride=1: types.SimpleNamespace(N=N, H=H, P=H // stride, stride=stride)
+    assert not e._img3_fills(d(255, 14), "dev") and e._img3_fills(d(256, 14), "dev")
+    assert not e._img3_fills(d(127, 28), "dev") and e._img3_fills(d(128, 28), "dev")
+    assert not e._img3_fills(d(54, 56), "dev") and e._img3_fills(d(55, 56), "dev")
+    assert not e._img3_fills(d(127, 56, 2), "dev") and e._img3_fills(d(128, 56, 2), "dev")   # gradient 28 x 28
+    assert not e._img3_fills(d(255, 28, 2), "dev") and e._img3_fills(d(256, 28, 2), "dev")   # gradient 14 x 14
+    assert not e._img3_fills(d(4096, 7), "dev")
+    e.img3x3_min_fill = 0.0
+    assert e._img3_fills(d(1, 14), "dev")
