@@ -221,6 +221,12 @@ int msfwsi_conv3x3_dgrad(const msfwsi_conv_desc* d, const void* dy, const void* 
  * Replaces: convolution_backward(weight) / linear backward(weight), tools/ssl_train.py:472. */
 int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* pro_scale,
                       const float* pro_shift, int target_blocks, void* stream);
+/* msfwsi_conv_wgrad for a 1x1 / stride-1 conv (16-bit storage) whose operand x is the producer's RAW output under pro_scale /
+ * pro_shift, with the normalised operand as a by-product: act_out [N*H*W][C] receives relu(pro_scale*x + pro_shift), bit for
+ * bit what msfwsi_bn_act writes.  MSFWSI_EUNSUPPORTED for other geometries / fp32.
+ * Replaces: native_batch_norm (apply) + relu + convolution_backward(weight), src/models/resnet.py:128-131 backwards. */
+int msfwsi_conv_wgrad_act(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, const float* pro_scale,
+                          const float* pro_shift, void* act_out, int target_blocks, void* stream);
 /* dw[K][R][S][C] (fp32) = dy^T * x, STORED (not accumulated): one workgroup per gradient tile over all pixels, no
  * atomics, dw need not be cleared.  For gradients with ONE launch per step and few rows -- the heads' Linear layers
  * (both views stacked), whose fp32 matrices (fuser: 1.36 GB each) are then written once instead of cleared, read and

@@ -36,6 +36,7 @@ SIGNATURES = {
     "msfwsi_conv_fwd": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_conv_dgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_conv_wgrad": [_desc, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_conv_wgrad_act": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_conv_wgrad_store": [_desc, _vp, _vp, _vp, _vp],
     "msfwsi_gram": [_desc, _vp, _vp, _vp],
     "msfwsi_stem_wgrad_bnbwd": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

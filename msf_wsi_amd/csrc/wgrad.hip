@@ -39,6 +39,7 @@ struct WgradParams {
                    // then moves the sum by ~1e-16, invisible after rounding to fp32 -- run-to-run reproducible forward)
     const float* pro_scale;
     const float* pro_shift;
+    void* aout;    // XPRO, 1x1 / stride 1 only, nullable: relu(pro_scale * x + pro_shift) [M][C], written by the tiles of row 0
     int N, H, W, C;
     int P, Q, K;
     int R, S, stride, pad;
@@ -312,7 +313,9 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
             }
         }
     };
-    auto commit = [&](int st) {
+    // (mb: the first pixel row of the slab being committed -- the activation by-product's address, 1x1 convs only)
+    T* __restrict__ aout = XPRO && tile_i == 0 ? reinterpret_cast<T*>(prm.aout) : nullptr;
+    auto commit = [&](int st, int mb) {
         if (XPRO) {
             char* Bb = Bs + st * Cfg::B_BYTES;
 #pragma unroll
@@ -324,6 +327,9 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) f[e] = fmaxf(fmaf(f[e], psc[i][e], psh[i][e]), 0.f);
                     v = pack16<T>(f);
+                    // the normalised operand is what msfwsi_bn_act would write: the tiles of output row 0 store it, so that the
+                    // launches that need it materialised (the two-source input gradient of the folded tail) skip that pass
+                    if (aout != nullptr) *reinterpret_cast<uint4*>(aout + (long)(mb + b_row[i]) * prm.C + b_c[i]) = v;
                 }
                 *reinterpret_cast<uint4*>(Bb + (i * NW + wave) * 1024 + lane * 16) = v;
             }
@@ -389,13 +395,13 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
         }
     } else {
         fetch(mbeg, 0);
-        commit(0);
+        commit(0, mbeg);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nk) fetch(mbeg + (kt + 1) * BKM, buf ^ 1);
             compute(buf);
-            if (kt + 1 < nk) commit(buf ^ 1);
+            if (kt + 1 < nk) commit(buf ^ 1, mbeg + (kt + 1) * BKM);
             __syncthreads();
         }
     }
@@ -836,10 +842,10 @@ extern "C" int msfwsi_stem_wgrad_bnbwd(const msfwsi_conv_desc* d, const void* x,
 
 static int wgrad_generic(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw, double* dw64,
                          const float* pro_scale, const float* pro_shift, int target_blocks, hipStream_t st,
-                         int store = 0) {
+                         int store = 0, void* aout = nullptr) {
     WgradParams prm{};
     prm.x = x; prm.dy = dy; prm.dw = dw; prm.dw64 = dw64; prm.store = store;
-    prm.pro_scale = pro_scale; prm.pro_shift = pro_shift;
+    prm.pro_scale = pro_scale; prm.pro_shift = pro_shift; prm.aout = aout;
     prm.N = d->N; prm.H = d->H; prm.W = d->W; prm.C = d->C;
     prm.P = d->P; prm.Q = d->Q; prm.K = d->K;
     prm.R = d->R; prm.S = d->S; prm.stride = d->stride; prm.pad = d->pad;
@@ -885,6 +891,25 @@ extern "C" int msfwsi_conv_wgrad(const msfwsi_conv_desc* d, const void* x, const
         return launch_wgrad_os<_Float16>(d, x, dy, dw, pro_scale, pro_shift, st0);
     }
     return wgrad_generic(d, x, dy, dw, nullptr, pro_scale, pro_shift, target_blocks, reinterpret_cast<hipStream_t>(stream));
+}
+
+// msfwsi_conv_wgrad for a 1x1 / stride 1 conv whose operand is the producer's raw output under its BatchNorm + ReLU, with the
+// normalised operand as a by-product: the register staging that applies relu(scale * x + shift) also stores it to act_out
+// (bit for bit msfwsi_bn_act's output).  The folded Bottleneck tail's M = g^T a2 launch uses it so that a2 -- which the
+// two-source input gradient needs materialised -- costs no pass of its own (src/models/resnet.py:128-131 backwards).
+extern "C" int msfwsi_conv_wgrad_act(const msfwsi_conv_desc* d, const void* x, const void* dy, float* dw,
+                                     const float* pro_scale, const float* pro_shift, void* act_out, int target_blocks,
+                                     void* stream) {
+    if (d == nullptr || x == nullptr || dy == nullptr || dw == nullptr || pro_scale == nullptr || pro_shift == nullptr ||
+        act_out == nullptr || act_out == x)
+        return MSFWSI_EINVAL;
+    if (d->dtype != MSFWSI_DT_BF16 && d->dtype != MSFWSI_DT_F16) return MSFWSI_EUNSUPPORTED;
+    if (d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->P != d->H || d->Q != d->W) return MSFWSI_EUNSUPPORTED;
+    if (d->C % 8 != 0 || d->K % 8 != 0) return MSFWSI_EUNSUPPORTED;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0) return MSFWSI_EINVAL;
+    if ((long)d->N * d->H * d->W > 0x7fffffffL) return MSFWSI_EINVAL;
+    return wgrad_generic(d, x, dy, dw, nullptr, pro_scale, pro_shift, target_blocks, reinterpret_cast<hipStream_t>(stream), 0,
+                         act_out);
 }
 
 // dw = dy^T x, STORED: every gradient tile is computed by one workgroup over all pixels and written once -- no atomics,

@@ -339,6 +339,9 @@ class Engine:
         # the strided conv2 of layer2.0 / layer3.0: input gradient in ONE launch (msfwsi_img3x3_s2_dgrad) instead of four
         # parity launches, with bn2's backward and the a1 by-product as above
         self.img3x3_s2 = os.environ.get("MSFWSI_IMG3X3_S2", "1") != "0"
+        # the folded tail's backward: a2 = relu(bn2(c2)) as a by-product of the M = g^T a2 launch (msfwsi_conv_wgrad_act)
+        self.fuse_a2_wgrad = os.environ.get("MSFWSI_FUSE_A2_WGRAD", "1") != "0"
+        self.fuse_a2_wgrad_max_c = int(os.environ.get("MSFWSI_FUSE_A2_WGRAD_MAX_C", "64"))
         self.img3x3_min_fill = float(os.environ.get("MSFWSI_IMG3X3_MIN_FILL", "1.0"))  # rounds of workgroups, see _img3_fills
         self._ncu: Dict[object, int] = {}
         self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
@@ -1371,16 +1374,24 @@ class Engine:
             kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, None,
                              rec.ds.c if rec.ds is not None and not ds_fold else None, g, sums, rec.HW)
         a2 = torch.empty_like(last.x)
+        W = WeightStore.physical(last.op.weight).view(K, 1, 1, Cw)
+        Mm = kn.zeros((K, 1, 1, Cw), torch.float32, dev)
+        fused_a2 = False
         if last.gram is not None:  # Gram matrix and column sums of a2 kept by the fused forward
             A, sa = last.gram
-            kn.bn_act(last.x, last.x_pro.scale, last.x_pro.shift, a2, relu=True)
+            # 64 channels (layer1, HBM-bound): M = g^T a2 with bn2 + ReLU applied in the weight-gradient kernel's register
+            # staging, which also writes a2 for the two-source launch below -- 1.41 (+ the write) against 0.68 + 1.57 ms of
+            # bn_act + the DMA-staged launch; wider layers lose with register staging (profiles/r05_kbench_mwgrad.txt)
+            fused_a2 = (self.fuse_a2_wgrad and Cw <= self.fuse_a2_wgrad_max_c and dtype != torch.float32
+                        and kn.conv_wgrad_act(d, last.x, g, Mm, (last.x_pro.scale, last.x_pro.shift), a2))
+            if not fused_a2:
+                kn.bn_act(last.x, last.x_pro.scale, last.x_pro.shift, a2, relu=True)
         else:  # relu(bn2(c2)) and its column sums in one pass
             A = None
             sa = kn.zeros((Cw,), torch.float64, dev)
             kn.bn_act_sum(last.x, last.x_pro.scale, last.x_pro.shift, a2, sa)
-        W = WeightStore.physical(last.op.weight).view(K, 1, 1, Cw)
-        Mm = kn.zeros((K, 1, 1, Cw), torch.float32, dev)
-        kn.conv_wgrad(d, a2, g, Mm)
+        if not fused_a2:
+            kn.conv_wgrad(d, a2, g, Mm)
         dsq = kn.conv_desc(dtype, d.N, d.P, d.Q, Cw, Cw, 1, 1, 1, 0)
         if A is None:
             A = kn.zeros((Cw, 1, 1, Cw), torch.float32, dev)

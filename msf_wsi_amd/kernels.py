@@ -670,6 +670,27 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, pro=None, target_blocks=0):
     return dw
 
 
+def conv_wgrad_act(d: ConvDesc, x, dy, dw, pro, act_out, target_blocks=0) -> bool:
+    """conv_wgrad of a 1x1 / stride-1 conv with pro = (scale, shift), and act_out <- relu(scale*x + shift) (= bn_act's output)
+    from the same register staging; False where the library declines (other geometries, fp32)"""
+    lib = _lib.load()
+    dt = x.dtype
+    _req(x, "x", dt, d.N * d.H * d.W * d.C)
+    _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
+    _req(dw, "dw", torch.float32, d.K * d.R * d.S * d.C)
+    _req(act_out, "act_out", dt, d.N * d.H * d.W * d.C)
+    ps, psh = pro
+    _req(ps, "pro_scale", torch.float32, d.C)
+    _req(psh, "pro_shift", torch.float32, d.C)
+    rc = _timed("conv_wgrad", d, x.element_size(), lambda: lib.msfwsi_conv_wgrad_act(
+        C.byref(d), _p(x), _p(dy), _p(dw), _p(ps), _p(psh), _p(act_out), int(target_blocks), _stream()),
+        pro=True, dtype=x.dtype, extra_elems=act_out.numel())
+    if rc == -2:
+        return False
+    _lib.check(rc, "conv_wgrad_act")
+    return True
+
+
 def conv_wgrad_store(d: ConvDesc, x, dy, dw):
     """dw = dy^T x, stored (no atomics, dw need not be cleared): one launch per step and tensor -- the heads' Linear layers"""
     lib = _lib.load()

@@ -849,3 +849,36 @@ def test_conv3x3_halo_dgrad(hip_lib, dt, geom, fused):
         gd = dx.double().cpu().reshape(-1, Cc)
         assert torch.allclose(s[0], gd.sum(0), rtol=1e-5, atol=1e-4)
         assert torch.allclose(s[1], (gd * cd.double().cpu().reshape(-1, Cc)).sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [(3, 9, 7, 64, 256), (2, 14, 14, 128, 512), (1, 5, 5, 24, 40)])
+def test_conv_wgrad_act_writes_the_normalised_operand(hip_lib, dt, geom):
+    """msfwsi_conv_wgrad_act: the 1x1 weight gradient with the producer's BatchNorm + ReLU applied in the register staging,
+    and the normalised operand stored from there -- the gradient equals msfwsi_conv_wgrad's with the same prologue (the
+    same kernel instance and split: bit for bit under one workgroup per tile) and fp64, the by-product equals msfwsi_bn_act's
+    output bit for bit; other geometries decline"""
+    from helpers import tuned
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cc, K = geom
+    g = torch.Generator().manual_seed(41)
+    x = rnd((N * H * W, Cc), dt, g).to(dt).cuda()
+    dy = rnd((N * H * W, K), dt, g, 0.1).to(dt).cuda()
+    sc, sh = (torch.rand(Cc, generator=g) + 0.5).cuda(), (torch.randn(Cc, generator=g) * 0.3).cuda()
+    d = kn.conv_desc(dt, N, H, W, Cc, K, 1, 1, 1, 0)
+    want_a = torch.empty_like(x)
+    kn.bn_act(x, sc, sh, want_a, relu=True)
+    with tuned(hip_lib, {15: 1}):  # one workgroup per tile: no atomics, the sums repeat
+        dw0 = torch.zeros(K, Cc, device="cuda")
+        kn.conv_wgrad(d, x, dy, dw0, pro=(sc, sh))
+        dw1 = torch.zeros(K, Cc, device="cuda")
+        act = torch.full_like(x, float("nan"))
+        assert kn.conv_wgrad_act(d, x, dy, dw1, (sc, sh), act)
+    torch.cuda.synchronize()
+    assert torch.equal(act, want_a)
+    assert torch.equal(dw0, dw1)
+    ref = dy.double().cpu().t() @ want_a.double().cpu()
+    assert rel(dw1.cpu(), ref) < 2e-5
+    d3 = kn.conv_desc(dt, N, H, W, Cc, K, 3, 3, 1, 1)
+    assert not kn.conv_wgrad_act(d3, x, dy, torch.zeros(K, 9 * Cc, device="cuda"), (sc, sh), act)

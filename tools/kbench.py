@@ -389,7 +389,30 @@ def case_s2dgrad():
         del dy, c2, dc, c1, a1, dx
 
 
-CASES = {"s2dgrad": case_s2dgrad, "gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+def case_mwgrad():
+    """the folded tail's M = g^T a2 launch (conv3's weight-gradient basis): a2 = relu(bn2(c2)) materialised by a
+    bn_act pass first (what the engine does) against normalised in the weight-gradient kernel's register staging"""
+    for H, Cw in ((56, 64), (28, 128), (14, 256), (7, 512)):
+        N, K = NIMG, 4 * Cw
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cw, K, 1, 1, 1, 0)
+        c2 = rnd(M, Cw)
+        a2 = torch.empty(M, Cw, dtype=DT, device="cuda")
+        g = rnd(M, K, scale=0.05)
+        dw = torch.zeros(K, Cw, device="cuda")
+        sc, sh = torch.rand(Cw, device="cuda") + 0.5, torch.randn(Cw, device="cuda") * 0.3
+        fl = 2.0 * M * Cw * K
+        nb = (M * Cw + M * K) * 2
+        tag = f"mwgrad {H}x{H} a2[{Cw}] x g[{K}]"
+        report(f"{tag} wgrad, operand materialised", timeit(lambda: kn.conv_wgrad(d, a2, g, dw)), nb, fl)
+        report(f"{tag} bn_act + wgrad", timeit(lambda: (kn.bn_act(c2, sc, sh, a2, relu=True), kn.conv_wgrad(d, a2, g, dw))), nb + 2 * M * Cw * 2, fl)
+        report(f"{tag} wgrad, BN+ReLU in the staging", timeit(lambda: kn.conv_wgrad(d, c2, g, dw, pro=(sc, sh))), nb, fl)
+        report(f"{tag} wgrad, BN+ReLU in the staging, a2 written from there",
+               timeit(lambda: kn.conv_wgrad_act(d, c2, g, dw, (sc, sh), a2)), nb + M * Cw * 2, fl)
+        del c2, a2, g, dw
+
+
+CASES = {"mwgrad": case_mwgrad, "s2dgrad": case_s2dgrad, "gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():
