@@ -23,6 +23,9 @@
 #ifndef MSFWSI_WGRAD_BIG_STAGES
 #define MSFWSI_WGRAD_BIG_STAGES 3  // LDS stages of the 256 x 256 tile (32 KiB each)
 #endif
+#ifndef MSFWSI_WGRAD_SMALL_STAGES
+#define MSFWSI_WGRAD_SMALL_STAGES 3  // LDS stages of the 4-wave tiles (A/B: make EXTRA=-DMSFWSI_WGRAD_SMALL_STAGES=2)
+#endif
 #ifndef MSFWSI_FETCH_FIRST
 #define MSFWSI_FETCH_FIRST 1  // DMA requests of slab kt+2 before the MFMAs of slab kt (0: after them; A/B: make EXTRA=-DMSFWSI_FETCH_FIRST=0)
 #endif
@@ -74,7 +77,7 @@ struct WgradCfg {
     static constexpr int B_BYTES = BKM * ROWJ;
     static constexpr int A_IT = A_BYTES / (1024 * NW);  // 1-KiB DMA instructions per wave per slab
     static constexpr int B_IT = B_BYTES / (1024 * NW);
-    static constexpr int NST = XPRO ? 2 : (NW >= 8 ? MSFWSI_WGRAD_BIG_STAGES : 3);
+    static constexpr int NST = XPRO ? 2 : (NW >= 8 ? MSFWSI_WGRAD_BIG_STAGES : MSFWSI_WGRAD_SMALL_STAGES);
     static constexpr int LDS_BYTES = NST * (A_BYTES + B_BYTES);
     static_assert(TI >= 1 && TJ >= 1, "tile too small");
     static_assert(A_IT >= 1 && B_IT >= 1, "tile too small");

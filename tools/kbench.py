@@ -412,7 +412,26 @@ def case_mwgrad():
         del c2, a2, g, dw
 
 
-CASES = {"mwgrad": case_mwgrad, "s2dgrad": case_s2dgrad, "gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+def case_wgradreg():
+    """HBM-bound 1x1 weight gradients at 56 x 56 whose operand is a block input (non-negative): the DMA-staged launch against
+    the register-staged one with a unit BatchNorm (relu(1 * x + 0) = x)"""
+    for H, Cn, K in ((56, 256, 64), (56, 256, 128), (56, 64, 64), (56, 64, 256), (28, 512, 128)):
+        N = NIMG
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cn, K, 1, 1, 1, 0)
+        x = rnd(M, Cn).abs_()
+        dy = rnd(M, K, scale=0.05)
+        dw = torch.zeros(K, Cn, device="cuda")
+        one, zero = torch.ones(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
+        fl = 2.0 * M * Cn * K
+        nb = (M * Cn + M * K) * 2
+        tag = f"wgradreg {H}x{H} x[{Cn}] dy[{K}]"
+        report(f"{tag} DMA-staged", timeit(lambda: kn.conv_wgrad(d, x, dy, dw)), nb, fl)
+        report(f"{tag} register-staged (unit prologue)", timeit(lambda: kn.conv_wgrad(d, x, dy, dw, pro=(one, zero))), nb, fl)
+        del x, dy, dw
+
+
+CASES = {"wgradreg": case_wgradreg, "mwgrad": case_mwgrad, "s2dgrad": case_s2dgrad, "gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():
