@@ -334,6 +334,9 @@ int msfwsi_stem_pool_bwd(int dtype, const void* dp, const unsigned char* argmax,
 /* out[n][c] = mean over HW of y[n][hw][c].  Replaces: AdaptiveAvgPool2d((1,1)) + flatten on the four
  * stage outputs, src/models/resnet.py:244-250. */
 int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW, int C, void* stream);
+/* The same pass also writing sout [N][ceil(H/2)][ceil(W/2)][C] = y[:, ::2, ::2, :] -- what msfwsi_pixel_stride(stride 2) makes
+ * for the next stage's strided downsample conv (src/models/resnet.py:181-185, 137): one read of y for both. */
+int msfwsi_gap_fwd_stride2(int dtype, const void* y, void* out, void* sout, int N, int H, int W, int C, void* stream);
 
 /* BatchNorm backward folded into the weights of the 1x1 conv W[K][C] that produced the BatchNorm input
  * (Bottleneck conv3 -> bn3, src/models/resnet.py:115-117, backward by autograd in the reference): with c = W a,

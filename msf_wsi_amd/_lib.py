@@ -57,6 +57,7 @@ SIGNATURES = {
     "msfwsi_nhwc_to_nchw": [_i, _vp, _vp, _i, _i, _l, _i, _vp],
     "msfwsi_dice_loss": [_i, _vp, _vp, _l, _i, _i, C.c_uint, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp],
     "msfwsi_gap_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "msfwsi_gap_fwd_stride2": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "msfwsi_bn_act_sum": [_i, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp],
     "msfwsi_fold_matvec": [_vp, _vp, _vp, _i, _i, _vp],
     "msfwsi_stem_conv_fwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_walk_kernel(
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void gap_fwd_kernel(const T* __restrict__ y, T* __restrict__ out, int N, int HW, int C, int cw,
-                               int nrl) {
+                               int nrl, T* __restrict__ sout = nullptr, int W = 0, FastDiv div_w = FastDiv{}) {
     // one workgroup per (channel block, image): lanes run along channels (coalesced 16-byte chunks of a pixel
     // row), `nrl` row lanes stride over the pixels, partial sums meet in LDS
     constexpr int VEC = ElemTraits<T>::VEC;
@@ -688,11 +688,20 @@ __global__ void gap_fwd_kernel(const T* __restrict__ y, T* __restrict__ out, int
     for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
     if (active) {
         const T* base = y + (long)n * HW * C + chunk * VEC;
+        // sout (nullable): the pixels of the even rows and columns as a dense [N][H/2][W/2][C] tensor -- the operand of the next
+        // stage's strided downsample branch (msfwsi_pixel_stride), taken from the pass that reads y anyway
+        const int Qs = (W + 1) >> 1;
+        T* sbase = sout != nullptr ? sout + (long)n * ((HW / W + 1) >> 1) * Qs * C + chunk * VEC : nullptr;
         for (int i = rl; i < HW; i += nrl) {
+            const uint4 v = *reinterpret_cast<const uint4*>(base + (long)i * C);
             float f[VEC];
-            unpack16<T>(*reinterpret_cast<const uint4*>(base + (long)i * C), f);
+            unpack16<T>(v, f);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+            if (sbase != nullptr) {
+                const unsigned h = fast_div((unsigned)i, div_w), w = (unsigned)i - h * (unsigned)W;
+                if (((h | w) & 1u) == 0) *reinterpret_cast<uint4*>(sbase + (long)((h >> 1) * Qs + (w >> 1)) * C) = v;
+            }
         }
     }
 #pragma unroll
@@ -1404,6 +1413,25 @@ extern "C" int msfwsi_gap_fwd(int dtype, const void* y, void* out, int N, int HW
     const size_t lds = (size_t)kThreads * vec * sizeof(float);
     MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(gap_fwd_kernel<T>, grid, dim3(kThreads), lds, ST(stream), (const T*)y,
                            (T*)out, N, HW, C, cw, nrl));
+    return msfwsi_launch_status();
+}
+
+// msfwsi_gap_fwd + msfwsi_pixel_stride(stride 2, expand 0) in one pass over y [N][H][W][C]: out = the pooled features, sout
+// [N][ceil(H/2)][ceil(W/2)][C] = y[:, ::2, ::2, :]
+extern "C" int msfwsi_gap_fwd_stride2(int dtype, const void* y, void* out, void* sout, int N, int H, int W, int C,
+                                      void* stream) {
+    MSFWSI_CHECK_ARG(dtype_ok(dtype) && y && out && sout && N > 0 && H > 0 && W > 0 && C % vec_of(dtype) == 0);
+    MSFWSI_CHECK_ARG(N <= 65535 && (long)H * W <= 0x7fffffffL);
+    const int vec = vec_of(dtype);
+    const int cpr = C / vec;
+    const int cw = cpr < kThreads ? cpr : kThreads;
+    const int HW = H * W;
+    int nrl = kThreads / cw;
+    if (nrl > HW) nrl = HW;
+    const dim3 grid((unsigned)((cpr + cw - 1) / cw), (unsigned)N);
+    const size_t lds = (size_t)kThreads * vec * sizeof(float);
+    MSFWSI_WITH_T(dtype, hipLaunchKernelGGL(gap_fwd_kernel<T>, grid, dim3(kThreads), lds, ST(stream), (const T*)y,
+                           (T*)out, N, HW, C, cw, nrl, (T*)sout, W, make_fastdiv((unsigned)W)));
     return msfwsi_launch_status();
 }
 

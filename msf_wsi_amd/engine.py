@@ -339,6 +339,7 @@ class Engine:
         # the strided conv2 of layer2.0 / layer3.0: input gradient in ONE launch (msfwsi_img3x3_s2_dgrad) instead of four
         # parity launches, with bn2's backward and the a1 by-product as above
         self.img3x3_s2 = os.environ.get("MSFWSI_IMG3X3_S2", "1") != "0"
+        self.gap_stride_fused = os.environ.get("MSFWSI_GAP_STRIDE", "1") != "0"  # gap_fwd + pixel_stride of a stage output in one pass
         # the folded tail's backward: a2 = relu(bn2(c2)) as a by-product of the M = g^T a2 launch (msfwsi_conv_wgrad_act)
         self.fuse_a2_wgrad = os.environ.get("MSFWSI_FUSE_A2_WGRAD", "1") != "0"
         self.fuse_a2_wgrad_max_c = int(os.environ.get("MSFWSI_FUSE_A2_WGRAD_MAX_C", "64"))
@@ -1047,7 +1048,9 @@ class Engine:
         y, h, w = pooled, P, Q
         blocks: List[BlockRec] = []
         feats: List[torch.Tensor] = []
-        for si, stage in enumerate(enc.stages()):
+        stages_list = list(enc.stages())
+        strided_next = None  # y[:, ::2, ::2, :] of the previous stage's output, when its pooling pass made it
+        for si, stage in enumerate(stages_list):
             nb = len(stage)
             for bi, blk in enumerate(stage):
                 cin = y.shape[-1]
@@ -1073,8 +1076,11 @@ class Engine:
                 if ds_tail:
                     xs = y
                     if dsc.stride[0] > 1:  # the branch's operand as a dense tensor: y[:, ::s, ::s, :]
-                        xs = torch.empty(N, gh, gw, cin, dtype=dtype, device=y.device)
-                        kn.pixel_stride(y, xs, dsc.stride[0], expand=False)
+                        xs = strided_next  # made by the previous stage's pooling pass (gap_fwd_stride2), if it could
+                        strided_next = None
+                        if xs is None or tuple(xs.shape) != (N, gh, gw, cin):
+                            xs = torch.empty(N, gh, gw, cin, dtype=dtype, device=y.device)
+                            kn.pixel_stride(y, xs, dsc.stride[0], expand=False)
                     got = self._ds_tail_fwd(conv3, main[-1][1], blk.downsample[0], blk.downsample[1], cur, cur_pro, xs,
                                             (N, gh, gw, cur.shape[-1]), dtype,
                                             want_bits=save and self.fuse_gate and self.gate_bits)
@@ -1121,7 +1127,16 @@ class Engine:
                     blocks.append(rec_b)
                 y, h, w = y_out, gh, gw
             f = torch.empty(N, y.shape[-1], dtype=dtype, device=x.device)
-            kn.gap_fwd(y, f, N, h * w, y.shape[-1])
+            # the next stage's strided downsample branch reads y[:, ::2, ::2, :]: written by the pooling pass over y
+            nxt = stages_list[si + 1][0] if si + 1 < len(stages_list) else None
+            nds = getattr(nxt, "downsample", None)
+            strided_next = None
+            if (self.gap_stride_fused and nds is not None and isinstance(nds[0], nn.Conv2d) and nds[0].stride == (2, 2)
+                    and nds[0].kernel_size == (1, 1) and self.fold_ds_strided and hasattr(nxt, "conv3")):
+                strided_next = torch.empty(N, (h + 1) // 2, (w + 1) // 2, y.shape[-1], dtype=dtype, device=x.device)
+                kn.gap_fwd_stride2(y, f, strided_next, N, h, w, y.shape[-1])
+            else:
+                kn.gap_fwd(y, f, N, h * w, y.shape[-1])
             feats.append(f)
         if not save:
             return EncPass(enc, N, H, W, None, None, None, None, [], feats, x_src=x, saved=False)

@@ -985,6 +985,17 @@ def gap_fwd(y, out, N, HW, Cn):
     return out
 
 
+def gap_fwd_stride2(y, out, sout, N, H, W, Cn):
+    """gap_fwd + pixel_stride(stride 2) in one pass: out [N][C] pooled features, sout = y[:, ::2, ::2, :]"""
+    lib = _lib.load()
+    _req(y, "y", None, N * H * W * Cn)
+    _req(out, "out", y.dtype, N * Cn)
+    _req(sout, "sout", y.dtype, N * ((H + 1) // 2) * ((W + 1) // 2) * Cn)
+    _stream_timed("gap_fwd", y.element_size() * (N * H * W * Cn + sout.numel()), lambda: _lib.check(
+        lib.msfwsi_gap_fwd_stride2(dt_of(y), _p(y), _p(out), _p(sout), N, H, W, Cn, _stream()), "gap_fwd_stride2"))
+    return out
+
+
 def fold_dots(W, Mm, out):
     """out[k] = sum_c W[k][c] * Mm[k][c]   (fp64; the sum over pixels of g*c for c = W a, Mm = g^T a)"""
     lib = _lib.load()

@@ -882,3 +882,25 @@ def test_conv_wgrad_act_writes_the_normalised_operand(hip_lib, dt, geom):
     assert rel(dw1.cpu(), ref) < 2e-5
     d3 = kn.conv_desc(dt, N, H, W, Cc, K, 3, 3, 1, 1)
     assert not kn.conv_wgrad_act(d3, x, dy, torch.zeros(K, 9 * Cc, device="cuda"), (sc, sh), act)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(3, 8, 8, 64), (2, 7, 9, 32), (5, 14, 14, 256)])
+def test_gap_fwd_stride2_is_gap_fwd_and_pixel_stride(hip_lib, dt, geom):
+    """one pass over a stage output: pooled features bit for bit msfwsi_gap_fwd's, the strided copy bit for bit
+    msfwsi_pixel_stride's (odd extents included)"""
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cn = geom
+    g = torch.Generator().manual_seed(42)
+    y = rnd((N, H, W, Cn), dt, g).to(dt).cuda()
+    f0 = torch.empty(N, Cn, dtype=dt, device="cuda")
+    kn.gap_fwd(y, f0, N, H * W, Cn)
+    s0 = torch.empty(N, (H + 1) // 2, (W + 1) // 2, Cn, dtype=dt, device="cuda")
+    kn.pixel_stride(y, s0, 2, expand=False)
+    f1 = torch.full_like(f0, float("nan"))
+    s1 = torch.full_like(s0, float("nan"))
+    kn.gap_fwd_stride2(y, f1, s1, N, H, W, Cn)
+    torch.cuda.synchronize()
+    assert torch.equal(f0, f1) and torch.equal(s0, s1)
+    assert torch.equal(s1, y[:, ::2, ::2, :].contiguous())
