@@ -28,7 +28,7 @@
 #endif
 #ifndef MSFWSI_IMG_ABLATE
 #define MSFWSI_IMG_ABLATE 0  // diagnostic builds (tools/build_variant.sh), WRONG RESULTS: 1 no staging loads, 2 one tap instead
-#endif                       // of nine, 4 no output stores / mask loads, 8 no weight re-loads, 16 no LDS reads in the k loop
+#endif                       // of nine, 4 no output stores / mask loads, 8 no weight re-loads, 16 no LDS reads in the k loop, 32 epilogue accesses as 8 rows x 128 B
 
 namespace {
 
@@ -255,6 +255,15 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
 
     // ---------------- epilogue: 16-byte row chunks through the wave's scratch; statistics / gate + sums ----------------
     const int q = lane & 3, r4 = lane >> 2;
+#if MSFWSI_IMG_ABLATE & 32
+    const int ab_row = (lane >> 3) + 8 * (wave & 1);         // 8 rows per access, the odd wave of a pair takes rows 8..15
+    const int ab_col = (wave & ~1) * 32 + (lane & 7) * 8;    // 128 contiguous bytes: the pair's 64 channels
+#define IMG_GROW(p_) (((p_) - r4 + ab_row) < MB ? ((p_) - r4 + ab_row) : MB - 1)
+#define IMG_GCOL(c_) (ab_col)
+#else
+#define IMG_GROW(p_) (p_)
+#define IMG_GCOL(c_) (c_)
+#endif
     T* __restrict__ out = reinterpret_cast<T*>(prm.out) + pix0 * KO;
     const T* __restrict__ mask_c = DGRAD ? reinterpret_cast<const T*>(prm.mask_c) : nullptr;
     if (mask_c != nullptr) mask_c += pix0 * KO;
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
 #pragma unroll
                 for (int t = 0; t < TM * 2; ++t) {
                     const int p = (t >> 1) * 32 + (t & 1) * 16 + r4;
-                    mk[t] = (MSFWSI_IMG_ABLATE & 4) ? make_uint4(p, 1, 2, 3) : *reinterpret_cast<const uint4*>(mask_c + (long)(p < MB ? p : 0) * KO + ncol);
+                    mk[t] = (MSFWSI_IMG_ABLATE & 4) ? make_uint4(p, 1, 2, 3) : *reinterpret_cast<const uint4*>(mask_c + (long)(p < MB ? IMG_GROW(p) : 0) * KO + IMG_GCOL(ncol));
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
                             cv = pack16<T>(f);
                             // the gating activation itself, for the weight gradient of this conv (its operand): the
                             // stand-alone msfwsi_bn_act pass would re-read c for it
-                            if (act != nullptr) *reinterpret_cast<uint4*>(act + (long)p * KO + ncol) = pack16<T>(a);
+                            if (act != nullptr) *reinterpret_cast<uint4*>(act + (long)IMG_GROW(p) * KO + IMG_GCOL(ncol)) = pack16<T>(a);
                         }
                     } else {
 #pragma unroll
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
                             s1[e] = fmaf(f[e], f[e], s1[e]);
                         }
                     }
-                    if (!(MSFWSI_IMG_ABLATE & 4) || cv.x == 0x12345u) *reinterpret_cast<uint4*>(out + (long)p * KO + ncol) = cv;
+                    if (!(MSFWSI_IMG_ABLATE & 4) || cv.x == 0x12345u) *reinterpret_cast<uint4*>(out + (long)IMG_GROW(p) * KO + IMG_GCOL(ncol)) = cv;
                 }
             }
         }
@@ -341,6 +350,8 @@ __global__ __launch_bounds__(KO * 2 / TN, 2 / TN) void img3x3_kernel(const Img3P
         }
     }
 }
+#undef IMG_GROW
+#undef IMG_GCOL
 
 // wpk[n/32][step][lane][j], step = tap * (Ck/16) + c/16:  forward  W'(n, tap, c) = w[n][tap][c]         (w = [K][3][3][C])
 //                                                          gradient W'(n, tap, c) = w[c][8 - tap][n]     (taps flipped)
