@@ -523,6 +523,8 @@ int msfwsi_inverse_perm(const long* perm, long* inv, long rows, int K, void* str
  * window / pixel) (A/B measurements, tests).
  * key 17 = 0 runs the panel kernels (csrc/panel.hip) on compiler-counted waits instead of the hand-counted ones (same
  * arithmetic, bit-identical results: the A/B reference of tools/check_hand_waits.py's static audit).
+ * key 18 = 0 keeps the panel kernels on 32-channel blocks where they would take the wide form (a wave owns 64 channels of
+ * 64 rows: 128-byte row segments in the epilogue; k <= 128); same products in another order of the fp32 sums.
  * One knob trades speed for run-to-run reproducibility: key 15 = cap on the pixel splits of the gather weight-gradient
  * kernel (0 = none; 1 = each gradient tile summed by one workgroup in pixel order instead of fp32 atomics in arrival
  * order -- the results then differ from the default's by rounding, 4e-7, and are the same on every run). */

@@ -167,7 +167,8 @@ def load() -> C.CDLL:
                      (4, "MSFWSI_SMALL_GRID_BLOCKS"), (5, "MSFWSI_S2_PARITY"), (6, "MSFWSI_WGRAD_BIG"),
                      (9, "MSFWSI_C3_STATIONARY"),
                      (10, "MSFWSI_WGRAD_OS"),
-                     (12, "MSFWSI_STEM_WS"), (15, "MSFWSI_WGRAD_MAX_SPLITS")):  # A/B switches (see msfwsi_set_tuning)
+                     (12, "MSFWSI_STEM_WS"), (15, "MSFWSI_WGRAD_MAX_SPLITS"), (17, "MSFWSI_PANEL_HAND"),
+                     (18, "MSFWSI_PANEL_WIDE")):  # A/B switches (see msfwsi_set_tuning)
         if env in os.environ:
             lib.msfwsi_set_tuning(key, int(os.environ[env]))
     _lib = lib

@@ -1156,6 +1156,7 @@ extern "C" __attribute__((visibility("hidden"))) long msfwsi_stem_set_os_min(lon
 extern "C" __attribute__((visibility("hidden"))) long msfwsi_wgrad_set_max_splits(long v, int write);
 extern "C" __attribute__((visibility("hidden"))) long msfwsi_pool_bwd_set_walk(long v, int write);
 extern "C" __attribute__((visibility("hidden"))) long msfwsi_panel_set_hand(long v, int write);
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_panel_set_wide(long v, int write);
 
 namespace {
 long own_tunable(msfwsi_tunable& g, long v, int write) {
@@ -1180,6 +1181,7 @@ bool tuning_access(int key, long v, int write, long* old) {
         case 15: *old = msfwsi_wgrad_set_max_splits(v, write); return true;
         case 16: *old = msfwsi_pool_bwd_set_walk(v, write); return true;
         case 17: *old = msfwsi_panel_set_hand(v, write); return true;
+        case 18: *old = msfwsi_panel_set_wide(v, write); return true;
     }
     return false;
 }

@@ -366,16 +366,278 @@ __device__ __forceinline__ void panel_blocks(const PanelParams& prm, char* panel
     }
 }
 
+// The WIDE form of the block loop (k <= 128, Nout a multiple of 64).  The launches of this kernel are bound by the L2 REQUEST
+// rate, and a wave that owns 32 output channels moves its epilogue's operands and results as 16 rows x 64 bytes per
+// instruction -- twice the requests of full 128-byte lines (an ablation with 8 rows x 128 bytes: -10 ... -15 %,
+// profiles/r05_panel_ablation_128B_rows.txt).  Here a wave owns 64 CHANNELS of 64 ROWS: waves (rh, cg) = (wave & 1, wave >> 1)
+// take the row half rh of the panel and the wide blocks cg, cg + 2, ... -- two weight fragments per k step (each used by two
+// row tiles instead of four: the weight stream from L2 doubles, 25 M requests more per launch against 100 M fewer in the
+// epilogue), the same 64 accumulator registers, one activation fragment read per two MFMAs instead of one.  Per wide block
+// the operation counts of panel_blocks hold with 2 KS weight loads: the A fragment of step ks is followed by
+// 2 KS - 1 + NL + NS younger operations, the B fragment by one fewer.
+template <typename T, int K, int BM, int EPI, bool HAND>
+__device__ __forceinline__ void panel_blocks_wide(const PanelParams& prm, char* panel, char* scratch, float* colsum,
+                                                  const char* gapl, long m0, int rows_left, int wave, int lane) {
+    constexpr int TMW = BM / 64, NG = TMW * 4, KS = K / 16, ROWB = K * 2;
+    constexpr int SCRW = 144;  // scratch pitch: 32 rows x (64 channels = 128 bytes + 16)
+    constexpr bool FWD = EPI == 1, LORES = EPI == 3;
+    static_assert(BM == 128 && K <= 128, "wide blocks: 128-row panels, k <= 128 (two weight fragments per k step in registers)");
+    typedef typename MmaFrag<T>::type frag_t;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int rh = wave & 1, cg = wave >> 1;
+    const int nwb = prm.Nout >> 6;
+    const int c8 = lane & 7, r8 = lane >> 3;  // chunk of the 128-byte row segment, row inside a group of 8
+    const int PQ = prm.P * prm.Q;
+    const unsigned img0 = FWD ? 0u : fast_div((unsigned)m0, prm.div_pq);
+    const char* eop_wg = reinterpret_cast<const char*>(FWD ? prm.ident : prm.resid);
+    const bool has_eop = eop_wg != nullptr;
+    if (!LORES && has_eop) eop_wg += m0 * prm.Nout * 2;
+    char* out_wg = reinterpret_cast<char*>(prm.out) + m0 * prm.Nout * 2;
+    const long gbase = ((m0 >> 7) * (long)(prm.Nout >> 5)) * 512 + (m0 & 127) * 4;
+    const unsigned char* mb_wg = (!FWD && prm.mask_bits != nullptr) ? prm.mask_bits + gbase : nullptr;
+    unsigned char* go_wg = (FWD && prm.gate_out != nullptr) ? prm.gate_out + gbase : nullptr;
+    const unsigned row_off = (unsigned)r8 * (unsigned)prm.Nout * 2u + (unsigned)c8 * 16u;
+    const unsigned bit_off = (unsigned)r8 * 4u + (unsigned)(c8 >> 2) * 512u;  // this lane's row and 32-channel block inside a wide block
+    constexpr int NL = NG * (FWD ? 1 : 2) + (FWD ? 4 : 0);
+    constexpr int NS = NG * (FWD ? 2 : 1);
+    constexpr int NWAIT = 2 * KS - 1 + NL + NS;
+    static_assert(NWAIT <= 63, "operation count per wide block exceeds the vmcnt range");
+
+    u32x4 er[NG];
+    unsigned ebw[FWD ? 1 : NG];
+    u32x4 pq[FWD ? 4 : 1];
+    unsigned ehave = 0;
+    auto request = [&](int t, int wb) __attribute__((always_inline)) {
+        const int rbase = rh * 64 + (t >> 2) * 32 + (t & 3) * 8;  // first row of the group (wave-uniform)
+        const bool ok = HAND || rbase + r8 < rows_left;
+        if constexpr (!FWD) {
+            if (HAND || mb_wg != nullptr) {
+                const unsigned boff = (ok ? (unsigned)rbase * 4u + bit_off : (unsigned)(c8 >> 2) * 512u) + (unsigned)wb * 1024u;
+                pl_load4<HAND>(ebw[t], mb_wg, boff);
+            }
+        }
+        if (HAND || has_eop) {
+            if constexpr (LORES) {
+                const unsigned m = (unsigned)(m0 + (ok ? rbase + r8 : 0));
+                const unsigned n = fast_div(m, prm.div_pq);
+                const unsigned rem = m - n * (unsigned)PQ;
+                const unsigned h = fast_div(rem, prm.div_q);
+                const unsigned w = rem - h * (unsigned)prm.Q;
+                const int Pl = (prm.P + 1) >> 1, Ql = (prm.Q + 1) >> 1;
+                const unsigned lo = (((n * (unsigned)Pl + (h >> 1)) * (unsigned)Ql + (w >> 1)) * (unsigned)prm.Nout +
+                                     (unsigned)(wb * 64 + c8 * 8)) * 2u;
+                pl_load16<HAND>(er[t], eop_wg, lo);
+                if (((h | w) & 1u) == 0) ehave |= 1u << t;
+            } else {
+                const unsigned off = (ok ? (unsigned)rbase * (unsigned)prm.Nout * 2u + row_off : (unsigned)c8 * 16u) + (unsigned)wb * 128u;
+                pl_load16<HAND>(er[t], eop_wg, off);
+            }
+        }
+    };
+    auto request_post = [&](int wb) __attribute__((always_inline)) {
+        if constexpr (FWD) {
+            const unsigned o = (unsigned)(wb * 64 + c8 * 8) * 4u;
+            pl_load16<HAND>(pq[0], prm.post_scale, o);
+            pl_load16<HAND>(pq[1], prm.post_scale, o + 16u);
+            pl_load16<HAND>(pq[2], prm.post_shift, o);
+            pl_load16<HAND>(pq[3], prm.post_shift, o + 16u);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        er[t] = (u32x4){0u, 0u, 0u, 0u};
+        if constexpr (!FWD) ebw[t] = 0xffffffffu;
+    }
+    const int wb0 = cg < nwb ? cg : nwb - 1;  // (a wave pair without a wide block loads and drops)
+#pragma unroll
+    for (int t = 0; t < NG; ++t) request(t, wb0);
+    request_post(wb0);
+    const char* wpk = reinterpret_cast<const char*>(prm.wpk);
+    u32x4 wfa[KS], wfb[KS];
+    {
+        const char* wb_ = wpk + (long)(2 * wb0) * KS * 1024;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pl_load16<HAND>(wfa[ks], wb_, (unsigned)(ks * 1024 + lane * 16));
+            pl_load16<HAND>(wfb[ks], wb_, (unsigned)((KS + ks) * 1024 + lane * 16));
+        }
+    }
+    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const int xv = lh ^ panel_swz<K>(l31);
+    const char* prow = panel + (rh * 64 + l31) * ROWB;
+
+    for (int wb = cg; wb < nwb; wb += 2) {
+        const int ncol = wb * 64 + c8 * 8;
+        const unsigned lane_off = row_off + (unsigned)wb * 128u;
+        const int wbn = wb + 2 < nwb ? wb + 2 : wb;  // (the last wide block re-requests its own operands: no branch)
+
+        f32x16 acc[2][TMW];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[n][tm][j] = 0.f;
+        const char* wn = wpk + (long)(2 * wbn) * KS * 1024;
+        frag_t xc[TMW];
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm) xc[tm] = *reinterpret_cast<const frag_t*>(prow + tm * 32 * ROWB + ((0 ^ xv) << 4));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            pl_wait<HAND, NWAIT>(wfa[ks]);
+            pl_wait<HAND, NWAIT - 1>(wfb[ks]);
+            const frag_t fa = __builtin_bit_cast(frag_t, wfa[ks]);
+            const frag_t fb = __builtin_bit_cast(frag_t, wfb[ks]);
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm) {
+                mma32<T>(acc[0][tm], fa, xc[tm]);
+                mma32<T>(acc[1][tm], fb, xc[tm]);
+                if (ks + 1 < KS)
+                    xc[tm] = *reinterpret_cast<const frag_t*>(prow + tm * 32 * ROWB + (((2 * (ks + 1)) ^ xv) << 4));
+            }
+            pl_load16<HAND>(wfa[ks], wn, (unsigned)(ks * 1024 + lane * 16));
+            pl_load16<HAND>(wfb[ks], wn, (unsigned)((KS + ks) * 1024 + lane * 16));
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (ks + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        if constexpr (FWD) {
+            pl_wait<HAND, 2 * KS>(pq[0]);
+            pl_wait<HAND, 2 * KS>(pq[1]);
+            pl_wait<HAND, 2 * KS>(pq[2]);
+            pl_wait<HAND, 2 * KS>(pq[3]);
+        }
+        float ssum[FWD ? 1 : 8];
+        if constexpr (!FWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ssum[e] = 0.f;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm) {
+            // both 32-channel tiles of the row tile side by side: lane (l31, lh) holds pixel l31, channels 8g + 4 lh + e
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2*>(scratch + l31 * SCRW + n * 64 + (8 * g + 4 * lh) * 2) =
+                        pack4<T>(acc[n][tm][4 * g], acc[n][tm][4 * g + 1], acc[n][tm][4 * g + 2], acc[n][tm][4 * g + 3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = tm * 4 + i;
+                const int rbase = rh * 64 + tm * 32 + i * 8;
+                const uint4 cv = *reinterpret_cast<const uint4*>(scratch + (i * 8 + r8) * SCRW + c8 * 16);
+                const bool ok = HAND || rbase + r8 < rows_left;
+                float f[8];
+                unpack16<T>(cv, f);
+                uint4 pk;
+                if constexpr (FWD) pl_wait<HAND, NWAIT>(er[t]);
+                else pl_wait<HAND, NWAIT - 1>(er[t], ebw[t]);
+                if constexpr (FWD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        f[e] = fmaf(f[e], __uint_as_float(pq[e >> 2][e & 3]), __uint_as_float(pq[2 + (e >> 2)][e & 3]));
+                    if (HAND || has_eop) {
+                        float id[8];
+                        unpack16<T>(as_uint4(er[t]), id);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += id[e];
+                    }
+                    if (prm.post_relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+                    }
+                    pk = pack16<T>(f);
+                } else {
+                    const bool addr = LORES ? ((ehave >> t) & 1u) != 0 : (HAND || has_eop);
+                    if (addr) {
+                        float rs[8];
+                        unpack16<T>(as_uint4(er[t]), rs);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += rs[e];
+                    }
+                    if (prm.gapg != nullptr) {
+                        const unsigned m = (unsigned)(m0 + (ok ? rbase + r8 : 0));
+                        const unsigned img = fast_div(m, prm.div_pq);
+                        uint4 gv;
+                        if constexpr (HAND) gv = *reinterpret_cast<const uint4*>(gapl + ((img - img0) * (unsigned)prm.Nout + (unsigned)ncol) * 2u);
+                        else gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(prm.gapg) + (long)img * prm.Nout + ncol);
+                        float gp[8];
+                        unpack16<T>(gv, gp);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fmaf(gp[e], prm.gap_scale, f[e]);
+                    }
+                    const unsigned b = (ebw[t] >> (8 * (c8 & 3))) & 0xffu;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (!((b >> e) & 1u)) f[e] = 0.f;
+                        if (ok) ssum[e] += f[e];
+                    }
+                    pk = pack16<T>(f);
+                }
+                request(t, wbn);
+                if constexpr (FWD) {
+                    if (HAND || go_wg != nullptr) {
+                        const unsigned gb = gate_bits_of<T>(pk);
+                        unsigned dw = gb << (8 * (c8 & 3));
+                        dw |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)dw, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+                        dw |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)dw, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+                        if (HAND || (ok && (c8 & 3) == 0))
+                            pl_store(reinterpret_cast<unsigned*>(go_wg + ((unsigned)rbase * 4u + bit_off + (unsigned)wb * 1024u)), dw);
+                    }
+                }
+                if (ok)
+                    pl_store(reinterpret_cast<u32x4*>(out_wg + ((unsigned)rbase * (unsigned)prm.Nout * 2u + lane_off)),
+                             (u32x4){pk.x, pk.y, pk.z, pk.w});
+            }
+        }
+        request_post(wbn);
+        if constexpr (!FWD) {
+            if (prm.sums != nullptr) {
+                // lanes with equal c8 hold the same 8 channels for different rows; the two row halves of the panel are two
+                // waves: their column sums meet in LDS by atomic adds (two commutative adds onto zero: one result)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                    for (int off = 8; off < 64; off <<= 1) ssum[e] += __shfl_xor(ssum[e], off, 64);
+                }
+                if (lane < 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) atomicAdd(colsum + ncol + e, ssum[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        pl_drain<HAND>(wfa[ks]);
+        pl_drain<HAND>(wfb[ks]);
+    }
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        pl_drain<HAND>(er[t]);
+        if constexpr (!FWD) pl_drain<HAND>(ebw[t]);
+    }
+    if constexpr (FWD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pl_drain<HAND>(pq[i]);
+    }
+}
+
 // PRO: 0 none, 1 relu(scale*c + shift), 2 k1*g + k2*c + k3.   EPI: 1 forward post, 0 input gradient, 3 input gradient with
-// the low-resolution (stride 2) residual.
-template <typename T, int K, int BM, int PRO, int EPI, bool HAND>
+// the low-resolution (stride 2) residual.  WIDE: panel_blocks_wide (64 channels x 64 rows per wave and block).
+template <typename T, int K, int BM, int PRO, int EPI, bool HAND, bool WIDE = false>
 __global__ __launch_bounds__(256, HAND ? 2 : 1) void panel_kernel(const PanelParams prm) {
     constexpr int NT = 256, NW = 4;
     constexpr int CPR = K / 8;       // 16-byte chunks per operand row
     constexpr int RPP = NT / CPR;    // rows staged per pass
     constexpr int NPASS = BM / RPP;
     constexpr int ROWB = K * 2;
-    constexpr int SCR_BYTES = 32 * 80;  // per wave: 32 rows x (32 channels = 64 bytes + 16: keeps ds_read_b128 aligned)
+    constexpr int SCR_BYTES = WIDE ? 32 * 144 : 32 * 80;  // per wave: 32 rows x (32 / 64 channels + 16 bytes: keeps ds_read_b128 aligned)
     constexpr bool FWD = EPI == 1;
     static_assert(K % 64 == 0 && BM % RPP == 0 && NT % CPR == 0 && BM % 32 == 0, "panel geometry");
 
@@ -453,10 +715,15 @@ __global__ __launch_bounds__(256, HAND ? 2 : 1) void panel_kernel(const PanelPar
             *reinterpret_cast<uint4*>(panel + row * ROWB + ((cc ^ panel_swz<K>(row)) << 4)) = t;
         }
     }
+    if constexpr (WIDE && !FWD) {
+        if (prm.sums != nullptr)  // two waves add into every column sum: from zero
+            for (int n = tid; n < prm.Nout; n += NT) colsum[n] = 0.f;
+    }
     __syncthreads();  // the only workgroup barrier before the sums: from here on every wave runs alone
 
     // HAND (chosen by the launcher): every panel whole and every optional operand of the epilogue class present
-    panel_blocks<T, K, BM, EPI, HAND>(prm, panel, scratch, colsum, gapl, m0, rows_left, wave, lane);
+    if constexpr (WIDE) panel_blocks_wide<T, K, BM, EPI, HAND>(prm, panel, scratch, colsum, gapl, m0, rows_left, wave, lane);
+    else panel_blocks<T, K, BM, EPI, HAND>(prm, panel, scratch, colsum, gapl, m0, rows_left, wave, lane);
 
     if constexpr (!FWD) {
         if (prm.sums != nullptr) {
@@ -638,11 +905,15 @@ __global__ void panel_pack_kernel(const T* __restrict__ w, T* __restrict__ wpk, 
     wpk[i] = w[n * stride_n + k * stride_k];
 }
 
+msfwsi_tunable g_panel_wide{1};  // msfwsi_set_tuning(18, .): 0 = 32-channel blocks everywhere (panel_blocks), the A/B reference of the wide form
 msfwsi_tunable g_panel_hand{1};  // msfwsi_set_tuning(17, .): 0 = every launch on hipcc's own waits (the A/B reference of the hand-counted ones)
 
 template <typename T, int K, int BM, int PRO, int EPI>
 int launch_panel(const PanelParams& prm, hipStream_t stream) {
-    const int LDS = BM * K * 2 + 4 * 32 * 80 + (EPI != 1 && prm.sums != nullptr ? prm.Nout * 4 : 0) +
+    // wide blocks (panel_blocks_wide): k <= 128 on 128-row panels, whole 64-channel blocks
+    constexpr bool CAN_WIDE = K <= 128 && BM == 128;
+    const bool wide = CAN_WIDE && g_panel_wide && prm.Nout % 64 == 0;
+    const int LDS = BM * K * 2 + 4 * 32 * (wide ? 144 : 80) + (EPI != 1 && prm.sums != nullptr ? prm.Nout * 4 : 0) +
                     (EPI != 1 && prm.gapg != nullptr ? prm.Nout * 4 : 0);
     // hand-counted loads (panel_blocks) need a fixed number of vector-memory operations per block: whole panels only, and
     // every optional operand of the epilogue class present (the engine's launches all are: M = N*H*W with N a multiple of
@@ -651,6 +922,9 @@ int launch_panel(const PanelParams& prm, hipStream_t stream) {
                                                    : (prm.resid != nullptr && prm.mask_bits != nullptr &&
                                                       (prm.gapg == nullptr || prm.P * prm.Q >= BM)));  // (a panel within two images)
     void (*kern)(const PanelParams) = hand ? panel_kernel<T, K, BM, PRO, EPI, true> : panel_kernel<T, K, BM, PRO, EPI, false>;
+    if constexpr (CAN_WIDE) {
+        if (wide) kern = hand ? panel_kernel<T, K, BM, PRO, EPI, true, true> : panel_kernel<T, K, BM, PRO, EPI, false, true>;
+    }
     if (LDS > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
@@ -682,6 +956,12 @@ bool is_1x1(const msfwsi_conv_desc* d) {
 }
 
 }  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) long msfwsi_panel_set_wide(long v, int write) {
+    const long old = g_panel_wide;
+    if (write) g_panel_wide = v;
+    return old;
+}
 
 extern "C" __attribute__((visibility("hidden"))) long msfwsi_panel_set_hand(long v, int write) {
     const long old = g_panel_hand;

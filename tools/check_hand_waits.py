@@ -161,7 +161,8 @@ def audit(name, body):
 
 def main():
     # (source, kernel-name test): every instance whose block / k loop issues its loads from inline asm
-    targets = [("panel.hip", lambda n: "panel_kernel" in n and n.endswith("Lb1EEEvNS_11PanelParamsE")),
+    # panel_kernel<T, K, BM, PRO, EPI, HAND, WIDE>: the HAND = true instances (both block-loop forms)
+    targets = [("panel.hip", lambda n: "panel_kernel" in n and re.search(r"ELb1ELb[01]EEEvNS_11PanelParamsE$", n) is not None),
                ("img3x3.hip", lambda n: "img3x3_kernel" in n or "img3x3_s2d_kernel" in n)]
     if len(sys.argv) > 1:
         files = [(a, None) for a in sys.argv[1:]]
