@@ -20,6 +20,7 @@ from __future__ import annotations
 import contextlib
 import os
 import threading
+import types
 import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -343,6 +344,7 @@ class Engine:
         # the folded tail's backward: a2 = relu(bn2(c2)) as a by-product of the M = g^T a2 launch (msfwsi_conv_wgrad_act)
         self.fuse_a2_wgrad = os.environ.get("MSFWSI_FUSE_A2_WGRAD", "1") != "0"
         self.fuse_a2_wgrad_max_c = int(os.environ.get("MSFWSI_FUSE_A2_WGRAD_MAX_C", "64"))
+        self.img3x3_chunk_bytes = int(os.environ.get("MSFWSI_IMG3X3_CHUNK_BYTES", str(1 << 30)))  # see _img3_bwd_chunks
         self.img3x3_min_fill = float(os.environ.get("MSFWSI_IMG3X3_MIN_FILL", "1.0"))  # rounds of workgroups, see _img3_fills
         self._ncu: Dict[object, int] = {}
         self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
@@ -1524,6 +1526,18 @@ class Engine:
             ncu = self._ncu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
         return d.N * bands >= self.img3x3_min_fill * ncu * per_cu
 
+    def _img3_bwd_chunks(self, d, a1_like: Optional[torch.Tensor], dev) -> int:
+        """image chunks of the gradient-launch + weight-gradient pair: 1 unless the by-product activation exceeds
+        img3x3_chunk_bytes (1 GiB) and every chunk still fills the chip twice"""
+        if a1_like is None:
+            return 1
+        nbytes = a1_like.numel() * a1_like.element_size()
+        n = 1
+        while (nbytes // n > self.img3x3_chunk_bytes and n < 8 and d.N % (2 * n) == 0
+               and self._img3_fills(types.SimpleNamespace(N=d.N // (2 * n) // 2, H=d.H, P=d.P, stride=d.stride), dev)):
+            n *= 2
+        return n
+
     def _img3_dgrad_weights(self, u: Unit, prev: Unit, dtype, with_bn: bool = True) -> Optional[torch.Tensor]:
         """the packed filter if u's input gradient runs on the image-stationary kernel: a served 3x3 geometry whose operand
         is prev's raw output under prev's BatchNorm + ReLU (conv2 of a Bottleneck of layer2 / layer3; of layer1 only when the
@@ -1557,19 +1571,45 @@ class Engine:
                 # the weight gradient's operand -- stored from the gate's own arithmetic
                 d = u.desc
                 da = torch.empty(d.N, d.H, d.W, d.C, dtype=dtype, device=dev)
-                # (64 channels: the output-stationary weight-gradient kernel normalises c1 in its own staging)
-                a1 = torch.empty_like(prev.c) if d.C != 64 else None
-                dc, bnb = cur, None
                 strided = d.stride == 2
+                want_a1 = d.C != 64  # (64 channels: the output-stationary weight-gradient kernel normalises c1 in its own staging)
+                inplace = (d.P if strided else d.H) == 14  # a workgroup owns the whole (gradient) image: bands read their neighbours' halo rows
+                a1 = dc = bnb = None
                 if bn_here is not None:
-                    # in place where a workgroup owns the whole (gradient) image: bands read their neighbours' halo rows
-                    dc = cur if (d.P if strided else d.H) == 14 else torch.empty_like(cur)
                     bnb = (bn_here[0], bn_here[1][0], bn_here[1][1], bn_here[1][2])
+                chunked = want_a1 and self._img3_bwd_chunks(d, prev.c, dev) > 1
+                if not chunked:
+                    a1 = torch.empty_like(prev.c) if want_a1 else None
+                    dc = cur
+                    if bnb is not None and not inplace:
+                        dc = torch.empty_like(cur)
+                elif inplace:
+                    dc = cur
                 launch = kn.img3x3_s2_dgrad if strided else kn.img3x3_dgrad
-                if not launch(d, cur, wimg, da, bnbwd=bnb, dc_out=dc if bnb is not None else None,
-                              mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2, act_out=a1):
-                    raise _lib.MsfwsiHipError("the image-stationary gradient refused a geometry its `supported` accepted")
-                self._unit_wgrad(u, dc, grads, dtype, x_mat=a1)
+                nchunk = self._img3_bwd_chunks(d, prev.c, dev) if chunked else 1
+                if nchunk > 1:
+                    # the by-product a1 is as large as da (3.3 GB per view at 56 x 56 x 128) and both live until the weight
+                    # gradient has run: with two views in flight that raised the allocator's pools by 9.5 GiB, to the card's
+                    # last GiB.  In chunks of images the launch + weight-gradient pair re-uses ONE chunk-sized a1 / dc
+                    # (the sums and the weight gradient accumulate; a chunk still fills the chip several times).
+                    nc = d.N // nchunk
+                    dch = kn.conv_desc(dtype, nc, d.H, d.W, d.C, d.K, d.R, d.S, d.stride, d.pad)
+                    a1c = torch.empty((nc,) + tuple(prev.c.shape[1:]), dtype=dtype, device=dev)
+                    dcc = torch.empty((nc,) + tuple(cur.shape[1:]), dtype=dtype, device=dev) if bnb is not None and dc is not cur else None
+                    dw = grads.get(u.op.weight)
+                    for ci in range(nchunk):
+                        sl = slice(ci * nc, (ci + 1) * nc)
+                        dco = (dcc if dcc is not None else cur[sl]) if bnb is not None else None
+                        if not launch(dch, cur[sl], wimg, da[sl], bnbwd=(bnb[0][sl],) + tuple(bnb[1:]) if bnb is not None else None,
+                                      dc_out=dco, mask=(prev.c[sl], prev.st.scale, prev.st.shift), sums=s2, act_out=a1c):
+                            raise _lib.MsfwsiHipError("the image-stationary gradient refused a geometry its `supported` accepted")
+                        kn.conv_wgrad(dch, a1c, dco if dco is not None else cur[sl], dw)
+                    del a1c, dcc
+                else:
+                    if not launch(d, cur, wimg, da, bnbwd=bnb, dc_out=dc if bnb is not None else None,
+                                  mask=(prev.c, prev.st.scale, prev.st.shift), sums=s2, act_out=a1):
+                        raise _lib.MsfwsiHipError("the image-stationary gradient refused a geometry its `supported` accepted")
+                    self._unit_wgrad(u, dc, grads, dtype, x_mat=a1)
                 del a1, dc
             else:
                 if bn_here is not None:

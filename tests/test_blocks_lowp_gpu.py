@@ -239,6 +239,33 @@ def test_deep_blocks_on_the_image_stationary_kernels(hip_lib, monkeypatch, arch,
         assert calls["fwd"] == 2 * nblk + 2 and calls["dgrad"] == nblk and calls["fused_bn"] == 0
 
 
+def test_image_kernel_backward_in_image_chunks(hip_lib, monkeypatch):
+    """Engine._img3_bwd_chunks: where the by-product activation a1 would be large, the gradient launch + weight gradient pair
+    runs over chunks of images with one chunk-sized a1 / dc (memory: two views' a1 beside their da filled the card).  Forced
+    here by a 1-byte threshold on four images: same fp64 block oracle, same bounds, and the launches counted"""
+    from msf_wsi_amd import kernels as kn
+
+    calls = {"s1": 0, "s2": 0}
+    dgrad, s2dgrad = kn.img3x3_dgrad, kn.img3x3_s2_dgrad
+
+    def count(which, fn):
+        def wrapped(d, *a, **k):
+            calls[which] += 1
+            assert d.N == 1 and k.get("act_out") is not None and k["act_out"].shape[0] == 1
+            return fn(d, *a, **k)
+        return wrapped
+
+    monkeypatch.setenv("MSFWSI_IMG3X3_MIN_FILL", "0")
+    monkeypatch.setenv("MSFWSI_IMG3X3_CHUNK_BYTES", "1")
+    monkeypatch.setattr(kn, "img3x3_dgrad", count("s1", dgrad))
+    monkeypatch.setattr(kn, "img3x3_s2_dgrad", count("s2", s2dgrad))
+    only = lambda name: name in ("layer2.0", "layer2.1", "layer3.0")
+    worst, bad = run_blocks("resnet50", torch.bfloat16, batch=4, size=224, only=only)
+    _report("chunked image-kernel backward", worst)
+    assert not bad, [(k, f"{worst[k]:.2e}") for k in bad]
+    assert calls == {"s1": 4, "s2": 8}  # four one-image chunks per block
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_stem_within_a_few_ulp(hip_lib, stationary_forced, dtype):
     """conv1 -> bn1 -> relu -> maxpool (resnet.py:234-237) through stem_ws_kernel, stem_pool_fwd / _bwd and
