@@ -261,6 +261,52 @@ def test_hand_counted_waits_equal_compiler_waits(hip_lib, dt, geom):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(32, 28, 28, 128, 512), (16, 56, 56, 64, 256), (3, 9, 7, 128, 192)])
+def test_wide_blocks_equal_narrow_blocks(hip_lib, dt, geom):
+    """the wide block form (k <= 128: a wave owns 64 channels of 64 rows, msfwsi_set_tuning(18, 1), the default) against
+    the 32-channel form: every output element is the same MFMA chain over the same k order, so outputs, gate bytes and
+    the written-back BatchNorm-backward operand are the SAME BITS; the column sums meet in another order (fp32 partials of
+    two waves instead of one: equal to fp32 rounding).  Whole panels (hand-counted instances) and a ragged one"""
+    from helpers import tuned
+    from msf_wsi_amd import kernels as kn
+
+    N, H, W, Cn, Kw = geom
+    M = N * H * W
+    g = torch.Generator().manual_seed(16)
+    a = rnd((M, Cn), dt, g).cuda()
+    c1 = rnd((M, Cn), dt, g).cuda()
+    w = rnd((Kw, Cn), dt, g, 1.0 / math.sqrt(Cn)).cuda()
+    w1 = rnd((Cn, Kw), dt, g, 1.0 / math.sqrt(Cn)).cuda()
+    ident = rnd((M, Kw), dt, g).cuda()
+    ps, pb = (torch.rand(Kw, generator=g) + 0.5).cuda(), (torch.randn(Kw, generator=g) * 0.2).cuda()
+    sc, sh = (torch.rand(Cn, generator=g) + 0.5).cuda(), (torch.randn(Cn, generator=g) * 0.3).cuda()
+    k3 = (torch.randn(Cn, generator=g) * 0.05).cuda()
+    bits_in = kn.gate_pack(torch.randint(0, 256, (M, Kw // 8), dtype=torch.uint8, generator=g), Kw, dt).cuda()
+    d = kn.conv_desc(dt, N, H, W, Cn, Kw, 1, 1, 1, 0)
+    d1 = kn.conv_desc(dt, N, H, W, Kw, Cn, 1, 1, 1, 0)
+    wpk = kn.panel_pack_weights(w, torch.empty_like(w), Kw, Cn, Cn, 1)
+    wpk1 = kn.panel_pack_weights(w1, torch.empty_like(w1), Kw, Cn, 1, Kw)
+
+    def run():
+        y = torch.empty(M, Kw, dtype=dt, device="cuda")
+        bits = kn.gate_bytes(M, Kw, dt, "cuda")
+        assert kn.panel_fwd_post(d, a, wpk, y, ps, pb, pro=(sc, sh), ident=ident, relu=True, gate_out=bits)
+        dx = torch.empty(M, Kw, dtype=dt, device="cuda")
+        dc = torch.empty(M, Cn, dtype=dt, device="cuda")
+        sums = kn.new_stats(Kw, 2, "cuda")
+        assert kn.panel_dgrad(d1, a, wpk1, dx, bnbwd=(c1, sc, sh, k3), dc_out=dc, resid=ident, mask_bits=bits_in, sums=sums)
+        torch.cuda.synchronize()
+        return y, kn.gate_unpack(bits, M, Kw, dt), dx, dc, sums.sum(0)[0]
+
+    with tuned(hip_lib, {18: 0}):
+        ref = run()
+    got = run()
+    for name, r, t in zip(("y", "gate bits", "dx", "dc"), ref[:4], got[:4]):
+        assert torch.equal(r, t), f"{name}: the wide form differs from the 32-channel form"
+    assert (ref[4] - got[4]).abs().max().item() <= 1e-5 * max(1.0, ref[4].abs().max().item())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("geom", [(3, 7, 9, 64), (2, 14, 14, 128), (700, 8, 8, 64), (300, 8, 8, 128)])
 def test_panel_gram(hip_lib, dt, geom):
     """Gram matrix + column sums of relu(scale*c + shift) in one pass over the raw conv output (msfwsi_panel_gram): against
