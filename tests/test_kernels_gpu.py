@@ -523,7 +523,10 @@ def test_stem_pool(hip_lib, dt, hw, pool_bwd_kernel):
     g = torch.Generator().manual_seed(6)
     c0 = rnd((N, Cn, H, W), dt, g)
     sc, sh = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.3
-    a = F.relu(c0 * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).to(dt).double().requires_grad_(True)
+    # the kernel forms scale*c + shift with ONE rounding (fma): the reference does the same -- the product of two fp32 numbers
+    # is exact in fp64, the sum is rounded once to fp32 (keeps the 1e-6 gate instead of loosening it to 1e-5)
+    lin = (c0.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+    a = F.relu(lin).to(dt).double().requires_grad_(True)
     p_ref = F.max_pool2d(a, 3, 2, 1)
     P, Q = p_ref.shape[2:]
     dp = rnd((N, Cn, P, Q), dt, g)
@@ -534,9 +537,7 @@ def test_stem_pool(hip_lib, dt, hw, pool_bwd_kernel):
     am = torch.empty(N, P, Q, Cn, dtype=torch.uint8, device="cuda")
     kn.stem_pool_fwd(c0d, sc.cuda(), sh.cuda(), out, am, N, H, W, Cn)
     torch.cuda.synchronize()
-    # (the kernel forms scale*c+shift with ONE rounding (fma), the torch expression above with two: a handful of the
-    #  34x70 case's 150 k elements land one unit of the storage type apart)
-    assert rel(out.float().cpu().permute(0, 3, 1, 2), p_ref.detach()) < 1e-5
+    assert rel(out.float().cpu().permute(0, 3, 1, 2), p_ref.detach()) < 1e-6
     if pool_bwd_kernel == "walk":  # the column-walk forward equals the per-window kernel bit for bit, argmax codes included
         out2, am2 = torch.empty_like(out), torch.empty_like(am)
         hip_lib.msfwsi_set_tuning(16, 0)
