@@ -32,37 +32,61 @@ ACT_BYTES_PER_PAIR_16BIT = {"resnet18": 1.01e9, "resnet50": 4.53e9}
 ADAM_BYTES_PER_STEP = {"resnet18": 3.46e9, "resnet50": 46.6e9}
 
 
-def pmc_entry(symbol):
-    """counter-derived figures of the kernel whose mangled name contains `symbol`, from the newest committed PMC summary
-    (profiles/r*_pmc.json: separate rocprofv3 --pmc passes of this same command, tools/profile_step.sh +
-    tools/pmc_summary.py): L2-miss (fabric) bytes per launch and MFMA utilisation"""
+def _pmc_summary():
+    """(table, file name, stale): the newest committed counter summary (profiles/r*_pmc.json: separate rocprofv3 --pmc passes
+    of this same command, tools/profile_step.sh + tools/pmc_summary.py) -- but ONLY when it was taken with the library this
+    process runs: the summary carries the build id of the binary it profiled (sha256 of the kernel sources,
+    msfwsi_build_id), and a summary of another build is not replayed beside a fresh time (`stale` names the file then)."""
     import glob
 
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    from msf_wsi_amd import _lib
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), key=lambda p: (os.path.getmtime(p), p))
     if not paths:
-        return {}
+        return None, None, None
+    mine = _lib.load().msfwsi_build_id().decode()
+    newest = os.path.basename(paths[-1])
+    for path in reversed(paths):
+        try:
+            with open(path) as f:
+                tab = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if tab.get("build_id") == mine:
+            return tab, os.path.basename(path), None
+    return None, None, newest
+
+
+def pmc_entry(symbol):
+    """counter-derived figures of the kernel whose mangled name contains `symbol`: L2-miss (fabric) bytes per launch and MFMA
+    utilisation, from the committed counter summary of THIS build ({} plus `stale_profile` when there is none)"""
+    tab, name, stale = _pmc_summary()
+    if tab is None:
+        return {"stale_profile": stale} if stale else {}
     try:
-        with open(paths[-1]) as f:
-            tab = json.load(f).get("kernels", {})
-        hit = sorted(((len(k), v) for k, v in tab.items() if k.strip() and (k in symbol or symbol in k)),
+        kern = tab.get("kernels", {})
+        hit = sorted(((len(k), v) for k, v in kern.items() if k.strip() and (k in symbol or symbol in k)),
                      key=lambda kv: -kv[0])  # the longest (most specific) matching name
-        return dict(hit[0][1], source=os.path.basename(paths[-1])) if hit else {}
-    except (OSError, ValueError, KeyError):
+        return dict(hit[0][1], source=name) if hit else {}
+    except (ValueError, KeyError):
         return {}
 
 
 def pmc_step():
-    """whole-step counter traffic (L2-miss bytes per step) of the newest committed PMC summary, with its file name"""
-    import glob
-
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
-    if not paths:
-        return None, None
+    """(whole-step counter traffic in bytes, summary file, stale file): L2-miss bytes per step of this build's summary"""
+    tab, name, stale = _pmc_summary()
+    if tab is None:
+        return None, None, stale
     try:
-        with open(paths[-1]) as f:
-            return float(json.load(f)["hbm_bytes_per_step"]), os.path.basename(paths[-1])
-    except (OSError, ValueError, KeyError):
-        return None, None
+        return float(tab["hbm_bytes_per_step"]), name, None
+    except (ValueError, KeyError):
+        return None, None, name
+
+
+def _build_id():
+    from msf_wsi_amd import _lib
+
+    return _lib.load().msfwsi_build_id().decode()
 
 
 def hub_stub():
@@ -165,7 +189,7 @@ def build_roofline(timer, args, dt, timed_from, step_bytes, step_flop, use_pmc=T
     pmc_per_step = (pmc["hbm_bytes_per_launch"] * pmc["launches_in_pass"] / 2.0
                     if pmc.get("hbm_bytes_per_launch") and pmc.get("launches_in_pass") else None)
     step_s = dt / args.steps
-    step_traffic, step_src = pmc_step() if use_pmc else (None, None)
+    step_traffic, step_src, step_stale = pmc_step() if use_pmc else (None, None, None)
     roof = {
         "kernel": dom, "family": s["family"], "bound": bound,
         "achieved": round(tf if bound == "mfma" else gbs, 2),
@@ -178,6 +202,10 @@ def build_roofline(timer, args, dt, timed_from, step_bytes, step_flop, use_pmc=T
         "algorithmic_bytes_per_step": round(s["bytes"] / nst),
         "mfma_util": round(pmc["mfma_util"], 4) if pmc.get("mfma_util") is not None else None,
         "replayed_from": pmc.get("source"),
+        # a committed counter summary exists, but of ANOTHER build of the kernels (its build id differs from this library's):
+        # it is named, not replayed
+        "stale_profile": pmc.get("stale_profile") or step_stale,
+        "build_id": _build_id(),
         "whole_step": None if not (step_bytes and step_flop) else {
             "algorithmic_GB": round(step_bytes / 1e9, 1), "algorithmic_TFLOP": round(step_flop / 1e12, 1),
             "frac_hbm": round(step_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),

@@ -126,15 +126,54 @@ def build(force: bool = False) -> str:
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     if force or not os.path.exists(LIB_PATH) or _stale():
         subprocess.run(["make", "-C", CSRC_DIR, "-j4"], check=True, stdout=subprocess.DEVNULL)
+        if _stale():
+            # make decides by file times; the binary and its objects are git-ignored and travel by rsync, so an object can
+            # be NEWER than a source it was not built from.  The digest says the library is still not of these sources:
+            # rebuild everything.
+            subprocess.run(["make", "-C", CSRC_DIR, "-j4", "-B"], check=True, stdout=subprocess.DEVNULL)
+            if _stale():
+                raise MsfwsiHipError(f"{LIB_PATH}: build id {built_id()} != source digest {source_id()} after a full rebuild")
     return LIB_PATH
 
 
-def _stale() -> bool:
+def id_files():
+    """the files the build id covers, in the Makefile's order (csrc/Makefile: ID_FILES)"""
+    names = sorted(f for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h")))
+    return [os.path.join(CSRC_DIR, f) for f in names] + [os.path.join(_HERE, "..", "include", "msfwsi_hip.h"),
+                                                         os.path.join(CSRC_DIR, "Makefile")]
+
+
+def source_id(extra: str = "") -> str:
+    """sha256 over the library's sources as the Makefile forms it (`(cat $(ID_FILES); echo "$(EXTRA)") | sha256sum`), 16 hex"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in id_files():
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(extra.encode() + b"\n")
+    return h.hexdigest()[:16]
+
+
+_ID_MARK = b"MSFWSI_BUILD_ID="
+
+
+def built_id(path: str = None) -> str:
+    """the build id baked into a library FILE (csrc/target.hip), read without loading it; "" when it carries none"""
     try:
-        t = os.path.getmtime(LIB_PATH)
-        srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h"))]
-        srcs.append(os.path.join(_HERE, "..", "include", "msfwsi_hip.h"))
-        return any(os.path.getmtime(s) > t for s in srcs)
+        with open(path or LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return ""
+    i = blob.find(_ID_MARK)
+    return blob[i + len(_ID_MARK):i + len(_ID_MARK) + 16].decode("ascii", "replace") if i >= 0 else ""
+
+
+def _stale() -> bool:
+    """the library was not built from the sources beside it: by CONTENT (sha256), not by file times -- binaries are
+    git-ignored and travel by rsync, where a pushed .so can be newer than an edited .hip (VERDICT r5, weak #7)"""
+    try:
+        return built_id() != source_id()
     except OSError:
         return True
 
@@ -161,8 +200,13 @@ def load() -> C.CDLL:
             raise MsfwsiHipError(f"symbol {name} missing from {LIB_PATH}") from e
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    lib.msfwsi_target.argtypes = []
-    lib.msfwsi_target.restype = C.c_char_p
+    for name in ("msfwsi_target", "msfwsi_build_id"):
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MsfwsiHipError(f"symbol {name} missing from {LIB_PATH}") from e
+        fn.argtypes = []
+        fn.restype = C.c_char_p
     for key, env in ((0, "MSFWSI_BIG_TILE_MIN_BLOCKS"), (1, "MSFWSI_FAST_DMA"), (2, "MSFWSI_WGRAD_LIN"),
                      (4, "MSFWSI_SMALL_GRID_BLOCKS"), (5, "MSFWSI_S2_PARITY"), (6, "MSFWSI_WGRAD_BIG"),
                      (9, "MSFWSI_C3_STATIONARY"),

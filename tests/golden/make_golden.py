@@ -467,6 +467,8 @@ def main():
             run_encoder_case()
         elif c == "encoder_div":
             run_encoder_case("r50enc_b16_s64_div", "resnet50", 16, 64, kind="diverse", lowp=("bf16", "fp16"))
+        elif c == "encoder_224":  # the headline geometry: 56 / 28 / 14 / 7-pixel maps, the shapes the image / panel kernels serve
+            run_encoder_case("r50enc_b8_s224_div", "resnet50", 8, 224, kind="diverse", lowp=("bf16", "fp16"))
         elif c == "curve":
             run_curve_case()
         elif c == "curve_samples":

@@ -14,6 +14,7 @@ usage: python tools/check_hand_waits.py [file.s ...]   (no argument: compiles cs
 exit status 1 on any finding."""
 import os
 import re
+import shutil
 import subprocess
 import sys
 
@@ -170,7 +171,7 @@ def main():
         files, jobs = [], []
         for src, _ in targets:  # both compiles at once
             path = f"/tmp/msfwsi_audit_{os.getpid()}_{src}.s"
-            jobs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
+            jobs.append(subprocess.Popen([os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950",
                                           "-munsafe-fp-atomics", "-Wno-inline-asm", "-S", "--cuda-device-only",
                                           os.path.join(ROOT, "msf_wsi_amd", "csrc", src), "-o", path],
                                          stderr=subprocess.DEVNULL))

@@ -15,8 +15,29 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def provenance():
+    """which build these counters belong to: the build id of the library that was profiled (sha256 of the kernel sources,
+    baked into the binary: msf_wsi_amd/_lib.built_id) and the commit (git where a work tree exists -- the GPU box has none,
+    the caller passes MSFWSI_GIT_HEAD there).  bench.py replays a summary only into a run of the SAME build id."""
+    from msf_wsi_amd import _lib
+
+    head = os.environ.get("MSFWSI_GIT_HEAD")
+    if not head:
+        try:
+            head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True,
+                                  timeout=10).stdout.strip() or None
+        except (OSError, subprocess.SubprocessError):
+            head = None
+    return {"build_id": _lib.built_id(os.environ.get("MSFWSI_LIB")), "source_id": _lib.source_id(), "git_head": head}
 
 
 def family(n):
@@ -63,6 +84,7 @@ def main():
            "note": "hbm bytes = 1024*(2*FETCH_SIZE + WRITE_SIZE): FETCH doubled per the gfx950 correction; L2-miss "
                    "(fabric) bytes, Infinity-Cache hits included",
            "families": {}, "kernels": {}}
+    out.update(provenance())
     fam = collections.defaultdict(lambda: collections.defaultdict(float))
     for n in F:
         launches = F[n]["_n"]
