@@ -100,12 +100,15 @@ def hub_stub():
     torch.hub.load_state_dict_from_url = fake
 
 
-def build(arch, device):
+def build(arch, device, rank=0):
+    """rank r seeds its replica with 3407 + 1000 r: like the reference's mp.spawn workers (tools/ssl_train.py:46-48,68 seed
+    the parent only) the ranks do NOT start from equal weights -- PretrainStep's rank-0 broadcast (DDP's, :170) makes them
+    equal, and a run that lost that broadcast would show it in the loss"""
     from msf_wsi_amd.models import resnet as R
     from msf_wsi_amd.models.backbone import MSFWSI
 
     hub_stub()
-    torch.manual_seed(3407)
+    torch.manual_seed(3407 + 1000 * rank)
     with torch.device(device):
         model = MSFWSI(R.__dict__[arch], 4)
     return model.train()
@@ -374,7 +377,7 @@ def run_finetune(args, world, rank, dev, dtype):
     if world == 1 and not args.no_cpu_baseline:
         del ts, model
         torch.cuda.empty_cache()
-        from oracle.hostcpu import usable_cpus
+        from msf_wsi_amd.hostcpu import usable_cpus
 
         threads = usable_cpus()
         out["cpu_baseline"] = finetune_cpu_baseline(args.arch, args.classes, S, threads, args.cpu_budget)
@@ -492,7 +495,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    model = build(args.arch, dev)
+    model = build(args.arch, dev, rank)
     ts = PretrainStep(model, lr=1e-3, global_batch=args.batch * world, dtype=dtype, arch=args.arch)
     ts.engine.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")
     batch = synthetic_batch(args.batch, args.size, 16, seed=rank, device=dev)
@@ -547,7 +550,9 @@ def main():
         ts.engine.dual_stream = keep
     # A number measured on a recompute plan (a pass run features-only and re-run before its backward: +16 % / +32 %
     # time) is not the configuration the metric names unless the caller asked for it: fail loudly instead of printing it
-    if "recompute:" in run_plan and "MSFWSI_RECOMPUTE" not in os.environ:
+    # (several ranks: the plan is COLLECTIVE -- the most conservative rank decides -- and a first contact with real peers must
+    #  produce a line, not die on policy: the line is printed with the plan labelled)
+    if "recompute:" in run_plan and "MSFWSI_RECOMPUTE" not in os.environ and world == 1:
         raise SystemExit(f"bench.py: the memory plan of this run fell back to '{run_plan}' (not enough HBM to "
                          f"keep every activation at {args.batch} tile pairs per GPU); set MSFWSI_RECOMPUTE=auto to accept "
                          f"a number measured with recomputation, or lower --batch")
@@ -577,6 +582,11 @@ def main():
                        "peak_mem_GiB": round(peak_mem, 1), "peak_reserved_GiB": round(peak_reserved, 1),
                        "step_TFLOP_per_s_algorithmic": round(FLOP_PER_PAIR.get(args.arch, 0) * pairs / dt / 1e12, 1),
                        "recompute_plan": run_plan, "plan_at_8_ranks": plan8,
+                       # a multi-rank line measured on a recompute plan says so here (+16 % / +32 % time per re-run pass)
+                       "recompute_fallback": "recompute:" in run_plan and "MSFWSI_RECOMPUTE" not in os.environ,
+                       # device memory the communicators took outside torch's pool when they were created and probed
+                       # (Engine.prepare_multirank: mem_get_info before / after)
+                       "comm_GiB": round(ts.engine.comm_bytes / 2 ** 30, 2),
                        # SyncBatchNorm exchanges (+ the plan) of the last step and the gradient exchange's messages
                        "collectives_per_step": run_collectives,
                        "gradient_messages_per_step": ts.reducer.launches_last_step,
@@ -616,8 +626,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del ts, model, batch
             torch.cuda.empty_cache()
-            # the CPUs this process may really use (cgroup quota: 16 on a GPU box that shows 256, oracle/hostcpu.py)
-            from oracle.hostcpu import usable_cpus
+            # the CPUs this process may really use (cgroup quota: 16 on a GPU box that shows 256, msf_wsi_amd/hostcpu.py)
+            from msf_wsi_amd.hostcpu import usable_cpus
 
             threads = usable_cpus()
             out["cpu_baseline"] = cpu_baseline(args.arch, args.size, args.cpu_budget, threads)

@@ -534,7 +534,7 @@ int msfwsi_get_tuning(int key, long* value);
 
 /* library identification: returns the gfx target string the code objects were built for */
 const char* msfwsi_target(void);
-/* build identification: 16 hex digits, sha256 over every source file this binary was built from (csrc/*.hip, csrc/*.h, this
+/* build identification: 16 hex digits, sha256 over every source file this binary was built from (the .hip and .h files under csrc/, this
  * header, the Makefile and its EXTRA flags).  The loader compares it with the digest of the sources beside it (a binary that
  * travelled without its sources' edits is rebuilt, whatever the file times say), and bench.py replays committed counter
  * summaries (profiles/r*_pmc.json) only when they were taken with this very build. */

@@ -6,6 +6,27 @@
 
 #include <atomic>
 
+// Raise a kernel's dynamic-LDS limit above the default 64 KiB -- ONCE per kernel (function pointer), not on every launch: the
+// hot path issues hundreds of such launches per step from host threads that already feed three streams.  A lock-free set of
+// the kernels already raised; two threads racing on a kernel's first launch may both set the attribute (harmless).
+inline int msfwsi_raise_lds(const void* kern, int bytes) {
+    static std::atomic<uintptr_t> seen[1024];
+    const uintptr_t key = reinterpret_cast<uintptr_t>(kern);
+    unsigned h = (unsigned)((key >> 4) * 2654435761u) & 1023u;
+    for (int probe = 0; probe < 1024; ++probe) {
+        const uintptr_t cur = seen[(h + probe) & 1023u].load(std::memory_order_acquire);
+        if (cur == key) return 0;
+        if (cur == 0) break;
+    }
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    for (int probe = 0; probe < 1024; ++probe) {
+        uintptr_t expected = 0;
+        if (seen[(h + probe) & 1023u].compare_exchange_strong(expected, key, std::memory_order_acq_rel) || expected == key) break;
+    }
+    return 0;
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;

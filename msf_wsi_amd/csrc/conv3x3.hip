@@ -709,9 +709,7 @@ int launch_c3w(C3WParams& prm, hipStream_t stream) {
     auto kern = conv3x3_ws_kernel<T, DGRAD>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES)) return e;
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), Cfg::LDS_BYTES, stream, prm);
@@ -736,9 +734,7 @@ int launch_c3(C3Params& prm, hipStream_t stream) {
     auto kern = conv3x3_kernel<T, BN, DGRAD>;
     static bool attr_done = false;  // one attribute per instantiation
     if (!attr_done && Cfg::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES)) return e;
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), Cfg::LDS_BYTES, stream, prm);

@@ -1101,9 +1101,7 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
     }
     if ((prm.src2 != nullptr || prm.resid_stride > 1) && !dma) return MSFWSI_EUNSUPPORTED;  // pure-DMA kernel features
     if (Cfg::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES)) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), Cfg::LDS_BYTES, stream, prm);
     return msfwsi_launch_status();

@@ -678,8 +678,7 @@ int launch_img_s2d(const Img3S2Params& prm, hipStream_t stream) {
     constexpr int LDS = (BH + 1) * (IW + 1) * C * 2 + (C / 32) * (32 * 80 + 256);
     void (*kern)(const Img3S2Params) = img3x3_s2d_kernel<T, C, BH, IW, PRO>;
     if (LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), LDS)) return e;
     }
     const long nwg = (long)prm.N * (prm.IH / BH);
     if (nwg <= 0 || nwg > 0x7fffffffL) return MSFWSI_EINVAL;
@@ -701,8 +700,7 @@ int launch_img(const Img3Params& prm, hipStream_t stream) {
     constexpr int LDS = (BH + 2) * (IW + 2) * C * 2 + (KO / (32 * TN)) * 32 * 80;
     void (*kern)(const Img3Params) = img3x3_kernel<T, C, KO, BH, IW, PRO, DGRAD, TN>;
     if (LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), LDS)) return e;
     }
     const long nwg = (long)prm.N * (prm.H / BH);
     if (nwg <= 0 || nwg > 0x7fffffffL) return MSFWSI_EINVAL;

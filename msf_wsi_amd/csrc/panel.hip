@@ -870,10 +870,12 @@ template <typename T, int K, int NWV>
 int launch_gram(const GramParams& prm, hipStream_t stream) {
     constexpr int LDS = 128 * K * 2 + K * 4;
     void (*kern)(const GramParams) = panel_gram_kernel<T, K, NWV>;
-    static int slots = 0;  // workgroups resident on the device at once (the kernel is persistent)
+    // workgroups resident on the device at once (the kernel is persistent); one process drives one GPU, two host threads of it
+    // may launch at once (Engine._run_views): a relaxed atomic, both would store the same value
+    static std::atomic<int> slots_cache{0};
+    int slots = slots_cache.load(std::memory_order_relaxed);
     if (LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), LDS)) return e;
     }
     if (slots == 0) {
         int dev = 0, cus = 0, per = 0;
@@ -882,6 +884,7 @@ int launch_gram(const GramParams& prm, hipStream_t stream) {
             cus <= 0 || per <= 0)
             return MSFWSI_EUNSUPPORTED;
         slots = cus * per;
+        slots_cache.store(slots, std::memory_order_relaxed);
     }
     const int grid = prm.npanel < slots ? prm.npanel : slots;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NWV), LDS, stream, prm);
@@ -926,8 +929,7 @@ int launch_panel(const PanelParams& prm, hipStream_t stream) {
         if (wide) kern = hand ? panel_kernel<T, K, BM, PRO, EPI, true, true> : panel_kernel<T, K, BM, PRO, EPI, false, true>;
     }
     if (LDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), LDS)) return e;
     }
     const long nwg = ((long)prm.M + BM - 1) / BM;
     if (nwg <= 0 || nwg > 0x7fffffffL) return MSFWSI_EINVAL;

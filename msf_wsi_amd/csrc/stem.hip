@@ -531,9 +531,7 @@ int launch_stem_ws(StemParams& prm, hipStream_t stream) {
     auto kern = stem_ws_kernel<T>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES)) return e;
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), Cfg::LDS_BYTES, stream, prm);

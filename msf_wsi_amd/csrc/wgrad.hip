@@ -26,6 +26,9 @@
 #ifndef MSFWSI_WGRAD_SMALL_STAGES
 #define MSFWSI_WGRAD_SMALL_STAGES 3  // LDS stages of the 4-wave tiles (A/B: make EXTRA=-DMSFWSI_WGRAD_SMALL_STAGES=2)
 #endif
+#ifndef MSFWSI_WGRAD_PIPE
+#define MSFWSI_WGRAD_PIPE 1  // fragment reads software-pipelined ACROSS the slab barrier (0: the round-2..5 loop; A/B: make EXTRA=-DMSFWSI_WGRAD_PIPE=0)
+#endif
 #ifndef MSFWSI_FETCH_FIRST
 #define MSFWSI_FETCH_FIRST 1  // DMA requests of slab kt+2 before the MFMAs of slab kt (0: after them; A/B: make EXTRA=-DMSFWSI_FETCH_FIRST=0)
 #endif
@@ -366,6 +369,108 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
 
     const int nk = (mend - mbeg + BKM - 1) / BKM;
     if (nk <= 0) return;
+#if MSFWSI_WGRAD_PIPE
+    if constexpr (!XPRO) {
+        // ---- Pixel loop, fragment reads software-pipelined ACROSS the slab barrier (round 6) ----
+        // The round-2..5 loop was: wait + barrier, DMA requests, ALL 16 transposed reads of the slab, `s_waitcnt lgkmcnt(0)`,
+        // 8 MFMAs -- every wave's first MFMA of a slab waited out the LDS latency right behind the barrier, and the four
+        // waves of a SIMD did so TOGETHER (the barrier puts them in phase): the matrix pipe idled for that latency once per
+        // 1024-cycle slab (hipcc's -S: `s_waitcnt lgkmcnt(0)` in front of the first v_mfma of every iteration), and ~20 VALU
+        // address additions per slab competed with the MFMAs for issue slots.  Now a slab's two k-groups live in two
+        // register sets: the reads of (slab kt, group 1) are issued BEFORE the MFMAs of (kt, group 0), the wave then waits
+        // for its DMA pieces of slab kt+1 AND for its own outstanding reads, joins the barrier, issues the DMA requests of
+        // slab kt+3 and the reads of (kt+1, group 0), and only then runs the MFMAs of (kt, group 1) -- whose operands were
+        // requested a whole MFMA group earlier.  Every MFMA group so finds its operands in registers; the latency of a read is
+        // hidden behind the other group's four MFMAs (128 cycles per wave, 512 per SIMD).
+        // Stage reuse: the requests of slab kt+3 overwrite the stage of slab kt.  Every wave has waited for ALL its reads
+        // of slab kt (lgkmcnt(0)) before the barrier behind which those requests are issued, so three stages suffice.
+        // Addresses: the per-lane offset of a fragment inside a stage image is computed once (fa / fb: the block swizzle of
+        // a row depends on bits of the row index that neither the k-group nor the +4-row half changes); k-group and half are
+        // immediates of the ds_read, the stage one addition per fragment column and slab.
+        constexpr int DMA_PER_SLAB = A_IT + B_IT;
+        static_assert(DMA_PER_SLAB >= 2 && DMA_PER_SLAB <= 4, "vmcnt literal table");
+        constexpr int NST = Cfg::NST;
+        static_assert(NST == 3, "three stages: slabs kt+1, kt+2 landed / in flight while kt is read, kt+3 requested into kt's");
+        static_assert(BKM / (2 * VEC) == 2, "two k-groups per slab: two register sets");
+        int fa[TI], fb[TJ];
+        if constexpr (sizeof(T) == 2) {
+            const int li = lane & 15, G = lane >> 4;
+            const int kb0 = (G >> 1) * 8 + (li >> 2);
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) fa[ti] = wnat_off<ROWI>(kb0, ((wi * TI + ti) * 32 + (G & 1) * 16 + (li & 3) * 4) * 2);
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj) fb[tj] = wnat_off<ROWJ>(kb0, ((wj * TJ + tj) * 32 + (G & 1) * 16 + (li & 3) * 4) * 2);
+        }
+        auto read_group = [&](int st, int ks, frag_t(&af)[TI], frag_t(&bf)[TJ]) {
+            const char* Ab = As + st * Cfg::A_BYTES;
+            const char* Bb = Bs + st * Cfg::B_BYTES;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) {
+                    const char* pa = Ab + fa[ti] + ks * 16 * ROWI;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWI));
+                    af[ti] = __builtin_bit_cast(frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int tj = 0; tj < TJ; ++tj) {
+                    const char* pb = Bb + fb[tj] + ks * 16 * ROWJ;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + 4 * ROWJ));
+                    bf[tj] = __builtin_bit_cast(frag_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) af[ti] = read_tr_frag<T, ROWI>(Ab, ks, (wi * TI + ti) * 32, lane);
+#pragma unroll
+                for (int tj = 0; tj < TJ; ++tj) bf[tj] = read_tr_frag<T, ROWJ>(Bb, ks, (wj * TJ + tj) * 32, lane);
+            }
+        };
+        auto mma_group = [&](const frag_t(&af)[TI], const frag_t(&bf)[TJ]) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < TJ; ++tj) mma32<T>(acc[ti][tj], af[ti], bf[tj]);
+        };
+        // prologue: three slabs requested, slab 0 landed and visible, its group 0 on the way to registers
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            if (i < nk) fetch(mbeg + i * BKM, i);
+        if (nk >= 3) wait_vmcnt<2 * DMA_PER_SLAB>();
+        else if (nk == 2) wait_vmcnt<DMA_PER_SLAB>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        frag_t a0[TI], b0[TJ], a1[TI], b1[TJ];
+        read_group(0, 0, a0, b0);
+        int st_c = 0;
+        // (the last slab is peeled off: ONE straight-line body, so that hipcc keeps one set of accumulator registers -- with
+        //  the final slab as a branch of the loop body it renamed the accumulators per branch and spilled 96 registers)
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            read_group(st_c, 1, a1, b1);
+            mma_group(a0, b0);
+            const int st_n = st_c == NST - 1 ? 0 : st_c + 1;
+            // my DMA pieces of slab kt+1 have landed (slab kt+2, if any, stays in flight); my reads of slab kt are done
+            if (kt + 2 < nk) wait_vmcnt<DMA_PER_SLAB>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#if MSFWSI_FETCH_FIRST
+            if (kt + 3 < nk) fetch(mbeg + (kt + 3) * BKM, st_c);
+            read_group(st_n, 0, a0, b0);
+            mma_group(a1, b1);
+#else
+            read_group(st_n, 0, a0, b0);
+            mma_group(a1, b1);
+            if (kt + 3 < nk) fetch(mbeg + (kt + 3) * BKM, st_c);
+#endif
+            st_c = st_n;
+        }
+        read_group(st_c, 1, a1, b1);
+        mma_group(a0, b0);
+        mma_group(a1, b1);
+#else
     if constexpr (!XPRO) {
         constexpr int DMA_PER_SLAB = A_IT + B_IT;
         static_assert(DMA_PER_SLAB >= 2 && DMA_PER_SLAB <= 4, "vmcnt literal table");
@@ -396,6 +501,7 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
             st_c = st_c == NST - 1 ? 0 : st_c + 1;
             st_f = st_f == NST - 1 ? 0 : st_f + 1;
         }
+#endif
     } else {
         fetch(mbeg, 0);
         commit(0, mbeg);
@@ -686,9 +792,7 @@ int launch_wgrad_os(const msfwsi_conv_desc* d, const void* x, const void* dy, fl
     auto kern = wgrad_os_kernel<T>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WgWCfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), WgWCfg::LDS_BYTES)) return e;
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), WgWCfg::LDS_BYTES, stream, prm);

@@ -85,6 +85,61 @@ def probe_collectives(group=None, device=None):
     return dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
 
 
+def broadcast_state(tensors: Sequence[torch.Tensor], group=None, src: int = 0, coalesce_below: int = 1 << 22):
+    """The DDP constructor's exchange (tools/ssl_train.py:170: `_sync_module_states` -- parameters AND buffers of rank 0
+    overwrite every other rank's): in place.  It is load-bearing in the reference: main() seeds the parent process only
+    (:46-48), the mp.spawn workers (:68) build their model from their own RNG state, and this broadcast is what makes the
+    replicas equal.  `src` is a rank of `group`.  Large tensors (the flat weight buffers of the optimizer groups) travel
+    as they are, small ones (BatchNorm buffers, scaler state) coalesced per dtype into one message each."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
+    small: Dict[Tuple[torch.dtype, torch.device], List[torch.Tensor]] = {}
+    for t in tensors:
+        if t.numel() == 0:
+            continue
+        if t.numel() >= coalesce_below and t.is_contiguous():
+            dist.broadcast(t, src=gsrc, group=group)
+        else:
+            small.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, dev), ts in small.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src=gsrc, group=group)
+        pos = 0
+        with torch.no_grad():
+            for t in ts:
+                t.copy_(flat[pos:pos + t.numel()].view(t.shape))
+                pos += t.numel()
+
+
+def probe_sharded(group=None, device=None) -> bool:
+    """One-time check of the sharded optimizer's collective forms on this backend: the IN-PLACE reduce_scatter_tensor (output =
+    this rank's slice of the input) and the in-place all_gather_into_tensor (input = this rank's slice of the output), on a
+    small buffer with known values.  The verdict is COLLECTIVE (MIN over ranks of the local result; a backend that rejects
+    the form raises on every rank alike), so every rank takes the same branch: True -> reduce-scatter / all-gather,
+    False -> the all-reduce form (GradReducer(shard=False))."""
+    backend = dist.get_backend(group)
+    dev = device if device is not None else ("cuda" if backend == "nccl" else "cpu")
+    w, r = dist.get_world_size(group), dist.get_rank(group)
+    ok = 1
+    try:
+        per = 8
+        buf = torch.arange(per * w, dtype=torch.float32, device=dev) + 1.0
+        dist.reduce_scatter_tensor(buf[r * per:(r + 1) * per], buf, op=dist.ReduceOp.SUM, group=group)
+        want = (torch.arange(r * per, (r + 1) * per, dtype=torch.float32, device=dev) + 1.0) * w
+        ok &= int(torch.equal(buf[r * per:(r + 1) * per], want))
+        out = torch.zeros(per * w, dtype=torch.bfloat16, device=dev)
+        out[r * per:(r + 1) * per] = float(r + 1)
+        dist.all_gather_into_tensor(out, out[r * per:(r + 1) * per], group=group)
+        want = torch.arange(1, w + 1, dtype=torch.bfloat16, device=dev).repeat_interleave(per)
+        ok &= int(torch.equal(out, want))
+    except Exception:  # noqa: BLE001 -- an unsupported form is the finding
+        ok = 0
+    flag = torch.full((1,), ok, dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag[0]))
+
+
 class FlatGroups:
     """Flat storage of the model parameters by optimizer group."""
 

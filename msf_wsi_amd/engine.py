@@ -469,6 +469,40 @@ class Engine:
             self._stream_groups[self._side_stream(dev, which).cuda_stream] = g
             probe_collectives(g, dev)  # the communicator's buffers exist before the memory plan measures what is free
 
+    def prepare_multirank(self, dev):
+        """COLLECTIVE, called once by the trainer's constructor when statistics are exchanged (more than one rank, or the
+        single-rank RCCL rehearsal): the multi-stream schedule's side-stream communicators are created and probed HERE -- a
+        point every rank passes in the same order -- and what they (and the main communicator's first collectives) took
+        from the card is MEASURED (`comm_bytes`: torch.cuda.mem_get_info before / after; RCCL allocates its channel buffers
+        and peer mappings outside torch's pool), so the memory plan's reserve is a measurement, not an assumption.  If a
+        rank cannot create or use them the verdict is collective (MIN over ranks) and every rank runs the views in
+        lockstep on the main communicator instead -- a slower schedule, never a dead first step."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        backend = dist.get_backend(self.group)
+        cdev = dev if backend == "nccl" else "cpu"
+        torch.cuda.synchronize(dev)
+        free0, _ = torch.cuda.mem_get_info(dev)
+        probe_collectives(self.group, dev)
+        ok = 1
+        if self.multirank_streams and self.allow_multistream:
+            try:
+                self._make_stream_groups(dev)
+            except Exception as e:  # noqa: BLE001 -- whatever the backend refuses is the finding
+                print(f"[msf_wsi_amd] side-stream communicators unavailable ({type(e).__name__}: {e}); the views run in "
+                      f"lockstep on the main communicator", flush=True)
+                ok = 0
+            flag = torch.full((1,), ok, dtype=torch.int32, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if not int(flag[0]):
+                self._stream_groups = {}
+                self.multirank_streams = False
+        torch.cuda.synchronize(dev)
+        free1, _ = torch.cuda.mem_get_info(dev)
+        self.comm_bytes = max(0, free0 - free1)
+
+    comm_bytes = 0  # device memory the communicators took outside torch's pool (prepare_multirank)
+
     def _side_stream(self, dev, which: str = "side") -> "torch.cuda.Stream":
         key = f"{dev}/{which}"
         if key not in self._side:
@@ -1225,7 +1259,9 @@ class Engine:
         avail = free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         # head room: 6 GiB for the allocator's fragmentation; with more than one rank another 4 GiB for RCCL's channel
         # buffers and the IPC mappings of the peers, which are allocated outside torch's pool after this measurement
-        budget = avail - (6 << 30) - ((4 << 30) if self._world() > 1 else 0)
+        # (prepare_multirank measured what the communicators took at creation -- already missing from `free`; the reserve
+        # covers what RCCL adds on first use of larger messages: at least 4 GiB, or as much again as creation took)
+        budget = avail - (6 << 30) - (max(4 << 30, self.comm_bytes) if self._world() > 1 else 0)
         # calibration (ResNet-50, 256 tile pairs, bf16): kept activations 180 GiB, measured peak 240.8 GiB with
         # 28 GiB of weights/optimizer -> backward transients (gradient tensors, re-normalised operands, the
         # recomputed conv3) are about a quarter of one full target pass

@@ -1,10 +1,10 @@
-"""How many CPUs the calling process may really use (test / measurement infrastructure, like the rest of oracle/).
+"""How many CPUs the calling process may really use (host-side support for measurements and tests: no arithmetic of the hot path lives here).
 
 A GPU box of the pool shows 256 logical CPUs to `os.cpu_count()` and an all-ones affinity mask, but its cgroup grants a
 CPU-time quota of 16 (`/sys/fs/cgroup/cpu.max` = "1600000 100000").  torch then starts 128 intra-op threads that are
-throttled to 16 CPUs' worth of time: the fp64 oracle step of ResNet-18 / 16 tile pairs of 64x64 measured 25.5 s with
+throttled to 16 CPUs' worth of time: a CPU fp64 step of ResNet-18 / 16 tile pairs of 64x64 measured 25.5 s with
 the default 128 threads against 4.5 s with 16 (tools/host_probe.py, gpurun_out/r4_probe.log) -- that, not the
-arithmetic, was most of the round-3 GPU suite's 960 s.  Every CPU-side timing or oracle run sizes its thread pool with
+arithmetic, was most of the round-3 GPU suite's 960 s.  Every CPU-side timing or checker run sizes its thread pool with
 `usable_cpus()`."""
 import os
 

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import kernels as kn
-from .dist import FlatGroups, GradReducer, world_size
+from .dist import FlatGroups, GradReducer, broadcast_state, probe_sharded, world_size
 from .engine import Engine, GradStore, WeightStore
 
 FUSER_WEIGHTS = (0.1, 0.4, 0.7, 1.0)  # tools/ssl_train.py:623-625
@@ -113,6 +113,12 @@ class FlatAdamScaler:
         owned = scattered = None
         if sharded:
             owned, scattered = reducer.take_shards()
+            if self._master_stale and self._last_scattered is not None and any(
+                    scattered.get(gi) != self._last_scattered.get(gi) for gi in self.lazy_master_groups):
+                # the fp32 masters of a lazy group are current only on the rank that stepped them LAST step; this step's
+                # buckets cut the group differently, so the new owners would step stale masters: fetch them first
+                # (collective; every rank sees the same layouts, so every rank takes this branch)
+                self.sync_master_weights()
         ngroups = len(self.flats.w)
 
         def ranges(gi):  # element ranges of group gi this rank steps
@@ -161,6 +167,7 @@ class FlatAdamScaler:
         self.engine.invalidate_weights()
 
     _small_cache = None
+    _small_layout = None
 
     def _gather_small_masters(self, reducer, owned, scattered):
         """lazy_master_groups keep the other ranks' fp32 masters stale -- but the 1-D parameters of those groups (BatchNorm
@@ -174,7 +181,13 @@ class FlatAdamScaler:
         lazy = [gi for gi in self.lazy_master_groups if self.flats.w16[gi] is not None]
         if not lazy:
             return
+        # the ownership mask is valid for ONE bucket layout: a step whose launch(part=...) sequence differs (bucket_inter
+        # toggled, another set of parts) moves the shard boundaries, and with them who holds the current master of an element
+        layout = tuple((gi, tuple(scattered.get(gi, [])), tuple(owned.get(gi, []))) for gi in lazy)
+        if self._small_cache is not None and self._small_layout != layout:
+            self._small_cache = None
         if self._small_cache is None:
+            self._small_layout = layout
             r = _rank(reducer.group)
             cache = []
             for gi in lazy:
@@ -270,10 +283,13 @@ class PretrainStep(FlatAdamScaler):
                  fuser_weights: Sequence[float] = FUSER_WEIGHTS, dtype: torch.dtype = torch.bfloat16,
                  use_scaler: Optional[bool] = None, init_scale: float = 65536.0, process_group=None,
                  sync_bn: bool = True, arch: str = "resnet18", loss: str = "cosine", temperature: float = 0.2,
-                 shard_optimizer: Optional[bool] = None):
-        """shard_optimizer (None: on with more than one rank unless MSFWSI_SHARD_OPT=0): gradients are reduce-scattered, each
-        rank runs Adam on 1/world of every bucket and the updated weights are all-gathered (fp32 masters of the encoders,
-        the 16-bit copy alone for the `inter_` heads) -- checkpoint() / resume() are then COLLECTIVE calls."""
+                 shard_optimizer: Optional[bool] = None, broadcast_from_rank0: bool = True):
+        """shard_optimizer (None: on with more than one rank unless MSFWSI_SHARD_OPT=0 or the backend fails the start-up probe
+        of the in-place reduce-scatter / all-gather forms, dist.probe_sharded): gradients are reduce-scattered, each rank runs
+        Adam on 1/world of every bucket and the updated weights are all-gathered (fp32 masters of the encoders, the 16-bit
+        copy alone for the `inter_` heads) -- checkpoint() / save_checkpoint() / resume() are then COLLECTIVE calls.
+        broadcast_from_rank0: with more than one rank the constructor is COLLECTIVE like DistributedDataParallel's
+        (ssl_train.py:170): parameters, BatchNorm buffers and the GradScaler state of rank 0 overwrite every other rank's."""
         _lib.load()
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -297,6 +313,13 @@ class PretrainStep(FlatAdamScaler):
         self.betas = (0.9, 0.999)
         self.eps = [1e-8, 1e-8, 1e-8]
         self.flats = FlatGroups(model, lowp_dtype=None if dtype == torch.float32 else dtype)
+        multi = world_size(process_group) > 1 or os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0"
+        if multi and broadcast_from_rank0:
+            # the DDP constructor's broadcast (ssl_train.py:170).  The reference seeds the parent process only (:46-48): its
+            # mp.spawn workers (:68) build their heads from their own RNG state and THIS exchange makes the replicas equal.
+            # The parameters are views of the flat buffers, so three large messages carry them; before the 16-bit copies are
+            # cast (_register_lowp_weights below)
+            broadcast_state(list(self.flats.w) + list(model.buffers()), process_group)
         self.engine = Engine(process_group=process_group, sync_bn=sync_bn)
         self.engine.allow_multistream = True  # flat, pre-allocated gradient accumulators: several streams may add into them
         model._engine = self.engine
@@ -305,8 +328,6 @@ class PretrainStep(FlatAdamScaler):
         # gradients travel on their OWN communicator: the multi-GB all-reduce of the head group must not sit in
         # front of the latency-bound SyncBN exchanges of the encoder backward that is still running
         grad_group = process_group
-        import os
-
         force = os.environ.get("MSFWSI_FORCE_SYNC", "0") != "0"
         if process_group is None and (world_size(process_group) > 1 or force):
             import torch.distributed as dist
@@ -317,10 +338,22 @@ class PretrainStep(FlatAdamScaler):
             grad_group = dist.new_group(backend=dist.get_backend())
         if shard_optimizer is None:
             shard_optimizer = os.environ.get("MSFWSI_SHARD_OPT", "1") != "0"
+        if shard_optimizer and multi:
+            # the sharded exchange uses RCCL's IN-PLACE reduce-scatter / all-gather forms: checked once, on small buffers
+            # with known values, with a COLLECTIVE verdict -- a backend that rejects or miscomputes them falls back to the
+            # all-reduce form on every rank alike instead of failing (or diverging) inside the first step
+            shard_optimizer = probe_sharded(grad_group, dev)
+        self.shard_optimizer = bool(shard_optimizer) and multi
         self.reducer = GradReducer(self.flats, grad_group, shard=bool(shard_optimizer))
         if dtype != torch.float32:
             self.lazy_master_groups = (2,)  # the `inter_` heads: kernels read their 16-bit copy only
         self._init_optimizer_state(use_scaler, init_scale)
+        if multi:
+            if broadcast_from_rank0:
+                broadcast_state([self.scale, self.growth_tracker, self.step_dev], process_group)
+            # the side streams' communicators are created HERE, at a point every rank passes in the same order, not lazily
+            # inside a step's forward where a rank that plans differently could desynchronise new_group
+            self.engine.prepare_multirank(dev)
 
         def _state_dict_guard(module, prefix, keep_vars):
             if self._master_stale:
@@ -433,7 +466,21 @@ class PretrainStep(FlatAdamScaler):
                 "scaler": self.scaler_state_dict()}
 
     def save_checkpoint(self, path: str, epoch: int):
-        torch.save(self.checkpoint(epoch), path)
+        """ssl_train.py:375-386,489-492.  With more than one rank this is a COLLECTIVE call: every rank calls it -- OUTSIDE
+        the reference's `if rank == 0` guard (:363), because the sharded optimizer's master weights and Adam moments are
+        gathered in checkpoint() -- rank 0 alone writes the file, and all ranks leave together (a barrier), so no rank
+        reads or resumes from a half-written file."""
+        ckpt = self.checkpoint(epoch)
+        multi = world_size(self.group) > 1
+        if not multi:
+            torch.save(ckpt, path)
+            return
+        import torch.distributed as dist
+
+        if dist.get_rank(self.group) == 0:
+            torch.save(ckpt, path)
+        del ckpt
+        dist.barrier(group=self.group)
 
     def resume(self, ckpt: dict) -> int:
         """ssl_train.py:313-335 incl. the hard-coded eps=0.1 after loading"""

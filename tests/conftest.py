@@ -13,8 +13,8 @@ for _p in (ROOT, HERE):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # torch's default intra-op pool follows os.cpu_count() (256 on a GPU box whose cgroup grants 16 CPUs): throttled
-    # 5x (oracle/hostcpu.py).  Size it to what the process may really use.
-    from oracle.hostcpu import set_torch_threads, usable_cpus
+    # 5x (msf_wsi_amd/hostcpu.py).  Size it to what the process may really use.
+    from msf_wsi_amd.hostcpu import set_torch_threads, usable_cpus
 
     # processes the tests spawn (the rank workers of test_dist_gpu / test_dropin_gpu: 2-4 at a time, and whatever else
     # inherits this environment) start with a quarter of the usable CPUs each instead of os.cpu_count() / 2 threads
@@ -30,7 +30,8 @@ def pytest_configure(config):
 # (tests/oracle_jobs.py) compute those while the GPU runs everything before them.
 # ----------------------------------------------------------------------------------------------------------------
 FILE_ORDER = ["test_parity_gpu", "test_train_gpu", "test_dist_gpu", "test_dropin_gpu", "test_fixes_gpu",
-              "test_lowp_parity_gpu", "test_lowp_default_gpu", "test_blocks_lowp_gpu", "test_encoder_gpu", "test_hooknet_gpu", "test_tiler",
+              "test_lowp_parity_gpu", "test_lowp_default_gpu", "test_blocks_lowp_gpu", "test_encoder_gpu", "test_headline_geometry_gpu",
+              "test_hooknet_gpu", "test_tiler",
               "test_augment", "test_metrics", "test_kernels_gpu", "test_production_gpu"]
 # (substring of the node id, rank inside the first group): tests that need a long-running oracle job
 LATE = [("test_step_parity_r18_b8_s224_config1", 1), ("test_step_parity_r50_b8_s64_diverse", 2),

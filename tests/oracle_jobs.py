@@ -164,7 +164,7 @@ def _run(name, key, path, threads):
 def usable_cpus():
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    from oracle.hostcpu import usable_cpus as f
+    from msf_wsi_amd.hostcpu import usable_cpus as f
 
     return f()
 
@@ -175,7 +175,7 @@ def start(requests, workers=None, threads=None):
     global _POOL, _DIR
     import multiprocessing as mp
 
-    # a GPU box grants 16 CPUs' worth of time (oracle/hostcpu.py).  The oracle's small-batch steps scale poorly with
+    # a GPU box grants 16 CPUs' worth of time (msf_wsi_amd/hostcpu.py).  The oracle's small-batch steps scale poorly with
     # threads (fp64 ResNet-18 step: 6.6 s on 4 threads, 4.5 s on 16), so several jobs side by side on 4 threads each
     # finish far sooner than one after the other on all of them; the test process keeps the rest for itself
     cpus = usable_cpus()

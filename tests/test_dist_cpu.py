@@ -383,3 +383,118 @@ def test_sharded_reducer_equals_allreduce_step():
         assert torch.equal(ret["w0"][gi], ret["w1"][gi])  # identical weights on every rank
     # each rank stepped about half of the parameters (its shards + the short tails of 6 buckets)
     assert ret["total"] // 2 <= ret["covered0"] <= ret["total"] // 2 + 6 * world * 5
+
+
+def _bcast_worker(rank, world, port, ret):
+    """the DDP constructor's rank-0 broadcast (tools/ssl_train.py:170) through dist.broadcast_state: every rank builds its
+    model from a DIFFERENT seed (the reference seeds the parent process only, :46-48; mp.spawn workers draw their own), lays
+    it out in the flat groups, and the broadcast leaves weights, views and BatchNorm buffers bit-identical to rank 0's"""
+    from msf_wsi_amd.dist import FlatGroups, broadcast_state, probe_sharded
+
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        model = build_product("resnet18")
+        with torch.no_grad():  # rank-dependent weights AND buffers
+            g = torch.Generator().manual_seed(100 + rank)
+            for p in model.parameters():
+                p.add_(torch.randn(p.shape, generator=g))
+            for b in model.buffers():
+                b.add_(rank + 1)
+        flats = FlatGroups(model, with_bf16=False, device="cpu")
+        before = float(model.inter_projector[3][0].weight.double().sum())
+        broadcast_state(list(flats.w) + list(model.buffers()))
+        sd = model.state_dict()
+        ret[rank] = {"before": before, "sum": {k: float(v.double().sum()) for k, v in sd.items()},
+                     "flat": [float(w.double().abs().sum()) for w in flats.w],
+                     "sharded_ok": probe_sharded(None, "cpu")}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank0_broadcast_makes_differently_seeded_replicas_equal():
+    ret = mp.Manager().dict()
+    mp.spawn(_bcast_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0]["before"] != ret[1]["before"]          # the replicas really differed
+    assert ret[0]["sum"] == ret[1]["sum"] and ret[0]["flat"] == ret[1]["flat"]   # bit-identical sums of every entry
+    assert len(ret[0]["sum"]) == 528
+    assert ret[0]["sum"]["context_encoder.bn1.num_batches_tracked"] == 1.0       # rank 0's buffers (0 + 1), not rank 1's
+    # gloo runs the in-place reduce-scatter / all-gather forms (or both ranks agree that it does not): same branch everywhere
+    assert ret[0]["sharded_ok"] == ret[1]["sharded_ok"]
+
+
+def _world8_worker(rank, world, port, ret):
+    """what the driver's 8-rank run does before its first kernel, on CPU tensors over gloo: rendezvous, the collective
+    capability probes, the rank-0 broadcast, the collective recompute plan with one rank short of memory, and one sharded
+    gradient exchange + gather over the trainer's bucket order"""
+    from msf_wsi_amd.dist import FlatGroups, GradReducer, broadcast_state, probe_collectives, probe_sharded, shard_bucket, shard_range
+    from msf_wsi_amd.engine import Engine
+
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        probe_collectives(None, "cpu")
+        sharded = probe_sharded(None, "cpu")
+        torch.manual_seed(1000 + rank)
+        model = torch.nn.ModuleDict({"context_a": torch.nn.Linear(70, 33), "target_a": torch.nn.Conv2d(8, 16, 3),
+                                     "inter_projector": torch.nn.ModuleList([torch.nn.Linear(130, 130, bias=False) for _ in range(4)]),
+                                     "inter_predictor": torch.nn.ModuleList([torch.nn.Linear(130, 32) for _ in range(4)])})
+        flats = FlatGroups(model, with_bf16=False, device="cpu")
+        broadcast_state(flats.w)
+        w0 = [w.clone() for w in flats.w]
+        # collective plan: rank 5 is short of memory -> every rank recomputes t1, one collective per shape
+        eng = Engine(sync_bn=True)
+        eng.recompute = "auto"
+        eng._plan_local = lambda *a, **k: (({"t1"}, False, False) if rank == 5 else (set(), False, True))
+        nosave = eng._plan_recompute(22.5e6 + rank, 256, 16, torch.device("cpu"), 0.0, shape_key=((3, 224, 224), "r50"))
+        gens = [torch.Generator().manual_seed(7 + r) for r in range(world)]
+        local = [[torch.randn(g.numel(), generator=gens[r]) for g in flats.g] for r in range(world)]
+        mean = [sum(local[r][gi] for r in range(world)) / world for gi in range(len(flats.g))]
+        for gi, g in enumerate(flats.g):
+            g.copy_(local[rank][gi])
+        red = GradReducer(flats, None, shard=sharded)
+        for s_ in (3, 2, 1, 0):
+            red.launch("inter", part=f"inter_predictor.{s_}.")
+            red.launch("inter", part=f"inter_projector.{s_}.")
+        for name in ("inter", "target", "context"):
+            red.launch(name)
+        red.wait()
+        owned, scattered = red.take_shards()
+        own_elems = 0
+        for gi in range(len(flats.g)):
+            for lo, hi in (owned.get(gi, []) if sharded else [(0, flats.g[gi].numel())]):
+                assert torch.allclose(flats.g[gi][lo:hi], mean[gi][lo:hi], rtol=0, atol=1e-6)
+                flats.w[gi][lo:hi] -= flats.g[gi][lo:hi]
+                own_elems += hi - lo
+            for lo, per in scattered.get(gi, []):  # the ownership rule the Adam pass relies on
+                assert (lo + rank * per, lo + (rank + 1) * per) in owned[gi]
+        for gi in range(len(flats.g)):
+            for wk in red.gather_weights(gi, scattered.get(gi, []), flats.w[gi]):
+                wk.wait()
+        ret[rank] = {"plan": (tuple(sorted(nosave)), eng.last_plan, eng.collectives), "sharded": sharded,
+                     "shard": shard_range(2048, world, rank), "own": own_elems,
+                     "w": [w.clone() for w in flats.w], "ref": [w0[gi] - mean[gi] for gi in range(len(w0))],
+                     "msgs": red.launches_last_step}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_rendezvous_plan_and_shard_ownership():
+    """world 8 is what the driver's scaling run uses (BASELINE config 3: 8 x 256 tile pairs): eight gloo processes on the
+    CPU form the group, agree on the collective probes and the recompute plan, and the sharded exchange over the trainer's
+    bucket order leaves every rank with the weights of the unsharded step"""
+    world = 8
+    ret = mp.Manager().dict()
+    mp.spawn(_world8_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    assert len({ret[r]["plan"] for r in range(world)}) == 1 and ret[0]["plan"][0] == ("t1",) and ret[0]["plan"][2] == 1
+    assert len({ret[r]["sharded"] for r in range(world)}) == 1
+    assert [ret[r]["shard"] for r in range(world)] == [(256 * r, 256 * (r + 1)) for r in range(world)]
+    assert len({ret[r]["msgs"] for r in range(world)}) == 1
+    total = sum(w.numel() for w in ret[0]["w"])
+    if ret[0]["sharded"]:
+        assert all(ret[r]["own"] < total // 4 for r in range(world))        # each rank stepped ~1/8 (+ tails)
+    for r in range(world):
+        for gi, ref in enumerate(ret[0]["ref"]):
+            assert torch.allclose(ret[r]["w"][gi], ref, rtol=0, atol=1e-6), (r, gi)
+            assert torch.equal(ret[r]["w"][gi], ret[0]["w"][gi])

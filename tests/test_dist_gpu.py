@@ -38,7 +38,19 @@ def _worker(rank, world, port, ret):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        model = build_product("resnet18").cuda().train()
+        model = build_product("resnet18")
+        if rank != 0:
+            # the reference seeds the parent process only (ssl_train.py:46-48): its spawned workers do NOT build equal
+            # replicas, DDP's constructor broadcast (:170) makes them equal.  Every rank but 0 starts from other weights AND
+            # other BatchNorm buffers here; the parity with the oracle below (which knows rank 0's weights only) and the
+            # num_batches_tracked == 2 check hold only if PretrainStep's rank-0 broadcast ran
+            with torch.no_grad():
+                g = torch.Generator().manual_seed(500 + rank)
+                for p in model.parameters():
+                    p.add_(0.05 * torch.randn(p.shape, generator=g))
+                for b in model.buffers():
+                    b.add_(3)
+        model = model.cuda().train()
         # world 2: the all-reduce exchange; world 4: the sharded optimizer (reduce-scatter, Adam on 1/4, all-gather)
         ts = PretrainStep(model, lr=LR, global_batch=B, dtype=torch.float32, use_scaler=False, sync_bn=True,
                           shard_optimizer=(world == 4))
@@ -52,9 +64,12 @@ def _worker(rank, world, port, ret):
         ret[f"collectives{rank}"] = ts.engine.collectives_last_step
         ret[f"plan{rank}"] = ts.engine.last_plan
         ret[f"grad_msgs{rank}"] = ts.reducer.launches_last_step
+        ts.sync_master_weights()  # collective (a no-op in fp32: no lazily gathered masters)
         if rank == 0:
             ret["loss"] = mean_loss
             ret["sd"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        if rank == world - 1:  # the replicas end the step bit-identical (checked against rank 0's below)
+            ret["sd_last"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         # a second step: the collective plan of the shape is known now, so the context views pair up too -- its count is
         # the steady state of a run (the first step's context passes ran one after the other to calibrate the plan)
         ts.step(local)
@@ -96,6 +111,8 @@ def test_ranks_match_single_process(hip_lib, world):
     assert len({ret[f"plan{r}"] for r in range(world)}) == 1
     print(f"world {world}: {ret['collectives0']} engine collectives per step, plan {ret['plan0']}")
 
+    for k, v in ret["sd"].items():  # rank world-1 started from OTHER weights and buffers: bit-identical to rank 0 now
+        assert torch.equal(v, ret["sd_last"][k]), k
     oc = oracle_case(CASE)
     assert abs(ret["loss"] - oc["loss64"]) <= 1e-3 * max(abs(oc["loss64"]), 1e-2), (ret["loss"], oc["loss64"])
     sd2 = ret["sd"]

@@ -174,7 +174,7 @@ def test_bench_line_contract_with_streams():
     assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and rf["concurrent_streams_in_timed_region"] == 3
     assert "ONE stream" in rf["measured_on"] and 0.02 < rf["timed_fraction_of_step"] <= 1.05, rf
     cb = d["cpu_baseline"]
-    from oracle.hostcpu import usable_cpus
+    from msf_wsi_amd.hostcpu import usable_cpus
 
     assert cb["kind"] == "port" and cb["cores"] == usable_cpus() and cb["value"] > 0
 

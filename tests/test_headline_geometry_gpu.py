@@ -16,7 +16,10 @@ import torch
 from helpers import LOWP_FLOOR, LOWP_TAG, load_golden, lowp_gate, rel, spread_gate
 from test_encoder_gpu import _trunk_case, _trunk_oracle, _trunk_product
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("reproducible_sums")]
+pytestmark = pytest.mark.gpu
+# (the 16-bit tests run under `reproducible_sums` like every whole-model statistical test; the fp32 test must NOT: with the
+#  pixel splits capped at one, a weight-gradient tile is ONE fp32 accumulation chain over all 8 x 56 x 56 = 25 088 rows --
+#  measured here: product median 1.6e-3 against 2.8e-4 on the default split-K path, whose partial sums cover ~1 000 rows)
 
 CASE = "r50enc_b8_s224_div"
 
@@ -117,7 +120,7 @@ def _gate_lowp(vec, dtype, names, rels, fr, what):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-def test_resnet50_trunk_224_production_dispatch(hip_lib, monkeypatch, dtype):
+def test_resnet50_trunk_224_production_dispatch(hip_lib, reproducible_sums, monkeypatch, dtype):
     """16-bit storage with the production dispatch forced: features and every gradient tensor within 2 x the distance of
     the REFERENCE UNDER AUTOCAST from its fp64 run (fixture spread_*_bf16 / _fp16), and the launches COUNTED:
     conv2 of the stride-1 Bottlenecks of layer2 / layer3 forward on the image kernel (3 + 5), every conv2 gradient of
@@ -143,7 +146,7 @@ def test_resnet50_trunk_224_production_dispatch(hip_lib, monkeypatch, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16], ids=["fp16"])
-def test_fault_in_image_kernel_bn_backward_is_caught(hip_lib, monkeypatch, dtype):
+def test_fault_in_image_kernel_bn_backward_is_caught(hip_lib, reproducible_sums, monkeypatch, dtype):
     """falsifiability at this geometry: the k2 coefficient of bn2's backward (dc = k1 g + k2 c + k3), as the image-stationary
     gradient kernel forms it in its staging, multiplied by 1.5 in every launch -- the whole-trunk gate must turn red.
     (fp16: the reference-under-autocast yardstick is 8 x tighter than bf16's, where one wrong coefficient of a residual

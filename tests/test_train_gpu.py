@@ -209,3 +209,28 @@ def test_three_streams_equal_one_stream(hip_lib, reproducible_sums):
                 if v.dtype.is_floating_point and v.numel() > 1 and float(v.norm()) > 0)
     print(f"three streams vs one: worst weight rel-L2 {worst:.2e}")
     assert worst <= 1e-5
+
+
+def test_example_epoch_loop_saves_and_resumes(hip_lib, tmp_path):
+    """examples/pretrain_loop.py: the reference's epoch loop (tools/ssl_train.py:338-392: epochs, save_freq, --resume) around
+    the fused step -- two epochs of two steps, checkpoints in the reference's layout and file names, then a resumed run that
+    starts at the saved epoch with the reference's eps = 0.1 quirk (:325-326)"""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pretrain_loop", os.path.join(root, "examples", "pretrain_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    common = ["--arch", "resnet18", "--batch", "4", "--size", "64", "--steps-per-epoch", "2", "--dtype", "bf16",
+              "--log-dir", str(tmp_path)]
+    step = mod.main(common + ["--epochs", "2"])
+    assert step.t == 4
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["checkpoint_0000.pth.tar", "checkpoint_0001.pth.tar"], names
+    ck = torch.load(tmp_path / "checkpoint_0000.pth.tar", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "arch", "state_dict", "optimizer", "scaler"} and ck["epoch"] == 1
+    assert all(k.startswith("module.") for k in ck["state_dict"]) and len(ck["state_dict"]) == 528
+    assert len(ck["optimizer"]["param_groups"]) == 3 and "scale" in ck["scaler"]
+    step2 = mod.main(common + ["--epochs", "2", "--resume", str(tmp_path / "checkpoint_0000.pth.tar")])
+    assert step2.t == 4 and step2.eps == [0.1, 0.1, 0.1]   # one more epoch of two steps on top of the two resumed ones
