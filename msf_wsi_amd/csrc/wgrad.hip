@@ -21,7 +21,7 @@
 #define MSFWSI_WGRAD_BIG_WAVES 16  // waves of the 256 x 256 tile (8: 128 x 64 per wave, 16: 64 x 64)
 #endif
 #ifndef MSFWSI_WGRAD_BIG_STAGES
-#define MSFWSI_WGRAD_BIG_STAGES 3  // LDS stages of the 256 x 256 tile (32 KiB each)
+#define MSFWSI_WGRAD_BIG_STAGES 4  // LDS stages of the 256 x 256 tile (32 KiB each); 4: the DMA requests of slab kt+3 are issued BEFORE the barrier of iteration kt (see the pixel loop)
 #endif
 #ifndef MSFWSI_WGRAD_SMALL_STAGES
 #define MSFWSI_WGRAD_SMALL_STAGES 3  // LDS stages of the 4-wave tiles (A/B: make EXTRA=-DMSFWSI_WGRAD_SMALL_STAGES=2)
@@ -390,7 +390,14 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
         constexpr int DMA_PER_SLAB = A_IT + B_IT;
         static_assert(DMA_PER_SLAB >= 2 && DMA_PER_SLAB <= 4, "vmcnt literal table");
         constexpr int NST = Cfg::NST;
-        static_assert(NST == 3, "three stages: slabs kt+1, kt+2 landed / in flight while kt is read, kt+3 requested into kt's");
+        static_assert(NST == 3 || NST == 4, "stages");
+        // NST == 4 (the 256 x 256 tile, one workgroup per CU: 128 KiB): the requests of slab kt+3 go into the stage of slab
+        // kt-1, which every wave left before the PREVIOUS barrier -- so they are issued right after the MFMAs of (kt, group 0)
+        // and BEFORE this iteration's wait + barrier.  A wave stalls in the issue of an LDS-DMA piece (60-185 cycles per piece,
+        // MI355X_MICROARCH.md); placed behind the barrier, all four waves of a SIMD stood in that stall together with an
+        // empty matrix pipe; placed here the stall runs under the wave's own four queued MFMAs (128 cycles of pipe time,
+        // 512 per SIMD) and under the barrier wait itself.  Three slabs are in flight instead of two.
+        constexpr bool EARLY = NST == 4;
         static_assert(BKM / (2 * VEC) == 2, "two k-groups per slab: two register sets");
         int fa[TI], fb[TJ];
         if constexpr (sizeof(T) == 2) {
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
         };
         // prologue: three slabs requested, slab 0 landed and visible, its group 0 on the way to registers
 #pragma unroll
-        for (int i = 0; i < NST; ++i)
+        for (int i = 0; i < 3; ++i)
             if (i < nk) fetch(mbeg + i * BKM, i);
         if (nk >= 3) wait_vmcnt<2 * DMA_PER_SLAB>();
         else if (nk == 2) wait_vmcnt<DMA_PER_SLAB>();
@@ -444,27 +451,42 @@ __global__ __launch_bounds__(wgrad_threads(BI, BJ)) void wgrad_kernel(const Wgra
         frag_t a0[TI], b0[TJ], a1[TI], b1[TJ];
         read_group(0, 0, a0, b0);
         int st_c = 0;
+        int st_f = 3;  // EARLY: the stage the next requests go to (slab kt+3 -> stage (kt+3) mod 4)
         // (the last slab is peeled off: ONE straight-line body, so that hipcc keeps one set of accumulator registers -- with
         //  the final slab as a branch of the loop body it renamed the accumulators per branch and spilled 96 registers)
         for (int kt = 0; kt + 1 < nk; ++kt) {
             read_group(st_c, 1, a1, b1);
             mma_group(a0, b0);
             const int st_n = st_c == NST - 1 ? 0 : st_c + 1;
-            // my DMA pieces of slab kt+1 have landed (slab kt+2, if any, stays in flight); my reads of slab kt are done
-            if (kt + 2 < nk) wait_vmcnt<DMA_PER_SLAB>();
-            else wait_vmcnt<0>();
+            if constexpr (EARLY) {
+                if (kt + 3 < nk) fetch(mbeg + (kt + 3) * BKM, st_f);
+                st_f = st_f == NST - 1 ? 0 : st_f + 1;
+                // my DMA pieces of slab kt+1 have landed (slabs kt+2, kt+3, if any, stay in flight); my reads of slab kt are done
+                if (kt + 3 < nk) wait_vmcnt<2 * DMA_PER_SLAB>();
+                else if (kt + 2 < nk) wait_vmcnt<DMA_PER_SLAB>();
+                else wait_vmcnt<0>();
+            } else {
+                // my DMA pieces of slab kt+1 have landed (slab kt+2, if any, stays in flight); my reads of slab kt are done
+                if (kt + 2 < nk) wait_vmcnt<DMA_PER_SLAB>();
+                else wait_vmcnt<0>();
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if constexpr (EARLY) {
+                read_group(st_n, 0, a0, b0);
+                mma_group(a1, b1);
+            } else {
 #if MSFWSI_FETCH_FIRST
-            if (kt + 3 < nk) fetch(mbeg + (kt + 3) * BKM, st_c);
-            read_group(st_n, 0, a0, b0);
-            mma_group(a1, b1);
+                if (kt + 3 < nk) fetch(mbeg + (kt + 3) * BKM, st_c);
+                read_group(st_n, 0, a0, b0);
+                mma_group(a1, b1);
 #else
-            read_group(st_n, 0, a0, b0);
-            mma_group(a1, b1);
-            if (kt + 3 < nk) fetch(mbeg + (kt + 3) * BKM, st_c);
+                read_group(st_n, 0, a0, b0);
+                mma_group(a1, b1);
+                if (kt + 3 < nk) fetch(mbeg + (kt + 3) * BKM, st_c);
 #endif
+            }
             st_c = st_n;
         }
         read_group(st_c, 1, a1, b1);
