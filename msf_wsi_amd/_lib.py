@@ -207,14 +207,15 @@ def load() -> C.CDLL:
             raise MsfwsiHipError(f"symbol {name} missing from {LIB_PATH}") from e
         fn.argtypes = []
         fn.restype = C.c_char_p
-    for key, env in ((0, "MSFWSI_BIG_TILE_MIN_BLOCKS"), (1, "MSFWSI_FAST_DMA"), (2, "MSFWSI_WGRAD_LIN"),
-                     (4, "MSFWSI_SMALL_GRID_BLOCKS"), (5, "MSFWSI_S2_PARITY"), (6, "MSFWSI_WGRAD_BIG"),
-                     (9, "MSFWSI_C3_STATIONARY"),
-                     (10, "MSFWSI_WGRAD_OS"),
-                     (12, "MSFWSI_STEM_WS"), (15, "MSFWSI_WGRAD_MAX_SPLITS"), (17, "MSFWSI_PANEL_HAND"),
-                     (18, "MSFWSI_PANEL_WIDE")):  # A/B switches (see msfwsi_set_tuning)
-        if env in os.environ:
-            lib.msfwsi_set_tuning(key, int(os.environ[env]))
+    # A/B of the C side's dispatch switches (include/msfwsi_hip.h, msfwsi_set_tuning): ONE variable,
+    # MSFWSI_TUNING="key=value,key=value" (e.g. "15=1" = one pixel split per weight-gradient tile, "6=0" = no 256 x 256 tile);
+    # round 5 had twelve variables, one per key
+    spec = os.environ.get("MSFWSI_TUNING", "").strip()
+    if spec:
+        for item in spec.split(","):
+            k, sep, v = item.strip().partition("=")
+            if not sep or lib.msfwsi_set_tuning(int(k), int(v)) != 0:
+                raise MsfwsiHipError(f"MSFWSI_TUNING: bad entry {item!r} (expected key=value with a key of msfwsi_set_tuning)")
     _lib = lib
     return lib
 

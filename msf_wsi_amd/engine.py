@@ -294,6 +294,27 @@ class _ViewPair:
 
 # ------------------------------------------------------------------------------------------------
 class Engine:
+    # Dispatch / schedule options: plain attributes with the measured-best defaults (each A/B is recorded in DESIGN.md and
+    # profiles/).  They are NOT environment switches any more (round 5 had 57 MSFWSI_* variables); code and tests set the
+    # attribute, and A/B scripts pass ONE variable, MSFWSI_ENGINE="name=value,name=value", checked against this table.
+    # tests/test_options_gpu.py flips every one of them on a whole training step.
+    OPTIONS = ("halo3x3", "fuse_pro3x3", "fold_bn3", "fuse_gate", "fold_bn3_fwd", "gate_bits", "fuse_two_source",
+               "panel_fwd", "panel_dgrad", "heads_on_streams", "img3x3", "img3x3_layer1", "img3x3_s2", "gap_stride_fused",
+               "fuse_a2_wgrad", "fuse_a2_wgrad_max_c", "img3x3_chunk_bytes", "img3x3_min_fill", "panel_gram", "panel_fwd_min_k", "stem_run",
+               "stem_s2d", "stem_fuse_bnbwd", "pair_head_wgrad", "pair_head_fwd", "bucket_inter", "store_head_wgrad", "fold_ds",
+               "fold_ds_fwd", "fold_ds_strided", "lores_resid", "ctx_stream", "coalesce_views")
+
+    def _apply_env_options(self):
+        spec = os.environ.get("MSFWSI_ENGINE", "").strip()
+        if not spec:
+            return
+        for item in spec.split(","):
+            name, sep, val = item.strip().partition("=")
+            if not sep or name not in self.OPTIONS:
+                raise _lib.MsfwsiHipError(f"MSFWSI_ENGINE: unknown option {item!r} (options: {', '.join(self.OPTIONS)})")
+            cur = getattr(self, name)
+            setattr(self, name, (val not in ("0", "false", "False")) if isinstance(cur, bool) else type(cur)(float(val)))
+
     def __init__(self, process_group=None, sync_bn: Optional[bool] = None):
         self.weights = WeightStore()
         self.group = process_group
@@ -302,70 +323,65 @@ class Engine:
         self._drop_c3 = False
         self._pair_bwd = True
         self.recompute = os.environ.get("MSFWSI_RECOMPUTE", "auto")  # off | t1 | targets | auto
-        self.materialize_3x3 = os.environ.get("MSFWSI_MATERIALIZE_3X3", "1") != "0"
-        self.materialize_wgrad = os.environ.get("MSFWSI_MATERIALIZE_WGRAD", "1") != "0"
-        self.materialize_1x1 = os.environ.get("MSFWSI_MATERIALIZE_1X1", "1") != "0"
         # halo-in-LDS 3x3 kernel: since the pure-DMA gather kernel lost its per-slab address arithmetic it only wins
         # for the 64-channel input gradient (494 vs 450 TFLOP/s); wider layers and the forward use the gather kernel
-        self.halo3x3 = os.environ.get("MSFWSI_HALO3X3", "1") != "0"
-        self.halo3x3_fwd = os.environ.get("MSFWSI_HALO3X3_FWD", "0") != "0"
-        self.fuse_pro3x3 = os.environ.get("MSFWSI_FUSE_PRO3X3", "1") != "0"  # 64->64 3x3: BatchNorm+ReLU in the conv's staging
+        self.halo3x3 = True
+        self.fuse_pro3x3 = True  # 64->64 3x3: BatchNorm+ReLU in the conv's staging
         # Bottleneck conv3+bn3 backward folded into weights (no c3 in backward at all); 0 = keep / re-make c3
-        self.fold_bn3 = os.environ.get("MSFWSI_FOLD_BN3", "1") != "0"
+        self.fold_bn3 = True
         # ... and the closing ReLU gate of a folded block applied by the producer of its output gradient
-        self.fuse_gate = os.environ.get("MSFWSI_FUSE_GATE", "1") != "0"
+        self.fuse_gate = True
         # forward of conv3 -> bn3 -> += identity -> relu in ONE conv launch: bn3's batch statistics come from the
         # Gram matrix of conv3's operand (sum c3 = W sum(a2), sum c3^2 = diag(W (a2^T a2) W^T)), c3 never exists
-        self.fold_bn3_fwd = os.environ.get("MSFWSI_FOLD_BN3_FWD", "1") != "0"
+        self.fold_bn3_fwd = True
         # ... which also emits the block's closing ReLU gate as one byte per 16-byte chunk for the backward pass
-        self.gate_bits = os.environ.get("MSFWSI_GATE_BITS", "1") != "0"
-        self.fuse_two_source = os.environ.get("MSFWSI_TWO_SOURCE", "1") != "0"
+        self.gate_bits = True
+        self.fuse_two_source = True
         # activation-stationary ("panel") kernels for the short-k 1x1 convs of a Bottleneck (csrc/panel.hip): conv3's fused
         # tail reads conv2's RAW output (bn2 + ReLU applied while the panel is staged), conv1's input gradient forms bn1's
         # backward dc1 = k1*g + k2*c1 + k3 in its staging and writes it back once for the weight gradient
         self.multirank_streams = os.environ.get("MSFWSI_MULTIRANK_STREAMS", "1") != "0"
-        self.panel_fwd = os.environ.get("MSFWSI_PANEL_FWD", "1") != "0"
-        self.panel_dgrad = os.environ.get("MSFWSI_PANEL_DGRAD", "1") != "0"
+        self.panel_fwd = True
+        self.panel_dgrad = True
         # conv2 of layer2 / layer3 on the image-stationary kernels (csrc/img3x3.hip): bn1 + ReLU in the forward staging, bn2's
         # backward in the gradient staging, a1 for the weight gradient as a by-product of the gradient's gate
         # the three head groups on the three streams of the multi-stream schedule (they are independent between the encoder
         # passes and the loss, and again between the loss and the encoder backward): their ~400 launches are too small to
         # fill the chip one after the other
-        self.heads_on_streams = os.environ.get("MSFWSI_HEAD_STREAMS", "1") != "0"
-        self.img3x3 = os.environ.get("MSFWSI_IMG3X3", "1") != "0"
+        self.heads_on_streams = True
+        self.img3x3 = True
         # layer1 (56x56x64): the weights-stationary kernel keeps the forward and the plain gradient (1.32 / 1.42 ms against 1.38
         # / 1.58 ms per N = 4096 launch); the image kernel takes only the gradient WITH bn2's backward folded in (2.04 against
         # 1.0 + 1.42 ms of msfwsi_bn_bwd_apply + gradient, profiles/r05_img3_kbench_c64.txt)
-        self.img3x3_layer1 = os.environ.get("MSFWSI_IMG3X3_L1", "1") != "0"
+        self.img3x3_layer1 = True
         # the strided conv2 of layer2.0 / layer3.0: input gradient in ONE launch (msfwsi_img3x3_s2_dgrad) instead of four
         # parity launches, with bn2's backward and the a1 by-product as above
-        self.img3x3_s2 = os.environ.get("MSFWSI_IMG3X3_S2", "1") != "0"
-        self.gap_stride_fused = os.environ.get("MSFWSI_GAP_STRIDE", "1") != "0"  # gap_fwd + pixel_stride of a stage output in one pass
+        self.img3x3_s2 = True
+        self.gap_stride_fused = True  # gap_fwd + pixel_stride of a stage output in one pass
         # the folded tail's backward: a2 = relu(bn2(c2)) as a by-product of the M = g^T a2 launch (msfwsi_conv_wgrad_act)
-        self.fuse_a2_wgrad = os.environ.get("MSFWSI_FUSE_A2_WGRAD", "1") != "0"
-        self.fuse_a2_wgrad_max_c = int(os.environ.get("MSFWSI_FUSE_A2_WGRAD_MAX_C", "64"))
-        self.img3x3_chunk_bytes = int(os.environ.get("MSFWSI_IMG3X3_CHUNK_BYTES", str(1 << 30)))  # see _img3_bwd_chunks
-        self.img3x3_min_fill = float(os.environ.get("MSFWSI_IMG3X3_MIN_FILL", "1.0"))  # rounds of workgroups, see _img3_fills
+        self.fuse_a2_wgrad = True
+        self.fuse_a2_wgrad_max_c = 64
+        self.img3x3_chunk_bytes = 1 << 30  # see _img3_bwd_chunks
+        self.img3x3_min_fill = 1.0  # rounds of workgroups, see _img3_fills
         self._ncu: Dict[object, int] = {}
-        self.panel_gram = os.environ.get("MSFWSI_PANEL_GRAM", "1") != "0"  # bn_act_sum + gram as ONE pass over the raw conv output
-        self.panel_fwd_min_k = int(os.environ.get("MSFWSI_PANEL_FWD_MIN_K", "128"))  # 56x56 / 64 channels: the gather kernel is at the HBM roof
-        self.stem_run = os.environ.get("MSFWSI_STEM_RUN", "1") != "0"
-        self.stem_s2d = os.environ.get("MSFWSI_STEM_S2D", "1") != "0"  # ... in space-to-depth form (4x4 / stride 1)
-        self.stem_fuse_bnbwd = os.environ.get("MSFWSI_STEM_FUSE_BNBWD", "1") != "0"  # bn1 backward inside the stem's dW
-        self.pair_head_wgrad = os.environ.get("MSFWSI_PAIR_HEAD_WGRAD", "1") != "0"  # one dW launch for both views
-        self.pair_head_fwd = os.environ.get("MSFWSI_PAIR_HEAD_FWD", "1") != "0"  # ... and one forward GEMM per layer
+        self.panel_gram = True  # bn_act_sum + gram as ONE pass over the raw conv output
+        self.panel_fwd_min_k = 128  # 56x56 / 64 channels: the gather kernel is at the HBM roof
+        self.stem_run = True
+        self.stem_s2d = True  # ... in space-to-depth form (4x4 / stride 1)
+        self.stem_fuse_bnbwd = True  # bn1 backward inside the stem's dW
+        self.pair_head_wgrad = True  # one dW launch for both views
+        self.pair_head_fwd = True  # ... and one forward GEMM per layer
         # gradient exchange of the fuser heads in per-scale buckets, each launched when its weight gradients are complete
-        self.bucket_inter = os.environ.get("MSFWSI_BUCKET_INTER", "1") != "0"
+        self.bucket_inter = True
         # the heads' big Linear weight gradients (one launch per step for both views) stored instead of accumulated
-        self.store_head_wgrad = os.environ.get("MSFWSI_STORE_HEAD_WGRAD", "1") != "0"
+        self.store_head_wgrad = True
         # stem backward as sums pass + apply pass (no gated gradient in memory): measured 2 ms SLOWER than
         # stem_pool_bwd + bn_bwd_apply (the pool-backward window logic is VALU-bound, not byte-bound): off
-        self.fold_ds = os.environ.get("MSFWSI_FOLD_DS", "1") != "0"  # stride-1 downsample branch folded like bn3
-        self.fold_ds_fwd = os.environ.get("MSFWSI_FOLD_DS_FWD", "1") != "0"  # ... and its forward: one two-source GEMM
-        self.fold_ds_strided = os.environ.get("MSFWSI_FOLD_DS_STRIDED", "1") != "0"  # ... also for the stride-2 branches
+        self.fold_ds = True  # stride-1 downsample branch folded like bn3
+        self.fold_ds_fwd = True  # ... and its forward: one two-source GEMM
+        self.fold_ds_strided = True  # ... also for the stride-2 branches
         # their input gradient stays low-resolution: conv1's dgrad epilogue adds it on the strided sub-grid
-        self.lores_resid = os.environ.get("MSFWSI_LORES_RESID", "1") != "0"
-        self.mat_min_rows = int(os.environ.get("MSFWSI_MAT_MIN_ROWS", "1"))  # rows from which 1x1 operands are materialised
+        self.lores_resid = True
         self._stem_cache: Dict[tuple, tuple] = {}
         self._gate_vecs: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
         self._plan_cache: Dict[tuple, Tuple[frozenset, bool]] = {}
@@ -399,16 +415,16 @@ class Engine:
         # ... and with two streams active, the two CONTEXT passes (1/17 of the images, launches too small to fill the chip:
         # 45 ms of a 545 ms step for 6 % of the work) run on a THIRD stream beside the target passes, forward and backward
         # (different encoder, different parameters: no ordering between them and the target passes).  Needs the
-        # memory calibration of an earlier step of the same shape (`_calib`).  MSFWSI_CTX_STREAM=0 turns it off.
-        self.ctx_stream = os.environ.get("MSFWSI_CTX_STREAM", "1") != "0"
+        # memory calibration of an earlier step of the same shape (`_calib`).  `ctx_stream = False` (MSFWSI_ENGINE=ctx_stream=0) turns it off.
+        self.ctx_stream = True
         self._calib: Dict[tuple, Tuple[float, float]] = {}
         self._side: Dict[str, torch.cuda.Stream] = {}
         self._stream_groups: Dict[int, object] = {}  # side stream handle -> its own communicator (see _comm)
         self._bn_order: Optional[Tuple[str, dict]] = None
         # Cross-replica runs: the two views of an encoder in LOCKSTEP on two host threads, one SyncBatchNorm message per
         # BatchNorm and direction for both views (_ViewPair).  On whenever statistics are exchanged (more than one rank,
-        # or MSFWSI_FORCE_SYNC) and the dual-stream schedule is off; MSFWSI_COALESCE_VIEWS=0 restores one pass after the other
-        self.coalesce_views = os.environ.get("MSFWSI_COALESCE_VIEWS", "1") != "0"
+        # or MSFWSI_FORCE_SYNC) and the dual-stream schedule is off; `coalesce_views = False` restores one pass after the other
+        self.coalesce_views = True
         self._tls = threading.local()   # .pair = (_ViewPair, view index) inside a lockstep pass
         # bookkeeping a trainer / bench.py reports: the collectives this engine issued since `reset_counters`, and
         # the recompute plan of the last forward ("keep-all", "recompute:t1", "recompute:t0,t1" [+ ",drop-c3"])
@@ -416,6 +432,7 @@ class Engine:
         self.collectives_last_step = 0
         self.last_plan = "keep-all"
         self.last_shape: Optional[tuple] = None
+        self._apply_env_options()
 
     def reset_counters(self):
         self.collectives = 0
@@ -786,7 +803,7 @@ class Engine:
             return u
         if fuse_pro:
             pass  # the weights-stationary 3x3 kernel applies BatchNorm + ReLU on the way into LDS: nothing to materialise
-        elif pro is not None and self.materialize_3x3 and (R * S > 1 or (self.materialize_1x1 and N * H * W >= self.mat_min_rows)):
+        elif pro is not None:
             # a 3x3 gather reads every input element 9 times: normalising it once into a transient tensor and
             # letting the conv stage by pure LDS-DMA is cheaper than re-applying BatchNorm+ReLU per tap
             xin = torch.empty_like(x)
@@ -797,7 +814,7 @@ class Engine:
         elif fuse_pro:
             kn.conv3x3_fwd(d, xin, w, c, stats=stats, pro=pro)
         elif (pro is None and bias is None and not pad_c
-              and (kn.conv3x3_stationary(d) if not self.halo3x3_fwd else kn.conv3x3_supported(d))):
+              and kn.conv3x3_stationary(d)):
             kn.conv3x3_fwd(d, xin, w, c, stats=stats)  # input patch staged once per channel slab, 9 taps reuse it
         else:
             kn.conv_fwd(d, xin, w, c, pro=pro, bias=bias.data if bias is not None else None, stats=epi_stats)
@@ -1018,7 +1035,7 @@ class Engine:
             x, pro = x_mat, None
         elif pro is not None and self.fuse_pro3x3 and kn.conv_wgrad_stationary(u.desc) and not u.s2d:
             pass  # the output-stationary kernel applies BatchNorm + ReLU in its staging: nothing to materialise
-        elif pro is not None and self.materialize_wgrad and u.desc.N * u.desc.H * u.desc.W >= 8192:
+        elif pro is not None and u.desc.N * u.desc.H * u.desc.W >= 8192:
             # normalise the operand once into a transient tensor: the weight-gradient kernel then stages both
             # tiles by LDS-DMA (3-stage pipeline) instead of register-staging with the BatchNorm prologue
             x = torch.empty_like(u.x)
@@ -1512,7 +1529,7 @@ class Engine:
             last.c = torch.empty(d.N, d.P, d.Q, d.K, dtype=dtype, device=rec.y_out.device)
             pro = (last.x_pro.scale, last.x_pro.shift) if last.x_pro is not None else None
             xin = last.x
-            if pro is not None and self.materialize_3x3 and self.materialize_1x1:
+            if pro is not None:
                 # the same normalised operand the forward used; shared with this conv's weight gradient below
                 last_xmat = self._normalised_operand(last)
                 xin, pro = last_xmat, None

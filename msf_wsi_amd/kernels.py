@@ -176,8 +176,15 @@ _TIMER_LOCK = threading.Lock()
 
 
 _TCODE = {4: "f", 2: "DF16b"}  # Itanium codes of float / __bf16 (fp16 "DF16_" is set by the caller's dtype)
-BIG_TILE_MIN_BLOCKS = int(os.environ.get("MSFWSI_BIG_TILE_MIN_BLOCKS", "1024"))
-SMALL_GRID_BLOCKS = int(os.environ.get("MSFWSI_SMALL_GRID_BLOCKS", "100"))
+
+
+def _tuning(key: int) -> int:
+    """the library's current value of a dispatch switch (msfwsi_get_tuning): _symbol mirrors the C side's dispatch from the
+    SAME values, whoever set them (MSFWSI_TUNING at load time, a test's helpers.tuned)"""
+    v = C.c_long()
+    _lib.check(_lib.load().msfwsi_get_tuning(int(key), C.byref(v)), "msfwsi_get_tuning")
+    return int(v.value)
+
 
 
 def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, epi: int = 0, two: bool = False) -> str:
@@ -188,22 +195,22 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
     bk = 16 if es == 4 else 32
     if kind == "conv_wgrad":
         if (es == 2 and d.C == 16 and d.K == 64 and (d.R, d.S, d.stride, d.pad) == (4, 4, 1, 2) and d.P == d.H
-                and d.N * (d.H + 2) * (d.W + 2) >= 32 * 512 * 256 and os.environ.get("MSFWSI_STEM_WS", "1") != "0"):
+                and d.N * (d.H + 2) * (d.W + 2) >= 32 * 512 * 256 and _tuning(12) != 0):
             return f"stem_wgrad_os_kernelI{tcode}Lb0EE"
         if (es == 2 and d.C == 64 and d.K == 64 and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1
-                and d.N * (d.H + 1) * (d.W + 1) >= 32 * 256 * 256 and os.environ.get("MSFWSI_WGRAD_OS", "1") != "0"):
+                and d.N * (d.H + 1) * (d.W + 1) >= 32 * 256 * 256 and _tuning(10) != 0):
             return f"wgrad_os_kernelI{tcode}E"
         bi = 64 if d.K <= 64 else 128
         bj = 64 if d.R * d.S * d.C <= 64 else 128
         if (es == 2 and not pro and d.K % 256 == 0 and (d.R * d.S * d.C) % 256 == 0
-                and os.environ.get("MSFWSI_WGRAD_BIG", "1") != "0"):
+                and _tuning(6) != 0):
             bi = bj = 256  # the 16-wave tile of the deep layers (msfwsi_conv_wgrad)
-        lin = (not pro and os.environ.get("MSFWSI_WGRAD_LIN", "1") != "0" and d.stride == 1 and d.P == d.H
+        lin = (not pro and _tuning(2) != 0 and d.stride == 1 and d.P == d.H
                and d.Q == d.W and d.pad <= 1 and d.R <= 3 and d.S <= 3 and d.R == 2 * d.pad + 1 and d.S == 2 * d.pad + 1)
         return f"wgrad_kernelI{tcode}Li{bi}ELi{bj}ELb{int(pro)}ELb{int(lin)}E"
     dgrad = kind == "conv_dgrad"
     if halo:
-        if es == 2 and d.C == 64 and d.K == 64 and os.environ.get("MSFWSI_C3_STATIONARY", "1") != "0":
+        if es == 2 and d.C == 64 and d.K == 64 and _tuning(9) != 0:
             return f"conv3x3_ws_kernelI{tcode}Lb{int(dgrad)}E"
         bn = 64 if (d.C if dgrad else d.K) <= 64 else 128
         return f"conv3x3_kernelI{tcode}Li{bn}ELb{int(dgrad)}E"
@@ -211,14 +218,14 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
     nout, csrc = (d.C, d.K) if dgrad else (d.K, d.C)
     if nout <= 64:
         tile = (128, 64, 2, 2)
-    elif not pro and es == 2 and ((M + 255) // 256) * ((nout + 127) // 128) >= BIG_TILE_MIN_BLOCKS:
+    elif not pro and es == 2 and ((M + 255) // 256) * ((nout + 127) // 128) >= _tuning(0):
         tile = (256, 128, 4, 2)
-    elif not pro and ((M + 127) // 128) * ((nout + 127) // 128) < SMALL_GRID_BLOCKS:
+    elif not pro and ((M + 127) // 128) * ((nout + 127) // 128) < _tuning(4):
         tile = (128, 64, 2, 2)
     else:
         tile = (128, 128, 2, 2)
     t = "Li%dELi%dELi%dELi%dE" % tile
-    if not pro and os.environ.get("MSFWSI_FAST_DMA", "1") != "0" and csrc % bk == 0 and d.R * d.S <= 32:
+    if not pro and _tuning(1) != 0 and csrc % bk == 0 and d.R * d.S <= 32:
         return f"igemm_dma_kernelI{tcode}{t}Lb{int(dgrad)}ELi{epi}ELb{int(two)}ELb0E"
     return f"igemm_kernelI{tcode}{t}Lb{int(dgrad)}ELb{int(pro)}E"
 
@@ -354,7 +361,7 @@ def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad, P: int = 0, Q: int = 0)
 
     tc = "DF16_" if x.dtype == torch.float16 else _TCODE[x.element_size()]
     ws = (x.element_size() == 2 and CP == 16 and K == 64 and (R, S, stride, pad) == (4, 4, 1, 2) and d.P == H and d.Q == W
-          and W <= 128 and os.environ.get("MSFWSI_STEM_WS", "1") != "0")  # mirrors msfwsi_stem_ws_fwd (csrc/stem.hip)
+          and W <= 128 and _tuning(12) != 0)  # mirrors msfwsi_stem_ws_fwd (csrc/stem.hip)
     _timed("conv_fwd", d, x.element_size(), run, dtype=x.dtype,
            symbol_override=f"stem_ws_kernelI{tc}E" if ws else f"igemm_dma_kernelI{tc}Li128ELi64ELi2ELi2ELb0ELi0ELb0ELb1E")
     return rc[0] == 0

@@ -30,7 +30,7 @@ def pytest_configure(config):
 # (tests/oracle_jobs.py) compute those while the GPU runs everything before them.
 # ----------------------------------------------------------------------------------------------------------------
 FILE_ORDER = ["test_parity_gpu", "test_train_gpu", "test_dist_gpu", "test_dropin_gpu", "test_fixes_gpu",
-              "test_lowp_parity_gpu", "test_lowp_default_gpu", "test_blocks_lowp_gpu", "test_encoder_gpu", "test_headline_geometry_gpu",
+              "test_lowp_parity_gpu", "test_lowp_default_gpu", "test_blocks_lowp_gpu", "test_encoder_gpu", "test_headline_geometry_gpu", "test_options_gpu",
               "test_hooknet_gpu", "test_tiler",
               "test_augment", "test_metrics", "test_kernels_gpu", "test_production_gpu"]
 # (substring of the node id, rank inside the first group): tests that need a long-running oracle job

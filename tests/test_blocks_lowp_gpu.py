@@ -221,7 +221,7 @@ def test_deep_blocks_on_the_image_stationary_kernels(hip_lib, monkeypatch, arch,
         assert (k.get("act_out") is None and k.get("bnbwd") is not None) if d.C == 64 else k.get("act_out") is not None
         return dgrad(d, *a, **k)
 
-    monkeypatch.setenv("MSFWSI_IMG3X3_MIN_FILL", "0")  # three images: far below the fill the engine asks for by default
+    monkeypatch.setenv("MSFWSI_ENGINE", "img3x3_min_fill=0")  # three images: far below the fill the engine asks for by default
     monkeypatch.setattr(kn, "img3x3_fwd", count_fwd)
     monkeypatch.setattr(kn, "img3x3_dgrad", count_dgrad)
     monkeypatch.setattr(kn, "img3x3_s2_dgrad", count_s2)
@@ -255,8 +255,7 @@ def test_image_kernel_backward_in_image_chunks(hip_lib, monkeypatch):
             return fn(d, *a, **k)
         return wrapped
 
-    monkeypatch.setenv("MSFWSI_IMG3X3_MIN_FILL", "0")
-    monkeypatch.setenv("MSFWSI_IMG3X3_CHUNK_BYTES", "1")
+    monkeypatch.setenv("MSFWSI_ENGINE", "img3x3_min_fill=0,img3x3_chunk_bytes=1")
     monkeypatch.setattr(kn, "img3x3_dgrad", count("s1", dgrad))
     monkeypatch.setattr(kn, "img3x3_s2_dgrad", count("s2", s2dgrad))
     only = lambda name: name in ("layer2.0", "layer2.1", "layer3.0")

@@ -341,7 +341,7 @@ def _shard_opt_worker(rank, world, port, ret, dtype):
     """the same two steps with the all-reduce exchange and with the sharded optimizer, on `world` ranks sharing the card"""
     import os
 
-    os.environ["MSFWSI_WGRAD_MAX_SPLITS"] = "1"  # one workgroup per weight-gradient tile: a rank's two runs repeat bit for bit
+    os.environ["MSFWSI_TUNING"] = "15=1"  # one workgroup per weight-gradient tile: a rank's two runs repeat bit for bit
     from msf_wsi_amd.dist import shard_range
     from msf_wsi_amd.train import PretrainStep
 

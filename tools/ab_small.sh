@@ -5,9 +5,9 @@ for shape in "--arch resnet50 --batch 16" "--arch resnet18 --batch 8" "--arch re
   echo "== $shape"
   for round in 1 2; do
     run "X=1" "$shape"
-    run "MSFWSI_IMG3X3=0" "$shape"
-    run "MSFWSI_IMG3X3_MIN_FILL=0" "$shape"
-    run "MSFWSI_IMG3X3_MIN_FILL=2" "$shape"
-    run "MSFWSI_HEAD_STREAMS=0" "$shape"
+    run "MSFWSI_ENGINE=img3x3=0" "$shape"
+    run "MSFWSI_ENGINE=img3x3_min_fill=0" "$shape"
+    run "MSFWSI_ENGINE=img3x3_min_fill=2" "$shape"
+    run "MSFWSI_ENGINE=heads_on_streams=0" "$shape"
   done
 done

@@ -31,7 +31,7 @@ def trainer_mode(arch, B, size, dtype, reps, mode):
     """the FUSED trainer: `reps` times a freshly built, identically seeded model + PretrainStep run 4 steps (the first on
     one stream, the others on three, the inter_ group's Adam pass under the next step's encoder passes), free blocks
     poisoned between steps; the 4 losses and every updated weight are compared BITWISE with the first repetition.  Run it
-    with MSFWSI_WGRAD_MAX_SPLITS=1 (the reproducible mode): then any difference is a race between streams -- a missing
+    with MSFWSI_TUNING=15=1 (the reproducible mode): then any difference is a race between streams -- a missing
     event, a block handed to another stream too early -- not the order of atomic additions."""
     from msf_wsi_amd.train import PretrainStep
     from oracle import msfwsi_oracle as orc
@@ -66,7 +66,7 @@ def trainer_mode(arch, B, size, dtype, reps, mode):
                 d = float((cur[k].double() - first[k].double()).norm() / (first[k].double().norm() + 1e-30))
                 print(f"  repetition {r}: {len(diff)}/{len(cur)} tensors differ from repetition 0; first {k}: rel {d:.2e}", flush=True)
         del ts, model
-    print(f"[race_check trainer {arch} B={B} size={size} {mode} splits-cap={os.environ.get('MSFWSI_WGRAD_MAX_SPLITS', 'none')}] "
+    print(f"[race_check trainer {arch} B={B} size={size} {mode} splits-cap={os.environ.get('MSFWSI_TUNING', 'none')}] "
           f"{reps} repetitions of 4 steps: {bad} not bitwise equal to the first", flush=True)
     return bad
 

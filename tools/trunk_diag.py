@@ -1,6 +1,6 @@
 """GPU box: per-tensor distance of the product's fp32 ResNet-50 trunk gradients from the fp64 oracle on the
 well-conditioned trunk case, in backward order -- where does the error enter (a jump = a gate flip; a ramp = arithmetic)?
-    [MSFWSI_FOLD_BN3=0 MSFWSI_FOLD_BN3_FWD=0 ...] python tools/trunk_diag.py"""
+    [MSFWSI_ENGINE=fold_bn3=0,fold_bn3_fwd=0,...] python tools/trunk_diag.py"""
 import os
 import sys
 
