@@ -33,6 +33,9 @@
 #define MSFWSI_ABLATE 0  // diagnostic builds (tools/build_variant.sh): 1 = pure-DMA kernel without its k loop (epilogue only),
 #endif                   // 2 = without the epilogue's global loads / stores (k loop + LDS transposition only), 3 = 3x3 launches
                          // without the activation DMA pieces of the filter taps s = 1, 2.  WRONG RESULTS.
+#ifndef MSFWSI_IGEMM_PIPE
+#define MSFWSI_IGEMM_PIPE 1  // igemm_dma_kernel: fragment reads pipelined across the slab barrier (0: the round-2..5 loop)
+#endif
 #ifndef MSFWSI_FETCH_FIRST
 #define MSFWSI_FETCH_FIRST 1  // DMA requests of slab kt+2 before the MFMAs of slab kt (0: after them; A/B: make EXTRA=-DMSFWSI_FETCH_FIRST=0)
 #endif
@@ -981,55 +984,116 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
 
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+    // fragments of k-group `ks` (0 / 1) of the slab in stage `buf`
+    auto read_group = [&](int buf, int ks, frag_t(&xf)[TM], frag_t(&wf)[TN]) __attribute__((always_inline)) {
         const char* Ab = As + buf * Cfg::A_BYTES;
         const char* Bb = Bs + buf * Cfg::B_BYTES;
+        const int cidx = ks * 2 + lh;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row = (wm * TM + tm) * 32 + l31;
+            xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * 64 + swz(row, cidx) * 16);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int ncol = (wn * TN + tn) * 32;
+            if (!DGRAD) {
+                const int row = ncol + l31;
+                wf[tn] = *reinterpret_cast<const frag_t*>(Bb + row * 64 + swz(row, cidx) * 16);
+            } else if constexpr (sizeof(T) == 2) {
+                // transposed LDS read: 16-lane group G -> columns 16*(G&1).., k-half G>>1
+                const int li = lane & 15, G = lane >> 4;
+                const int q = li >> 2, p = li & 3;
+                const int kbase = ks * 16 + (G >> 1) * 8 + q;
+                const int cb = (ncol + (G & 1) * 16 + p * 4) * 2;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Bb + nat_off<ROWB>(kbase, cb)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Bb + nat_off<ROWB>(kbase + 4, cb)));
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                wf[tn] = __builtin_bit_cast(frag_t, both);
+            } else {
+                frag_t t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    t[e] = *reinterpret_cast<const float*>(Bb + nat_off<ROWB>(ks * 8 + lh * 4 + e, (ncol + l31) * 4));
+                wf[tn] = t;
+            }
+        }
+    };
+    auto mma_group = [&](const frag_t(&xf)[TM], const frag_t(&wf)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) mma_step<T>(acc[tn][tm], wf[tn], xf[tm]);
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             frag_t xf[TM], wf[TN];
-            const int cidx = ks * 2 + lh;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int row = (wm * TM + tm) * 32 + l31;
-                xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * 64 + swz(row, cidx) * 16);
-            }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int ncol = (wn * TN + tn) * 32;
-                if (!DGRAD) {
-                    const int row = ncol + l31;
-                    wf[tn] = *reinterpret_cast<const frag_t*>(Bb + row * 64 + swz(row, cidx) * 16);
-                } else if constexpr (sizeof(T) == 2) {
-                    // transposed LDS read: 16-lane group G -> columns 16*(G&1).., k-half G>>1
-                    const int li = lane & 15, G = lane >> 4;
-                    const int q = li >> 2, p = li & 3;
-                    const int kbase = ks * 16 + (G >> 1) * 8 + q;
-                    const int cb = (ncol + (G & 1) * 16 + p * 4) * 2;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(Bb + nat_off<ROWB>(kbase, cb)));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(Bb + nat_off<ROWB>(kbase + 4, cb)));
-                    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    wf[tn] = __builtin_bit_cast(frag_t, both);
-                } else {
-                    frag_t t;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        t[e] = *reinterpret_cast<const float*>(Bb + nat_off<ROWB>(ks * 8 + lh * 4 + e, (ncol + l31) * 4));
-                    wf[tn] = t;
-                }
-            }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) mma_step<T>(acc[tn][tm], wf[tn], xf[tm]);
+            read_group(buf, ks, xf, wf);
+            mma_group(xf, wf);
         }
     };
+    (void)compute;
 
     // ---------------- main loop: TWO slabs in flight, counted vmcnt ----------------
     const int nk = MSFWSI_ABLATE == 1 ? 0 : prm.Ktot / BK;
     constexpr int DMA_PER_SLAB = A_IT + NB;
     static_assert(DMA_PER_SLAB >= 2 && DMA_PER_SLAB <= 6, "unexpected DMA count per slab");
+#if MSFWSI_IGEMM_PIPE
+    // Fragment reads software-pipelined ACROSS the slab barrier, as in csrc/wgrad.hip's pixel loop (round 6): a slab's two
+    // k-groups live in two register sets; the reads of (slab kt, group 1) are issued before the MFMAs of (kt, group 0), the
+    // wave then waits for its DMA pieces of slab kt+1 and for its own outstanding reads, joins the barrier, requests slab
+    // kt+3 into the stage of slab kt (every wave has finished reading it: lgkmcnt(0) sits before the barrier) and reads
+    // (kt+1, group 0) before it runs the MFMAs of (kt, group 1).  Before: all fragment reads of a slab and an
+    // `s_waitcnt lgkmcnt(0)` stood between the barrier and the slab's first MFMA, for the four waves of a SIMD at once.
+    auto wait_slabs = [&](int n) __attribute__((always_inline)) {  // all but the youngest n slabs' pieces have landed
+        constexpr int D = DMA_PER_SLAB;
+        if (n >= 2) {
+            if constexpr (D == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (D == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if constexpr (D == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if (n == 1) {
+            if constexpr (D == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (D == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if constexpr (D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+    if (nk > 0) {
+        fetch(0);
+        if (nk > 1) fetch(1);
+        if (nk > 2) fetch(2);
+        wait_slabs(nk >= 3 ? 2 : nk - 1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        frag_t x0[TM], w0[TN], x1[TM], w1[TN];
+        read_group(0, 0, x0, w0);
+        int st_c = 0;
+        for (int kt = 0; kt + 1 < nk; ++kt) {  // (the last slab is peeled off: one straight-line body, one set of accumulators)
+            read_group(st_c, 1, x1, w1);
+            mma_group(x0, w0);
+            const int st_n = st_c == 2 ? 0 : st_c + 1;
+            wait_slabs(kt + 2 < nk ? 1 : 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 3 < nk) fetch(st_c);
+            read_group(st_n, 0, x0, w0);
+            mma_group(x1, w1);
+            st_c = st_n;
+        }
+        read_group(st_c, 1, x1, w1);
+        mma_group(x0, w0);
+        mma_group(x1, w1);
+    }
+#else
     if (nk > 0) fetch(0);
     if (nk > 1) fetch(1);
     int st_c = 0, st_f = 2;
@@ -1060,6 +1124,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         st_c = st_c == 2 ? 0 : st_c + 1;
         st_f = st_f == 2 ? 0 : st_f + 1;
     }
+#endif
     __syncthreads();
     igemm_epilogue<T, BM, BN, WM, WN, DGRAD, false, EPI>(acc, prm, smem, tile_m, m0, n0);
 }

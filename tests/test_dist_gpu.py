@@ -68,8 +68,11 @@ def _worker(rank, world, port, ret):
         if rank == 0:
             ret["loss"] = mean_loss
             ret["sd"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        if rank == world - 1:  # the replicas end the step bit-identical (checked against rank 0's below)
-            ret["sd_last"] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        if rank == world - 1:  # the replicas end the step bit-identical (checked against rank 0's below): digests, not 0.5 GB
+            import hashlib
+
+            ret["sd_last"] = {k: hashlib.sha256(v.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+                              for k, v in model.state_dict().items()}
         # a second step: the collective plan of the shape is known now, so the context views pair up too -- its count is
         # the steady state of a run (the first step's context passes ran one after the other to calibrate the plan)
         ts.step(local)
@@ -111,8 +114,10 @@ def test_ranks_match_single_process(hip_lib, world):
     assert len({ret[f"plan{r}"] for r in range(world)}) == 1
     print(f"world {world}: {ret['collectives0']} engine collectives per step, plan {ret['plan0']}")
 
+    import hashlib
+
     for k, v in ret["sd"].items():  # rank world-1 started from OTHER weights and buffers: bit-identical to rank 0 now
-        assert torch.equal(v, ret["sd_last"][k]), k
+        assert hashlib.sha256(v.contiguous().numpy().tobytes()).hexdigest() == ret["sd_last"][k], k
     oc = oracle_case(CASE)
     assert abs(ret["loss"] - oc["loss64"]) <= 1e-3 * max(abs(oc["loss64"]), 1e-2), (ret["loss"], oc["loss64"])
     sd2 = ret["sd"]
