@@ -562,8 +562,17 @@ def main():
         Bs, Ks, sk = ts.engine.last_shape
         plan8 = ts.engine.plan_preview(Bs, Ks, sk, dev, 8)  # with the 4 GiB RCCL reserve of a multi-rank run
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    replicas_equal = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # the replicas started from DIFFERENT seeds (build) and must have ended the run with equal weights: the checksum of the
+        # weights every kernel reads (the 16-bit copies where they exist, else the fp32 masters), MIN and MAX over the ranks
+        chk = torch.stack([(w16 if w16 is not None else w).double().abs().sum()
+                           for w, w16 in zip(ts.flats.w, ts.flats.w16)])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_equal = bool(torch.equal(lo, hi))
     dt = float(tmax.item())
 
     if rank == 0:
@@ -587,6 +596,9 @@ def main():
                        # device memory the communicators took outside torch's pool when they were created and probed
                        # (Engine.prepare_multirank: mem_get_info before / after)
                        "comm_GiB": round(ts.engine.comm_bytes / 2 ** 30, 2),
+                       # several ranks: the weights' checksum is the same on every rank after the run (the ranks were seeded
+                       # differently; PretrainStep's rank-0 broadcast and the gradient exchange keep them equal)
+                       "replicas_equal": replicas_equal,
                        # SyncBatchNorm exchanges (+ the plan) of the last step and the gradient exchange's messages
                        "collectives_per_step": run_collectives,
                        "gradient_messages_per_step": ts.reducer.launches_last_step,
