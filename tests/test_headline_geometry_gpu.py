@@ -176,3 +176,51 @@ def test_fault_in_image_kernel_bn_backward_is_caught(hip_lib, reproducible_sums,
     assert len(hits) >= 10, "the fault was never injected"
     with pytest.raises(AssertionError):
         _gate_lowp(vec, dtype, names, rels, fr, "fault injection (k2 x 1.5 in the image kernel's BatchNorm backward)")
+
+
+def test_resnet50_trunk_224_full_size_replicated(hip_lib, reproducible_sums, monkeypatch):
+    """The trunk AT THE FULL SIZE of BASELINE config 2's target pass -- 4 096 images of 224 x 224, bf16 -- on the engine's
+    NATURAL dispatch (nothing forced: at this size the image-stationary kernels fill the chip on their own, the by-product
+    activations exceed 1 GiB so the backward runs in image chunks, the 256 x 128 tiles and the 256 x 256 weight-gradient tile
+    are chosen by the launch geometry), tied to the reference fixture by a size-independent property: the batch is the
+    fixture's eight images REPEATED 512 times.  Train-mode BatchNorm over 512 identical copies of a batch has the statistics
+    of the batch, so every copy's features are the eight-image features and every parameter gradient of
+    L = sum_s <features_s, R_s (repeated)> is 512 x the eight-image gradient -- exactly, in exact arithmetic.  Gates: the
+    features of the first, a middle and the last copy and the gradients / 512 against the fp64 oracle of the eight images
+    (pinned to the reference's fp64 loss), with the same reference-under-autocast yardstick as the eight-image test."""
+    free, total = torch.cuda.mem_get_info()
+    if total < 250 * 2 ** 30:
+        pytest.skip("needs the 288 GB of an MI355X")
+    torch.cuda.empty_cache()
+    vec, man = load_golden(CASE)
+    calls = _count_launches(monkeypatch)
+    enc, sd0, x, Rs = _trunk_case(man)
+    f64, g64 = _trunk_oracle(sd0, x, Rs, want_loss=float(vec["loss"][0]))
+    REP, B = 512, man["B"]
+    enc = enc.cuda().train()
+    xr = x.cuda().repeat(REP, 1, 1, 1)
+    Rr = [r.cuda().repeat(REP, 1) for r in Rs]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        feats = enc(xr)
+    loss = sum((f.float() * r).sum() for f, r in zip(feats, Rr))
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f"[trunk 224 x {REP * B} images bf16] launches: {calls}; peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+    # the natural dispatch took the production kernels (whole-batch launches; the image-kernel backward in chunks)
+    assert calls.get("img3x3_fwd", 0) == 8 and calls.get("img3x3_s2_dgrad", 0) >= 2 and calls.get("img3x3_dgrad", 0) >= 11, calls
+    assert calls.get("panel_fwd_post", 0) == 12 and calls.get("panel_dgrad", 0) == 15 and calls.get("panel_gram", 0) == 5, calls
+    assert calls.get("stem_wgrad_bnbwd", 0) == 1 and calls.get("gap_fwd_stride2", 0) == 3, calls
+    tag = "bf16"
+    for copy in (0, REP // 2, REP - 1):
+        fr = np.array([rel(f[copy * B:(copy + 1) * B].float(), r) for f, r in zip(feats, f64)])
+        assert (fr <= np.maximum(LOWP_FLOOR[torch.bfloat16], 2.0 * vec[f"spread_feat_{tag}"])).all(), (copy, fr)
+    # every copy carries the same features up to the rounding of sums taken in another order
+    spread = max(rel(f[:B].float(), f[(REP - 1) * B:].float()) for f in feats)
+    assert spread <= 2 * LOWP_FLOOR[torch.bfloat16], spread
+    named = dict(enc.named_parameters())
+    names = man["param_keys"]
+    rels = np.array([rel(named[k].grad.double().cpu() / REP, g64[k]) for k in names])
+    lowp_gate(rels, names, vec[f"spread_grad_{tag}"], LOWP_FLOOR[torch.bfloat16],
+              f"resnet50 trunk 224x224, {REP * B} images (the fixture's eight x {REP}), bf16, natural dispatch: gradients / {REP}")
+    del feats, xr, Rr, enc
+    torch.cuda.empty_cache()

@@ -482,10 +482,14 @@ def test_config2_full_size_properties(hip_lib, freed):
     # model, fixture r50_b8_s64 -- so the embeddings themselves are not comparable between two bf16 evaluation orders)
     fr = [float((a - b).norm() / b.norm()) for a, b in zip(z_fold, z_expl)]
     print("   pooled-feature rel-L2, folded vs explicit:", [f"{v:.1e}" for v in fr])
-    # two bf16 evaluation orders of a 50-layer network: rounding-level after layers 1-2, a few per cent at layer 3 and
-    # ~1e-1 at layer 4 (each BatchNorm re-normalises, i.e. amplifies, the accumulated bf16 noise); a wrong statistic
-    # would be O(1) from the first folded block on (the statistics themselves: test_gram_statistics_... above)
-    assert max(fr[0], fr[1], fr[4], fr[5]) < 1e-2 and max(fr) < 0.25
+    # two bf16 evaluation orders of a 50-layer network: rounding-level after layers 1-2; on N(0,1) images the deeper
+    # features of two bf16 evaluation orders drift apart (each BatchNorm re-normalises, i.e. amplifies, the accumulated
+    # noise), which is why round 5 could only bound them by 0.25 -- a bound that catches nothing.  Round 6: the FULL-SIZE
+    # trunk is pinned to the reference instead (tests/test_headline_geometry_gpu.py::
+    # test_resnet50_trunk_224_full_size_replicated: 4 096 well-conditioned images, natural dispatch, every gradient tensor
+    # against the fp64 reference); what stays here is what only the whole model at 256 tile pairs can show -- the statistics
+    # of the shallow stages, the step's bookkeeping and the memory plan
+    assert max(fr[0], fr[1], fr[4], fr[5]) < 1e-2
     del z_fold, z_expl
     torch.cuda.empty_cache()
     loss = float(ts.step(batch))
