@@ -113,6 +113,15 @@ int msfwsi_stem_s2d_wfold(const float* dw2, float* dw, int K, void* stream);
 int msfwsi_conv_dgrad2(const msfwsi_conv_desc* d, const void* dy, const void* w_cat, void* dx, const void* src2, int C2,
                        const float* bias, const void* mask_c, const float* mask_scale, const float* mask_shift,
                        double* sums, int nshard, void* stream);
+/* The same with the second source given as the RAW conv output c2 [N,H,W,C2] of the layer whose BatchNorm + ReLU produces
+ * the operand: a2 = relu(pro_scale * c2 + pro_shift) (fp32 [C2] each; src/models/resnet.py:128-130) is formed on the
+ * fragments the kernel reads from LDS -- the arithmetic of msfwsi_bn_act, so the result is BIT FOR BIT that of
+ * msfwsi_conv_dgrad2 on the materialised a2 -- and a2 is neither written nor read: with mask_c = c2 (the gate of the
+ * folded tail's input gradient) the launch reads g and c2 and writes da2.  16-bit storage types; otherwise as
+ * msfwsi_conv_dgrad2 (MSFWSI_EUNSUPPORTED also when 2 C2 floats exceed the tile's reduction area in LDS). */
+int msfwsi_conv_dgrad2_pro(const msfwsi_conv_desc* d, const void* dy, const void* w_cat, void* dx, const void* c2, int C2,
+                           const float* pro_scale, const float* pro_shift, const float* bias, const void* mask_c,
+                           const float* mask_scale, const float* mask_shift, double* sums, int nshard, void* stream);
 
 /* ---- activation-stationary ("panel") 1x1 convolutions: short k, wide output (csrc/panel.hip) -------------------
  * For the w -> 4w / 4w <- w convolutions of a Bottleneck (src/models/resnet.py:124,131): the [128 x k] operand panel of

@@ -66,6 +66,7 @@ SIGNATURES = {
     "msfwsi_stem_s2d_wfold": [_vp, _vp, _i, _vp],
     "msfwsi_conv_fwd_post2": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "msfwsi_conv_dgrad2": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "msfwsi_conv_dgrad2_pro": [_desc, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_conv_fwd_post": [_desc, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "msfwsi_row_scale_cat": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "msfwsi_fold_dots": [_vp, _vp, _vp, _i, _i, _vp],

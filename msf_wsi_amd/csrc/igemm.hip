@@ -67,6 +67,8 @@ struct IgemmParams {
     int s_run;               //   is a run of s_run pixels x pix_stride channels, padded to C = a multiple of the slab)
     const void* src2;        // DGRAD 1x1 only, nullable: second source [M][C2] whose k-range follows the first
     int C2;                  //   (out = src . W[0:C] + src2 . W[C:C+C2]; Ktot = C + C2)
+    const float* pro2_scale; // nullable, [C2]: the second source is a RAW conv output c and the operand is relu(pro2_scale * c +
+    const float* pro2_shift; //   pro2_shift) -- formed on the fragments read from LDS (msfwsi_conv_dgrad2_pro), never stored
     unsigned char* gate_out;        // gate bytes of [M][Nout/VEC] chunks (layout: gate_off, common.h), nullable: bit e = (out[m][VEC*chunk+e] > 0)
     const unsigned char* mask_bits; // same layout, nullable: gates this gradient instead of mask_c (stats = {sum g, 0})
     int N, H, W, C;          // source tensor
@@ -769,10 +771,12 @@ __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, void* lds
 // RUN (stem): the S filter taps of one filter row are contiguous in NHWC memory when the channel count is one chunk
 // (7 taps x 8 padded channels = 56 elements), so a filter row is ONE tap whose "channels" are that run, padded to 64
 // with a zero weight column: the 7x7/C=3 stem becomes 7 taps x 2 slabs on this kernel instead of the generic one.
-template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, int EPI = 0, bool TWO = false, bool RUN = false>
+template <typename T, int BM, int BN, int WM, int WN, bool DGRAD, int EPI = 0, bool TWO = false, bool RUN = false, bool P2 = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmParams prm) {
     static_assert(!(TWO && !DGRAD && EPI != 1) && !(DGRAD && EPI != 0 && EPI != 3) && !(!DGRAD && EPI == 3),
                   "second source: input gradient or post-epilogue forward; post epilogue: forward; strided residual: dgrad");
+    static_assert(!P2 || (TWO && DGRAD && EPI == 0 && sizeof(T) == 2 && MSFWSI_IGEMM_PIPE),
+                  "BatchNorm + ReLU on the second source: two-source input gradient, 16-bit storage, pipelined loop");
     static_assert(!(RUN && (DGRAD || TWO || EPI != 0)), "run mode: plain forward only");
     typedef IgemmCfg<T, BM, BN, WM, WN, DGRAD, false> Cfg;
     constexpr int VEC = Cfg::VEC, BK = Cfg::BK, ROWB = Cfg::ROWB;
@@ -984,8 +988,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[a][b][j] = 0.f;
 
+    float* p2 = reinterpret_cast<float*>(smem + Cfg::MAIN_BYTES);  // [2][C2] (P2): the epilogue's reduction area
+    if constexpr (P2) {
+        for (int i = tid; i < prm.C2; i += 64 * NW) {
+            p2[i] = prm.pro2_scale[i];
+            p2[prm.C2 + i] = prm.pro2_shift[i];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // plain loads: done before the DMA pipeline's counted waits begin
+        __syncthreads();
+    }
+    (void)p2;
     // fragments of k-group `ks` (0 / 1) of the slab in stage `buf`
-    auto read_group = [&](int buf, int ks, frag_t(&xf)[TM], frag_t(&wf)[TN]) __attribute__((always_inline)) {
+    // (kslab: first k of the slab -- P2 only: a slab of the SECOND source (k >= C) holds a raw conv output, and the operand is
+    //  relu(scale * c + shift) of it, formed here on the fragment: the arithmetic of msfwsi_bn_act, so the values the MFMAs
+    //  see are bit for bit those of the materialised activation.  The per-channel scale / shift sit in the epilogue's
+    //  reduction area of LDS (free during the k loop): LDS reads, so the counted vmcnt of the DMA pipeline is untouched)
+    auto read_group = [&](int buf, int ks, frag_t(&xf)[TM], frag_t(&wf)[TN], int kslab) __attribute__((always_inline)) {
         const char* Ab = As + buf * Cfg::A_BYTES;
         const char* Bb = Bs + buf * Cfg::B_BYTES;
         const int cidx = ks * 2 + lh;
@@ -993,6 +1011,24 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         for (int tm = 0; tm < TM; ++tm) {
             const int row = (wm * TM + tm) * 32 + l31;
             xf[tm] = *reinterpret_cast<const frag_t*>(Ab + row * 64 + swz(row, cidx) * 16);
+        }
+        if constexpr (P2) {
+            if (kslab >= prm.C) {  // wave-uniform
+                const float* ps = p2 + (kslab - prm.C) + cidx * 8;
+                float sc[8], sh[8];
+                *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(ps);
+                *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(ps + 4);
+                *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(ps + prm.C2);
+                *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(ps + prm.C2 + 4);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    float f[8];
+                    unpack16<T>(__builtin_bit_cast(uint4, xf[tm]), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f);
+                    xf[tm] = __builtin_bit_cast(frag_t, pack16<T>(f));
+                }
+            }
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -1031,7 +1067,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             frag_t xf[TM], wf[TN];
-            read_group(buf, ks, xf, wf);
+            read_group(buf, ks, xf, wf, 0);
             mma_group(xf, wf);
         }
     };
@@ -1074,10 +1110,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         frag_t x0[TM], w0[TN], x1[TM], w1[TN];
-        read_group(0, 0, x0, w0);
+        read_group(0, 0, x0, w0, 0);
         int st_c = 0;
         for (int kt = 0; kt + 1 < nk; ++kt) {  // (the last slab is peeled off: one straight-line body, one set of accumulators)
-            read_group(st_c, 1, x1, w1);
+            read_group(st_c, 1, x1, w1, kt * BK);
             mma_group(x0, w0);
             const int st_n = st_c == 2 ? 0 : st_c + 1;
             wait_slabs(kt + 2 < nk ? 1 : 0);
@@ -1085,11 +1121,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const IgemmPara
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (kt + 3 < nk) fetch(st_c);
-            read_group(st_n, 0, x0, w0);
+            read_group(st_n, 0, x0, w0, (kt + 1) * BK);
             mma_group(x1, w1);
             st_c = st_n;
         }
-        read_group(st_c, 1, x1, w1);
+        read_group(st_c, 1, x1, w1, (nk - 1) * BK);
         mma_group(x0, w0);
         mma_group(x1, w1);
     }
@@ -1147,6 +1183,15 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
             if constexpr (DGRAD) {
                 kern = prm.src2 != nullptr ? igemm_dma_kernel<T, BM, BN, WM, WN, true, 0, true>
                                            : igemm_dma_kernel<T, BM, BN, WM, WN, true, 0, false>;
+                if (prm.pro2_scale != nullptr) {
+                    if constexpr (sizeof(T) == 2 && MSFWSI_IGEMM_PIPE) {
+                        if (prm.src2 == nullptr || prm.resid_stride > 1 || 2 * prm.C2 * (int)sizeof(float) > Cfg::RED_BYTES)
+                            return MSFWSI_EUNSUPPORTED;
+                        kern = igemm_dma_kernel<T, BM, BN, WM, WN, true, 0, true, false, true>;
+                    } else {
+                        return MSFWSI_EUNSUPPORTED;
+                    }
+                }
                 if (prm.resid_stride > 1) {
                     if (prm.src2 != nullptr) return MSFWSI_EUNSUPPORTED;
                     kern = igemm_dma_kernel<T, BM, BN, WM, WN, true, 3, false>;
@@ -1164,7 +1209,7 @@ int launch_igemm(IgemmParams& prm, hipStream_t stream) {
             }
         }
     }
-    if ((prm.src2 != nullptr || prm.resid_stride > 1) && !dma) return MSFWSI_EUNSUPPORTED;  // pure-DMA kernel features
+    if ((prm.src2 != nullptr || prm.resid_stride > 1 || prm.pro2_scale != nullptr) && !dma) return MSFWSI_EUNSUPPORTED;  // pure-DMA kernel features
     if (Cfg::LDS_BYTES > 64 * 1024) {
         if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES)) return e;
     }
@@ -1335,6 +1380,36 @@ extern "C" int msfwsi_conv_dgrad2(const msfwsi_conv_desc* d, const void* dy, con
     IgemmParams prm{};
     prm.src = dy; prm.wgt = w_cat; prm.out = dx;
     prm.src2 = src2; prm.C2 = C2; prm.bias = bias;
+    prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
+    prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
+    prm.N = d->N; prm.H = d->P; prm.W = d->Q; prm.C = d->K;
+    prm.P = d->H; prm.Q = d->W; prm.Nout = d->C;
+    prm.R = 1; prm.S = 1; prm.stride = 1; prm.pad = 0;
+    prm.M = d->N * d->H * d->W;
+    prm.Ktot = d->K + C2;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    MSFWSI_WITH_T(d->dtype, return dispatch_tile<T, true, false>(prm, st));
+    return MSFWSI_EINVAL;
+}
+
+extern "C" int msfwsi_conv_dgrad2_pro(const msfwsi_conv_desc* d, const void* dy, const void* w_cat, void* dx,
+                                      const void* c2, int C2, const float* pro_scale, const float* pro_shift,
+                                      const float* bias, const void* mask_c, const float* mask_scale,
+                                      const float* mask_shift, double* sums, int nshard, void* stream) {
+    int rc = check_desc(d);
+    if (rc != MSFWSI_OK) return rc;
+    MSFWSI_CHECK_ARG(dy != nullptr && w_cat != nullptr && dx != nullptr && c2 != nullptr && C2 > 0);
+    MSFWSI_CHECK_ARG(pro_scale != nullptr && pro_shift != nullptr);
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (mask_scale == nullptr) && (mask_c == nullptr) == (mask_shift == nullptr));
+    MSFWSI_CHECK_ARG((mask_c == nullptr) == (sums == nullptr) && (sums == nullptr || nshard >= 1));
+    // 16-bit storage, 1x1 / stride 1, whole k slabs in both ranges: the pure-DMA kernel's two-source instance
+    if (d->dtype == MSFWSI_DT_F32 || d->R != 1 || d->S != 1 || d->stride != 1 || d->pad != 0 || d->K % 32 != 0 ||
+        C2 % 32 != 0 || !g_fast_dma)
+        return MSFWSI_EUNSUPPORTED;
+    IgemmParams prm{};
+    prm.src = dy; prm.wgt = w_cat; prm.out = dx;
+    prm.src2 = c2; prm.C2 = C2; prm.bias = bias;
+    prm.pro2_scale = pro_scale; prm.pro2_shift = pro_shift;
     prm.mask_c = mask_c; prm.mask_scale = mask_scale; prm.mask_shift = mask_shift;
     prm.stats = sums; prm.nshard = nshard > 0 ? nshard : 1;
     prm.N = d->N; prm.H = d->P; prm.W = d->Q; prm.C = d->K;

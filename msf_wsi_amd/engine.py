@@ -299,7 +299,7 @@ class Engine:
     # attribute, and A/B scripts pass ONE variable, MSFWSI_ENGINE="name=value,name=value", checked against this table.
     # tests/test_options_gpu.py flips every one of them on a whole training step.
     OPTIONS = ("halo3x3", "fuse_pro3x3", "fold_bn3", "fuse_gate", "fold_bn3_fwd", "gate_bits", "fuse_two_source",
-               "panel_fwd", "panel_dgrad", "heads_on_streams", "img3x3", "img3x3_layer1", "img3x3_s2", "gap_stride_fused",
+               "dgrad2_pro", "dgrad2_pro_max_c", "panel_fwd", "panel_dgrad", "heads_on_streams", "img3x3", "img3x3_layer1", "img3x3_s2", "gap_stride_fused",
                "fuse_a2_wgrad", "fuse_a2_wgrad_max_c", "img3x3_chunk_bytes", "img3x3_min_fill", "panel_gram", "panel_fwd_min_k", "stem_run",
                "stem_s2d", "stem_fuse_bnbwd", "pair_head_wgrad", "pair_head_fwd", "bucket_inter", "store_head_wgrad", "fold_ds",
                "fold_ds_fwd", "fold_ds_strided", "lores_resid", "ctx_stream", "coalesce_views")
@@ -337,6 +337,14 @@ class Engine:
         # ... which also emits the block's closing ReLU gate as one byte per 16-byte chunk for the backward pass
         self.gate_bits = True
         self.fuse_two_source = True
+        # ... whose second source is conv2's RAW output, normalised inside the launch (msfwsi_conv_dgrad2_pro): a2 is not
+        # read there, and at 64 channels never stored
+        self.dgrad2_pro = True
+        # ... up to this width: at 64 channels (layer1, HBM-bound) the launch gets 13 % faster and a2 disappears (2.36 -> 2.06
+        # ms per N = 4096 launch, profiles/r06_kbench_dgrad2pro.txt); from 128 channels on the launches are bound by L2 ingest
+        # and issue slots, every column tile repeats the transform, and the saved read does not pay for it (1.19 -> 1.28 ms at
+        # 28 x 28, 0.77 -> 0.95 at 14 x 14)
+        self.dgrad2_pro_max_c = 64
         # activation-stationary ("panel") kernels for the short-k 1x1 convs of a Bottleneck (csrc/panel.hip): conv3's fused
         # tail reads conv2's RAW output (bn2 + ReLU applied while the panel is staged), conv1's input gradient forms bn1's
         # backward dc1 = k1*g + k2*c1 + k3 in its staging and writes it back once for the weight gradient
@@ -1443,22 +1451,39 @@ class Engine:
             sums = kn.new_stats(K, 3, dev)
             kn.block_end_bwd(dy, rec.y_out, gapg, 1.0 / rec.HW, None,
                              rec.ds.c if rec.ds is not None and not ds_fold else None, g, sums, rec.HW)
-        a2 = torch.empty_like(last.x)
         W = WeightStore.physical(last.op.weight).view(K, 1, 1, Cw)
         Mm = kn.zeros((K, 1, 1, Cw), torch.float32, dev)
+        # Round 6: the two-source launch below takes conv2's RAW output as its second source and forms a2 = relu(bn2(c2)) on
+        # the fragments it reads from LDS (msfwsi_conv_dgrad2_pro: the arithmetic of bn_act, bit for bit) -- the same tensor
+        # it reads for the gate.  a2 is then needed only by the M = g^T a2 launch: where that launch normalises its operand
+        # in its own staging (64 channels) a2 is never stored at all; elsewhere the bn_act pass stays (the DMA-staged
+        # weight-gradient kernel wants a materialised operand) but its output is read once instead of twice
+        src2_in_launch = (self.dgrad2_pro and Cw <= self.dgrad2_pro_max_c and self.fuse_two_source
+                          and dtype != torch.float32 and prev.c is last.x and last.x_pro is prev.st)
+        a2 = None
         fused_a2 = False
         if last.gram is not None:  # Gram matrix and column sums of a2 kept by the fused forward
             A, sa = last.gram
             # 64 channels (layer1, HBM-bound): M = g^T a2 with bn2 + ReLU applied in the weight-gradient kernel's register
-            # staging, which also writes a2 for the two-source launch below -- 1.41 (+ the write) against 0.68 + 1.57 ms of
-            # bn_act + the DMA-staged launch; wider layers lose with register staging (profiles/r05_kbench_mwgrad.txt)
-            fused_a2 = (self.fuse_a2_wgrad and Cw <= self.fuse_a2_wgrad_max_c and dtype != torch.float32
-                        and kn.conv_wgrad_act(d, last.x, g, Mm, (last.x_pro.scale, last.x_pro.shift), a2))
+            # staging (which also writes a2 where the two-source launch still wants it) -- 1.41 (+ the write) against
+            # 0.68 + 1.57 ms of bn_act + the DMA-staged launch; wider layers lose with register staging
+            # (profiles/r05_kbench_mwgrad.txt)
+            if self.fuse_a2_wgrad and Cw <= self.fuse_a2_wgrad_max_c and dtype != torch.float32:
+                if src2_in_launch:   # nobody reads a2: the same register-staged launch without the by-product
+                    kn.conv_wgrad(d, last.x, g, Mm, pro=(last.x_pro.scale, last.x_pro.shift))
+                    fused_a2 = True
+                else:
+                    a2 = torch.empty_like(last.x)
+                    fused_a2 = kn.conv_wgrad_act(d, last.x, g, Mm, (last.x_pro.scale, last.x_pro.shift), a2)
+                    if not fused_a2:
+                        a2 = None
             if not fused_a2:
+                a2 = torch.empty_like(last.x)
                 kn.bn_act(last.x, last.x_pro.scale, last.x_pro.shift, a2, relu=True)
         else:  # relu(bn2(c2)) and its column sums in one pass
             A = None
             sa = kn.zeros((Cw,), torch.float64, dev)
+            a2 = torch.empty_like(last.x)
             kn.bn_act_sum(last.x, last.x_pro.scale, last.x_pro.shift, a2, sa)
         if not fused_a2:
             kn.conv_wgrad(d, a2, g, Mm)
@@ -1482,10 +1507,16 @@ class Engine:
         kn.fold_weights(W, Mm, WA, k[0], k[1], k[2], sa, grads.get(last.op.weight), Wk1, Wk2, bvec)
         kn.conv_wgrad(dlin, W, Wk2, G)  # G[i][j] = sum_k k2[k] W[k][i] W[k][j]
         s2 = kn.new_stats(Cw, 2, dev)
-        da = torch.empty_like(a2)
+        da = torch.empty_like(last.x)
         gate = (prev.c, prev.st.scale, prev.st.shift)
         # one launch: da2 = gate([g | a2] . [k1 o W ; G] + W^T k3), the k range of a2 follows the one of g
         wcat = wcat32 if dtype == torch.float32 else kn.cast_lowp(wcat32, torch.empty_like(wcat32, dtype=dtype))
+        if src2_in_launch and kn.conv_dgrad2(d, g, wcat, da, last.x, bias=bvec, mask=gate, sums=s2,
+                                             src2_pro=(last.x_pro.scale, last.x_pro.shift)):
+            return g, da, s2, kd, resid_ds
+        if a2 is None:  # (the launch declined the shape after the weight gradient had skipped the by-product)
+            a2 = torch.empty_like(last.x)
+            kn.bn_act(last.x, last.x_pro.scale, last.x_pro.shift, a2, relu=True)
         if self.fuse_two_source and kn.conv_dgrad2(d, g, wcat, da, a2, bias=bvec, mask=gate, sums=s2):
             return g, da, s2, kd, resid_ds
         # shapes without a two-source kernel: the a2 term as a separate w -> w conv, added as the residual

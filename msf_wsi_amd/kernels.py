@@ -187,7 +187,8 @@ def _tuning(key: int) -> int:
 
 
 
-def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, epi: int = 0, two: bool = False) -> str:
+def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, epi: int = 0, two: bool = False,
+            p2: bool = False) -> str:
     """The mangled template-instance fragment of the kernel this launch reaches; mirrors dispatch_tile() /
     launch_igemm() (csrc/igemm.hip), msfwsi_conv_wgrad() (csrc/wgrad.hip) and conv3x3.hip.  Only used to label
     timings so that bench.py's roofline names the same kernel as the rocprofv3 summary."""
@@ -226,13 +227,13 @@ def _symbol(kind: str, d: ConvDesc, tcode: str, pro: bool, halo: bool = False, e
         tile = (128, 128, 2, 2)
     t = "Li%dELi%dELi%dELi%dE" % tile
     if not pro and _tuning(1) != 0 and csrc % bk == 0 and d.R * d.S <= 32:
-        return f"igemm_dma_kernelI{tcode}{t}Lb{int(dgrad)}ELi{epi}ELb{int(two)}ELb0E"
+        return f"igemm_dma_kernelI{tcode}{t}Lb{int(dgrad)}ELi{epi}ELb{int(two)}ELb0ELb{int(p2)}E"
     return f"igemm_kernelI{tcode}{t}Lb{int(dgrad)}ELb{int(pro)}E"
 
 
 def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = False, halo: bool = False,
            dtype=None, symbol_override: Optional[str] = None, epi: int = 0, two: bool = False, extra_k: int = 0,
-           same_operand: bool = False):
+           same_operand: bool = False, p2: bool = False):
     """extra_elems: elements of the additional activation-sized operands the launch reads (residual / identity, the
     gate's activation, the second source of a two-source launch) -- algorithmic bytes of the fused work, counted once
     each.  extra_k: the second source's reduction range (its FLOPs and weight bytes).  same_operand: a Gram launch
@@ -254,7 +255,7 @@ def _timed(kind, d: ConvDesc, esize: int, fn, extra_elems: int = 0, pro: bool = 
         e1.record()
     shape = f"N{d.N} {d.H}x{d.W} C{d.C}->K{d.K} {d.R}x{d.S}/s{d.stride}" + (" +src2" if two else "") + (
         f" epi{epi}" if epi else "") + (f" +{extra_elems * esize >> 20}MiB epilogue" if extra_elems else "")
-    TIMER.records.append((kind, symbol_override or _symbol(kind, d, tcode, pro, halo, epi, two), flops, nbytes, e0, e1,
+    TIMER.records.append((kind, symbol_override or _symbol(kind, d, tcode, pro, halo, epi, two, p2), flops, nbytes, e0, e1,
                           shape))
     return r
 
@@ -363,7 +364,7 @@ def stem_conv_fwd(x, w_run, y, stats, R, S, stride, pad, P: int = 0, Q: int = 0)
     ws = (x.element_size() == 2 and CP == 16 and K == 64 and (R, S, stride, pad) == (4, 4, 1, 2) and d.P == H and d.Q == W
           and W <= 128 and _tuning(12) != 0)  # mirrors msfwsi_stem_ws_fwd (csrc/stem.hip)
     _timed("conv_fwd", d, x.element_size(), run, dtype=x.dtype,
-           symbol_override=f"stem_ws_kernelI{tc}E" if ws else f"igemm_dma_kernelI{tc}Li128ELi64ELi2ELi2ELb0ELi0ELb0ELb1E")
+           symbol_override=f"stem_ws_kernelI{tc}E" if ws else f"igemm_dma_kernelI{tc}Li128ELi64ELi2ELi2ELb0ELi0ELb0ELb1ELb0E")
     return rc[0] == 0
 
 
@@ -621,12 +622,19 @@ def panel_dgrad(d: ConvDesc, dy, wpk, dx, bnbwd=None, dc_out=None, resid=None, r
     return True
 
 
-def conv_dgrad2(d: ConvDesc, dy, w_cat, dx, src2, bias=None, mask=None, sums=None) -> bool:
+def conv_dgrad2(d: ConvDesc, dy, w_cat, dx, src2, bias=None, mask=None, sums=None, src2_pro=None) -> bool:
     """dx = gate(dy . w_cat[0:K] + src2 . w_cat[K:] + bias) in one launch (1x1 only); False if the library has no
-    kernel for this shape (the caller then adds the second product as a residual)"""
+    kernel for this shape (the caller then adds the second product as a residual).
+    src2_pro = (scale, shift): src2 is a RAW conv output and the operand is relu(scale * src2 + shift), formed inside the
+    launch (msfwsi_conv_dgrad2_pro: bit for bit the result on the materialised activation, which is never stored)"""
     lib = _lib.load()
     dt = dy.dtype
     C2 = src2.shape[-1]
+    psc = psh = None
+    if src2_pro is not None:
+        psc, psh = src2_pro
+        _req(psc, "pro_scale", torch.float32, C2)
+        _req(psh, "pro_shift", torch.float32, C2)
     _req(dy, "dy", dt, d.N * d.P * d.Q * d.K)
     _req(w_cat, "w_cat", dt, (d.K + C2) * d.C)
     _req(dx, "dx", dt, d.N * d.H * d.W * d.C)
@@ -644,13 +652,21 @@ def conv_dgrad2(d: ConvDesc, dy, w_cat, dx, src2, bias=None, mask=None, sums=Non
     rc = [0]
 
     def run():
-        rc[0] = lib.msfwsi_conv_dgrad2(C.byref(d), _p(dy), _p(w_cat), _p(dx), _p(src2), int(C2), _p(bias), _p(mc), _p(msc),
-                                       _p(msh), _p(sums), nsh, _stream())
+        if psc is not None:
+            rc[0] = lib.msfwsi_conv_dgrad2_pro(C.byref(d), _p(dy), _p(w_cat), _p(dx), _p(src2), int(C2), _p(psc), _p(psh),
+                                               _p(bias), _p(mc), _p(msc), _p(msh), _p(sums), nsh, _stream())
+        else:
+            rc[0] = lib.msfwsi_conv_dgrad2(C.byref(d), _p(dy), _p(w_cat), _p(dx), _p(src2), int(C2), _p(bias), _p(mc), _p(msc),
+                                           _p(msh), _p(sums), nsh, _stream())
         if rc[0] != -2:
             _lib.check(rc[0], "conv_dgrad2")
 
+    # algorithmic bytes: with the operand formed in the launch AND the gate read from the same raw tensor, that tensor is one
+    # operand (counted once)
+    one_tensor = psc is not None and mask is not None and mask[0].data_ptr() == src2.data_ptr()
     _timed("conv_dgrad", d, dy.element_size(), run,
-           extra_elems=src2.numel() + (dx.numel() if mask is not None else 0), dtype=dt, two=True, extra_k=int(C2))
+           extra_elems=src2.numel() + (dx.numel() if mask is not None and not one_tensor else 0), dtype=dt, two=True,
+           extra_k=int(C2), p2=psc is not None)
     return rc[0] == 0
 
 

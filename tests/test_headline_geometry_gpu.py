@@ -52,13 +52,14 @@ def _count_launches(monkeypatch, fault=None):
                 a, k = fault(name, a, k)
             ok = real(*a, **k)
             if ok is not False:     # (False: the kernel declined the shape and the engine fell back)
-                calls[name] = calls.get(name, 0) + 1
+                key = name + ("_pro" if name == "conv_dgrad2" and k.get("src2_pro") is not None else "")
+                calls[key] = calls.get(key, 0) + 1
             return ok
 
         monkeypatch.setattr(kn, name, counted)
 
     for name in ("img3x3_fwd", "img3x3_dgrad", "img3x3_s2_dgrad", "panel_fwd_post", "panel_dgrad", "panel_gram",
-                 "gap_fwd_stride2", "conv3x3_fwd", "conv3x3_dgrad", "conv_wgrad_act", "stem_wgrad_bnbwd"):
+                 "gap_fwd_stride2", "conv3x3_fwd", "conv3x3_dgrad", "conv_wgrad_act", "stem_wgrad_bnbwd", "conv_dgrad2"):
         wrap(name)
     return calls
 
@@ -149,7 +150,10 @@ def test_resnet50_trunk_224_production_dispatch(hip_lib, reproducible_sums, monk
     # fused tails on the panel kernel: every Bottleneck without a downsample branch from 128 channels up (layer2-4: 3 + 5 + 2)
     # plus layer1's two at 64 channels where k >= panel_fwd_min_k allows; conv1's input gradients: all 16 blocks but the first
     assert calls.get("panel_fwd_post", 0) == 12 and calls.get("panel_dgrad", 0) == 15, calls
-    assert calls.get("panel_gram", 0) == 5 and calls.get("conv_wgrad_act", 0) == 3, calls
+    # the folded tails' two-source input gradients: layer1's three normalise conv2's raw output inside the launch (a2 is
+    # never stored: no by-product weight-gradient launch either), the other thirteen read the materialised a2
+    assert calls.get("panel_gram", 0) == 5 and calls.get("conv_dgrad2_pro", 0) == 3 and calls.get("conv_dgrad2", 0) == 13 + 4, calls  # (+ the four folded downsample branches)
+    assert calls.get("conv_wgrad_act", 0) == 0, calls
     assert calls.get("conv3x3_fwd", 0) == 3, calls   # layer1's conv2 forward stays weights-stationary
 
 

@@ -183,6 +183,58 @@ def test_conv_dgrad2_two_sources(hip_lib, dt, shape):
     assert torch.allclose(st[1], (got * c.to(dt).double()).sum(0), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(3, 10, 256, 64, 64), (2, 7, 512, 128, 128), (1, 5, 64, 32, 32), (2, 23, 256, 64, 64),
+                                   (1, 9, 2048, 512, 512), (5, 14, 1024, 256, 256)])
+@pytest.mark.parametrize("big", [False, True])
+def test_conv_dgrad2_second_source_normalised_in_the_launch(hip_lib, dt, shape, big):
+    """msfwsi_conv_dgrad2_pro: the second source is the RAW conv output c2 and the operand relu(scale * c2 + shift) is formed
+    on the fragments inside the launch -- BIT FOR BIT the result (output and BatchNorm sums) of msfwsi_conv_dgrad2 on the
+    activation msfwsi_bn_act materialises, with c2 also the gate's tensor as in the folded tail's backward
+    (src/models/resnet.py:128-131 backwards); both tile classes (big: the 256 x 128 / 8-wave tile forced); ragged last tile;
+    also against fp64"""
+    from helpers import tuned
+    from msf_wsi_amd import kernels as kn
+
+    N, H, K, Cc, C2 = shape
+    assert Cc == C2  # the folded tail: the gate's tensor IS the second source
+    g = torch.Generator().manual_seed(17)
+    M = N * H * H
+    dy = rnd((M, K), dt, g).to(dt).cuda()
+    c2 = rnd((M, C2), dt, g).to(dt).cuda()
+    W1 = rnd((K, Cc), dt, g, 1.0 / math.sqrt(K))
+    W2 = rnd((C2, Cc), dt, g, 1.0 / math.sqrt(C2))
+    bias = (torch.randn(Cc, generator=g) * 0.1).cuda()
+    sc, sh = (torch.rand(C2, generator=g) + 0.5).cuda(), (torch.randn(C2, generator=g) * 0.3).cuda()
+    wcat = torch.cat([W1, W2], 0).to(dt).cuda()
+    d = kn.conv_desc(dt, N, H, H, Cc, K, 1, 1, 1, 0)
+    with tuned(hip_lib, {0: 1} if big else {}):
+        a2 = torch.empty_like(c2)
+        kn.bn_act(c2, sc, sh, a2, relu=True)
+        want, got = torch.empty(M, Cc, dtype=dt, device="cuda"), torch.full((M, Cc), float("nan"), dtype=dt, device="cuda")
+        s_want, s_got = kn.new_stats(Cc), kn.new_stats(Cc)
+        assert kn.conv_dgrad2(d, dy, wcat, want, a2, bias=bias, mask=(c2, sc, sh), sums=s_want)
+        ok = kn.conv_dgrad2(d, dy, wcat, got, c2, bias=bias, mask=(c2, sc, sh), sums=s_got, src2_pro=(sc, sh))
+    torch.cuda.synchronize()
+    if not ok:
+        # the scale / shift vectors live in the tile's reduction area of LDS: the 128 x 64 tile of a small grid has room for
+        # 256 channels; wider second sources are DECLINED there (the engine then reads the materialised activation)
+        assert C2 > 256 and not big, shape
+        return
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(s_got.sum(0), s_want.sum(0))
+    a64 = torch.relu(c2.double() * sc.double() + sh.double()).to(dt).double()
+    ref = dy.double() @ wcat[:K].double() + a64 @ wcat[K:].double() + bias.double()
+    pre = c2.double() * sc.double() + sh.double()
+    refg = torch.where(pre > 0, ref.float().to(dt).double(), torch.zeros_like(ref)).cpu()
+    clear = (pre.abs() > 1e-3).cpu()
+    assert rel(torch.where(clear, got.double().cpu(), refg), refg) < tol(dt)
+    # fp32 storage has no such launch: the library declines, it does not fall back silently
+    d32 = kn.conv_desc(torch.float32, 1, 4, 4, 32, 32, 1, 1, 1, 0)
+    z = torch.zeros(16, 32, device="cuda")
+    assert not kn.conv_dgrad2(d32, z, torch.zeros(64, 32, device="cuda"), torch.empty_like(z), z, src2_pro=(sc[:32], sh[:32]))
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("hw", [(30, 30), (33, 17), (64, 64)])
 def test_stem_conv_as_row_runs(hip_lib, dt, hw):

@@ -26,7 +26,7 @@ STEP_CASE = "r18_b8_s64"
 
 # option -> the value it is flipped to (booleans: the opposite of the default) and the options that go with it
 TRUNK_FLIPS = {
-    "halo3x3": {}, "fuse_pro3x3": {}, "fuse_gate": {}, "gate_bits": {}, "fuse_two_source": {}, "panel_fwd": {},
+    "halo3x3": {}, "fuse_pro3x3": {}, "fuse_gate": {}, "gate_bits": {}, "fuse_two_source": {}, "dgrad2_pro": {}, "panel_fwd": {},
     "panel_dgrad": {}, "img3x3": {}, "img3x3_layer1": {}, "img3x3_s2": {}, "gap_stride_fused": {}, "fuse_a2_wgrad": {},
     "panel_gram": {}, "stem_run": {}, "stem_s2d": {}, "stem_fuse_bnbwd": {}, "lores_resid": {},
     "fold_bn3_fwd": {}, "fold_ds_fwd": {}, "fold_ds_strided": {},
@@ -34,6 +34,7 @@ TRUNK_FLIPS = {
     "fold_bn3": {"fold_bn3_fwd": False}, "fold_ds": {"fold_ds_fwd": False, "fold_ds_strided": False},
     "fuse_a2_wgrad_max_c": {"fuse_a2_wgrad_max_c": 256}, "img3x3_chunk_bytes": {"img3x3_chunk_bytes": 1 << 30},
     "img3x3_min_fill": {"img3x3_min_fill": 1e9}, "panel_fwd_min_k": {"panel_fwd_min_k": 64},
+    "dgrad2_pro_max_c": {"dgrad2_pro_max_c": 512},   # the in-launch normalisation of the second source at every width
 }
 STEP_FLIPS = ("heads_on_streams", "pair_head_wgrad", "pair_head_fwd", "bucket_inter", "store_head_wgrad", "ctx_stream",
               "coalesce_views")

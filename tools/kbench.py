@@ -431,7 +431,32 @@ def case_wgradreg():
         del x, dy, dw
 
 
-CASES = {"wgradreg": case_wgradreg, "mwgrad": case_mwgrad, "s2dgrad": case_s2dgrad, "gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
+def case_dgrad2pro():
+    """the folded tail's two-source input gradient: second source materialised (a2 read, c2 read as the gate's tensor) against
+    msfwsi_conv_dgrad2_pro (c2 read once: source and gate), and the bn_act pass the layer1 form no longer needs"""
+    for H, K, Cw in ((56, 256, 64), (28, 512, 128), (14, 1024, 256), (7, 2048, 512)):
+        N = NIMG
+        M = N * H * H
+        d = kn.conv_desc(DT, N, H, H, Cw, K, 1, 1, 1, 0)
+        g = rnd(M, K, scale=0.05)
+        c2 = rnd(M, Cw)
+        a2 = torch.empty_like(c2)
+        sc, sh = torch.ones(Cw, device="cuda"), torch.zeros(Cw, device="cuda")
+        wcat = rnd(K + Cw, Cw, scale=0.05)
+        bias = torch.zeros(Cw, device="cuda")
+        da = torch.empty(M, Cw, dtype=DT, device="cuda")
+        fl = 2.0 * M * (K + Cw) * Cw
+        report(f"dgrad2pro {H}x{H} bn_act (c2 -> a2)", timeit(lambda: kn.bn_act(c2, sc, sh, a2, relu=True)), 2 * M * Cw * 2)
+        report(f"dgrad2pro {H}x{H} g[{K}] a2[{Cw}] materialised, gate from c2",
+               timeit(lambda: kn.conv_dgrad2(d, g, wcat, da, a2, bias=bias, mask=(c2, sc, sh), sums=kn.new_stats(Cw, 2, "cuda"))),
+               (M * K + 3 * M * Cw) * 2, fl)
+        report(f"dgrad2pro {H}x{H} g[{K}] c2[{Cw}] normalised in the launch",
+               timeit(lambda: kn.conv_dgrad2(d, g, wcat, da, c2, bias=bias, mask=(c2, sc, sh), sums=kn.new_stats(Cw, 2, "cuda"),
+                                             src2_pro=(sc, sh))), (M * K + 2 * M * Cw) * 2, fl)
+        del g, c2, a2, da
+
+
+CASES = {"dgrad2pro": case_dgrad2pro, "wgradreg": case_wgradreg, "mwgrad": case_mwgrad, "s2dgrad": case_s2dgrad, "gramsplit": case_gramsplit, "s2pro": case_s2pro, "img3": case_img3, "panel": case_panel, "deep": case_deep, "epi3": case_epi3, "s2": case_s2, "wide": case_wide, "pool": case_pool, "fuser": case_fuser, "dma": case_dma}
 
 
 def main():
