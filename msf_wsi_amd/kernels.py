@@ -7,7 +7,6 @@ include/msfwsi_hip.h.  Nothing here computes on the CPU or through torch operato
 from __future__ import annotations
 
 import ctypes as C
-import os
 import threading
 from typing import Optional
 
