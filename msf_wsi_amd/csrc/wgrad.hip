@@ -852,33 +852,28 @@ int launch_wgrad(WgradParams& prm, int target_blocks, hipStream_t stream) {
     constexpr int lds_dma = WgradCfg<T, BI, BJ, false>::LDS_BYTES;
     constexpr int threads = 64 * Cfg::NW;
     const bool pro = prm.pro_scale != nullptr;
-    if constexpr (lds_dma > 65536 || lds_pro > 65536) {  // more than the default dynamic LDS limit: raise it once
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipSuccess;
-            if (lds_pro > 65536)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, true, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_pro);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, false, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_dma);
-            if (e != hipSuccess) return (int)e;
-            raised = true;
+    if constexpr (lds_dma > 65536 || lds_pro > 65536) {  // more than the default dynamic LDS limit: raised once per kernel
+        if constexpr (lds_pro > 65536) {
+            if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, true, false>), lds_pro)) return e;
         }
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, false, true>), lds_dma)) return e;
+        if (int e = msfwsi_raise_lds(reinterpret_cast<const void*>(wgrad_kernel<T, BI, BJ, false, false>), lds_dma)) return e;
     }
     // pixel splits: fill the resident workgroup slots once, never overshoot them (target_blocks > 0 overrides)
     long splits;
     if (target_blocks > 0) {
         splits = (target_blocks + tiles - 1) / tiles;
     } else {
-        static int slots_pro = 0, slots_dma = 0;  // same occupancy for the generic and the linear DMA instance
-        int& slots = pro ? slots_pro : slots_dma;
-        if (slots == 0)
+        // same occupancy for the generic and the linear DMA instance; two host threads of the process may launch at once
+        // (Engine._run_views): relaxed atomics, both would store the same value
+        static std::atomic<int> slots_pro{0}, slots_dma{0};
+        std::atomic<int>& cache = pro ? slots_pro : slots_dma;
+        int slots = cache.load(std::memory_order_relaxed);
+        if (slots == 0) {
             slots = pro ? resident_slots(wgrad_kernel<T, BI, BJ, true, false>, threads, lds_pro)
                         : resident_slots(wgrad_kernel<T, BI, BJ, false, true>, threads, lds_dma);
+            cache.store(slots, std::memory_order_relaxed);
+        }
         splits = slots / tiles;
         // Small launches (the context passes, N = 256): every split ends with an atomic add of its whole tile (fp64 for a
         // Gram matrix) -- at 196 rows per split the adds of a 256 x 256 tile move five times the bytes of the operands.  At
