@@ -1285,8 +1285,11 @@ class Engine:
         # head room: 6 GiB for the allocator's fragmentation; with more than one rank another 4 GiB for RCCL's channel
         # buffers and the IPC mappings of the peers, which are allocated outside torch's pool after this measurement
         # (prepare_multirank measured what the communicators took at creation -- already missing from `free`; the reserve
-        # covers what RCCL adds on first use of larger messages: at least 4 GiB, or as much again as creation took)
-        budget = avail - (6 << 30) - (max(4 << 30, self.comm_bytes) if self._world() > 1 else 0)
+        # covers what RCCL adds on first use: at least 4 GiB, or TWICE what creation took -- with real peers the channel
+        # buffers of four communicators are unmeasured here (one rank: 1.07 GiB), and a plan that is one allocation away from
+        # the card's limit dies inside RCCL, where nothing can fall back; the cost of being wrong the other way is the
+        # lockstep schedule instead of side streams, a few per cent)
+        budget = avail - (6 << 30) - (max(4 << 30, 2 * self.comm_bytes) if self._world() > 1 else 0)
         # calibration (ResNet-50, 256 tile pairs, bf16): kept activations 180 GiB, measured peak 240.8 GiB with
         # 28 GiB of weights/optimizer -> backward transients (gradient tensors, re-normalised operands, the
         # recomputed conv3) are about a quarter of one full target pass
