@@ -791,7 +791,6 @@ __global__ __launch_bounds__(64 * NWV) void panel_gram_kernel(const GramParams p
     float csum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) csum[e] = 0.f;
-    for (int i = tid; i < K; i += NT) colsum[i] = 0.f;
     f32x16 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
@@ -847,11 +846,23 @@ __global__ __launch_bounds__(64 * NWV) void panel_gram_kernel(const GramParams p
         }
         __syncthreads();  // every wave is done with the image before the next panel overwrites it
     }
-    // column sums: lanes with the same chunk column add into LDS, then one fp64 atomic per channel
+    // column sums: the NT / CPR threads that share a chunk column combine their partial sums in a FIXED order -- through the
+    // panel's LDS image, free after the loop's last barrier -- and one fp64 atomic per channel leaves the workgroup.  (Round 5
+    // combined them with fp32 atomic adds in LDS: 16-32 addends in arrival order, i.e. a column sum that differed in its last
+    // bits from run to run -- the seed of the run-to-run differences tools/race_check.py showed on the Bottleneck path: the
+    // sum feeds bn3's mean, and 16-bit storage amplifies one flipped rounding through every BatchNorm below it.)
+    {
+        float* part = reinterpret_cast<float*>(panel);  // [NT / CPR][K]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(colsum + cc * 8 + e, csum[e]);
-    __syncthreads();
-    for (int i = tid; i < K; i += NT) atomicAdd(prm.sums + i, (double)colsum[i]);
+        for (int e = 0; e < 8; ++e) part[rr * K + cc * 8 + e] = csum[e];
+        __syncthreads();
+        for (int i = tid; i < K; i += NT) {
+            double t = 0.0;
+            for (int r = 0; r < NT / CPR; ++r) t += (double)part[r * K + i];
+            atomicAdd(prm.sums + i, t);
+        }
+    }
+    (void)colsum;
     // D[i][j]: lane -> column j, registers -> rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll

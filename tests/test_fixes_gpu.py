@@ -404,3 +404,35 @@ def test_forward_is_reproducible_run_to_run(hip_lib, dtype):
             first = fo
         else:
             assert all(torch.equal(fo[k], first[k]) for k in fo), (r, [k for k in fo if not torch.equal(fo[k], first[k])][:3])
+
+
+def test_step_is_reproducible_run_to_run_with_one_split(hip_lib, reproducible_sums):
+    """Under `reproducible_sums` (one pixel split per weight-gradient tile) the whole forward + backward of the
+    ResNet-50-derived model repeats BIT FOR BIT: every gradient tensor of five runs on the same input.  The statistical
+    gates of the suite rest on that (one outcome per build, tests/conftest.py::reproducible_sums).  Round 5 broke it
+    unnoticed: the fused Gram pass (csrc/panel.hip, panel_gram_kernel) combined the column sums of a2 with fp32 atomic adds
+    in LDS -- 16-32 addends in arrival order -- so bn3's mean differed in its last bits from run to run, and 16-bit storage
+    amplified a flipped rounding to 5e-3 on the gradients of the layers below (tools/race_check.py, round 6: found with
+    tools/grad_repro_diag.py; the sums are now combined in a fixed order).  8 tile pairs: the target views' 128 images put
+    layer1 / layer2 on the fused Gram pass (several panels per workgroup)."""
+    from helpers import reference_loop_loss
+    from oracle import msfwsi_oracle as orc
+
+    (c1, c2), (t1, t2), idx = orc.diverse_batch(8, 64, 16, 0)
+    model = build_product("resnet50", residual_gain=0.1).cuda().train()
+    args = ((c1.cuda(), t1.cuda()), (c2.cuda(), t2.cuda()), idx)
+    first = None
+    for r in range(5):
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            outs = model(*args)
+        loss, _ = reference_loop_loss(outs)
+        loss.backward()
+        torch.cuda.synchronize()
+        gr = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        if first is None:
+            first = gr
+        else:
+            bad = [n for n in gr if not torch.equal(gr[n], first[n])]
+            assert not bad, (r, len(bad), bad[:4])

@@ -385,3 +385,29 @@ def test_panel_dgrad_pooled_gradient_from_lds(hip_lib, dt, geom, lowres):
     ref = dy.cpu().double() @ w.cpu().double() + res.reshape(M, Cin) + (gapg.cpu().double() / (H * W)).repeat_interleave(H * W, dim=0)
     ref = ref * unpack_bits(bits, M, Cin).double()
     assert rel(dx, ref) < tol(dt)
+
+
+@pytest.mark.parametrize("K", [64, 128])
+def test_panel_gram_sums_repeat_bit_for_bit(hip_lib, K):
+    """the fused Gram pass on the same operand twenty times: Gram matrix AND column sums equal bit for bit (the column sums
+    of round 5 met in LDS through fp32 atomic adds in arrival order: last-bit differences from run to run that the 16-bit
+    network amplified -- tests/test_fixes_gpu.py::test_step_is_reproducible_run_to_run_with_one_split)"""
+    from msf_wsi_amd import kernels as kn
+
+    g = torch.Generator().manual_seed(K)
+    M = 128 * 515 + 37                      # several panels per persistent workgroup, a ragged last one
+    c = (torch.randn(M, K, generator=g) * 1.7).to(torch.bfloat16).cuda()
+    sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3).cuda()
+    first = None
+    for _ in range(20):
+        A = torch.zeros(K, K, dtype=torch.float32, device="cuda")
+        sa = torch.zeros(K, dtype=torch.float64, device="cuda")
+        assert kn.panel_gram(c, sc, sh, A, sa)
+        torch.cuda.synchronize()
+        # (cross-workgroup sums are fp64 atomics: their order moves the result by ~1e-16, below the fp32 values the
+        #  engine rounds them to)
+        cur = (A.clone(), sa.float().clone())
+        if first is None:
+            first = cur
+        else:
+            assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])
